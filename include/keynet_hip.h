@@ -1,0 +1,134 @@
+/*
+ * keynet_hip.h -- C ABI of libkeynet_hip.so: the MI355X (gfx950) engine behind the keyed forward of visym/keynet.
+ *
+ * Drop-in boundary.  The reference has exactly one plug-in seam for the forward path: the object stored in
+ * KeyedLayer.W (keynet/layer.py:81-82), selected by layergen(..., backend=) (keynet/system.py:303-314), whose
+ * torchdot() is the hot loop (keynet/layer.py:92).  Each entry point below names the reference interface it
+ * replaces.  Plain pointers and sizes only; no torch / numpy / scipy types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns KN_OK (0) or a KN_ERR_* code; kn_last_error() gives the message (thread-local);
+ *     no C++ exception crosses the boundary.
+ *   - "host" pointers are ordinary CPU memory and are COPIED during the call (caller keeps ownership);
+ *     "dev" pointers are HIP device memory owned by the caller (PyTorch-ROCm allocations in the Python host).
+ *   - activations are FEATURE-MAJOR: X is [n_features, n_vecs] f32, element (f, b) at x[f*ldx + b].  This is the
+ *     layout the reference hands to scipy (x_affine.t() -> ravel, keynet/layer.py:92 + scipy _matmul_multivector).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All compute calls are asynchronous and
+ *     stream-ordered; a handle may be used from several streams/threads concurrently (it is immutable after create).
+ */
+#ifndef KEYNET_HIP_H
+#define KEYNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KN_ABI_VERSION 1
+
+enum kn_status {
+    KN_OK = 0,
+    KN_ERR_INVALID = 1,    /* bad argument (NULL, negative size, index out of range): the reference's `assert`s */
+    KN_ERR_SHAPE = 2,      /* non-conformal shapes: keynet/sparse.py:605 */
+    KN_ERR_HIP = 3,        /* a HIP runtime call failed (message has the hipError string) */
+    KN_ERR_NOMEM = 4,
+    KN_ERR_NODEVICE = 5,   /* no gfx950 device visible */
+    KN_ERR_UNSUPPORTED = 6
+};
+
+/* kn_spmm flags */
+#define KN_FLAG_RELU   1u  /* fuse torch.nn.functional.relu over the whole output incl. the homogeneous row
+                              (unkeyed nn.ReLU after a keyed layer: keynet/system.py:92; keyed ReLU: keynet/layer.py:93) */
+#define KN_FLAG_EXACT  2u  /* demand the reference's accumulation order and mul-then-add rounding (bit-exact with
+                              scipy csr_matvecs).  CSR operators always honour it; conv-tap operators switch from the
+                              MFMA path to the order-preserving path */
+
+typedef struct kn_operator* kn_handle_t;   /* opaque keyed operator resident in HBM */
+
+int         kn_abi_version(void);
+const char* kn_last_error(void);
+/* number of visible HIP devices and the gcnArchName of the current one (buf may be NULL) */
+int         kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len);
+
+/* ---- operators ---------------------------------------------------------------------------------------------- */
+
+/* Replaces keynet.sparse.SparseMatrix(A) for a scipy CSR matrix (keynet/sparse.py:419-425).
+ * indptr[rows+1], indices[nnz], data[nnz] are HOST arrays; the STORED order of each row is preserved on the device
+ * (keyed matrices are SpGEMM outputs: unsorted, non-canonical; sorting them changes results -- SURVEY 8c). */
+int kn_csr_create(int64_t rows, int64_t cols, int64_t nnz,
+                  const int32_t* indptr, const int32_t* indices, const float* data,
+                  kn_handle_t* out);
+
+/* Replaces keynet.sparse.TiledMatrix / DiagonalTiledMatrix (keynet/sparse.py:517-571, 657-687):
+ * blocks[nblocks][3] = (row0, col0, k) as iterated by __iter__; tile k = COO entries tile_ptr[k]..tile_ptr[k+1] of
+ * (tile_row, tile_col, tile_val) relative to the block origin.  Semantics = tosparse() (keynet/sparse.py:621-641). */
+int kn_tiled_create(int64_t rows, int64_t cols,
+                    int64_t nblocks, const int64_t* blocks,
+                    int64_t ntiles, const int64_t* tile_ptr,
+                    const int32_t* tile_row, const int32_t* tile_col, const float* tile_val,
+                    kn_handle_t* out);
+
+/* Replaces keynet.sparse.Conv2dTiledMatrix (keynet/sparse.py:690-776): spatial blocks x dense channel matrices.
+ *   inshape/outshape = (C,H,W); rows = Cout*Hout*Wout (+1), cols = Cin*Hin*Win (+1)
+ *   blocks[nblocks][3]   = (i, j, k) incl. the bias blocks (j == Cin*Hin*Win)             (sparse.py:753,773,776)
+ *   tile_keys[nent][3]   = (it, jt, k) in dict order                                      (sparse.py:764)
+ *   tile_isbias[nent]    = 1 for the 1x1 bias tiles                                       (sparse.py:767-772)
+ *   tile_chan            = f32[n_chan][Cout][Cin] for the non-bias entries, in tile_keys order
+ *   tile_bias            = f32[n_bias] for the bias entries, in tile_keys order
+ * Expansion rule (sparse.py:802-812): W[i+it+ic*HoWo, j+jt+jc*HiWi] = tile[(it,jt,k)][ic,jc]. */
+int kn_conv2dtiled_create(int64_t rows, int64_t cols,
+                          const int64_t inshape[3], const int64_t outshape[3],
+                          int64_t nblocks, const int64_t* blocks,
+                          int64_t nent, const int64_t* tile_keys, const uint8_t* tile_isbias,
+                          const float* tile_chan, const float* tile_bias,
+                          kn_handle_t* out);
+
+/* The same operator in factored form  W = sum_e coef_e * ( taps[tap_e] (x) E[out_e, in_e] )  + last column + e_last row,
+ * i.e. what Conv2dTiledMatrix stores after de-duplicating its channel matrices.  Used by the direct-to-tiled keying
+ * (never materialises the 15 G-nnz CSR of keyed VGG-16; keynet/layer.py:24-41 + sparse.py:720-776 collapsed).
+ *   taps      f32[ntaps][Cout][Cin]
+ *   ent_*     [nent]: output pixel (0..HoWo), input pixel (0..HiWi), tap id, coefficient
+ *   lastcol   f32[Cout*HoWo + 1] = W[:, Cin*HiWi] (bias column incl. the homogeneous 1 at the end), or NULL => no
+ *             homogeneous row/column at all (bias=False operators, rows == Cout*HoWo). */
+int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3],
+                       int64_t ntaps, const float* taps,
+                       int64_t nent, const int32_t* ent_out, const int32_t* ent_in, const int32_t* ent_tap, const float* ent_coef,
+                       const float* lastcol,
+                       kn_handle_t* out);
+
+int kn_destroy(kn_handle_t h);
+
+/* SparseMatrix.nnz / TiledMatrix.nnz / Conv2dTiledMatrix.nnz (keynet/sparse.py:494,649,778): stored parameters. */
+int kn_nnz(kn_handle_t h, int64_t* nnz);
+/* nnz of the expanded operator the reference applies (tocsr()), = the algorithmic MAC count per input vector */
+int kn_nnz_expanded(kn_handle_t h, int64_t* nnz);
+int kn_shape(kn_handle_t h, int64_t* rows, int64_t* cols);
+
+/* tocsr()/tocoo() (keynet/sparse.py:502-507, 643-647, 816-835): expanded operator into HOST buffers sized by
+ * kn_nnz_expanded (indptr[rows+1]).  CSR operators come back in stored order; tiled ones canonical (sorted). */
+int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data);
+
+/* ---- the hot path -------------------------------------------------------------------------------------------- */
+
+/* Replaces SparseMatrix.torchdot / TiledMatrix.torchdot (keynet/sparse.py:488-492, 603-612):
+ *   Y[rows, n_vecs] = W . X[cols, n_vecs]      (+ ReLU when KN_FLAG_RELU)
+ * x_dev/y_dev: device f32, feature-major, leading dimensions ldx/ldy >= n_vecs (floats).  x and y must not alias. */
+int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
+            float* y_dev, int64_t ldy, uint32_t flags, void* stream);
+
+/* unkeyed nn.ReLU on a whole activation block (keynet/system.py:92) when it could not be fused */
+int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream);
+
+/* keynet.torch.affine_to_linear (keynet/torch.py:65-68) fused with the x.t() of keynet/layer.py:92:
+ * x_dev [n, d] row-major images  ->  out_dev [d+1, n] feature-major with the ones row appended. */
+int kn_affine_to_linear(const float* x_dev, int64_t n, int64_t d, float* out_dev, int64_t ldo, void* stream);
+
+/* keynet.torch.linear_to_affine (keynet/torch.py:71-77): y_dev [d+1, n] feature-major -> out_dev [n, d] row-major;
+ * *maxdev_dev (device float, may be NULL) receives max_b |y[d, b] - 1| so the host can raise ValueError when > 1e-3. */
+int kn_linear_to_affine(const float* y_dev, int64_t ldy, int64_t n, int64_t d, float* out_dev, float* maxdev_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEYNET_HIP_H */

@@ -1,0 +1,194 @@
+"""ctypes binding of include/keynet_hip.h (the C ABI of libkeynet_hip.so).
+
+The product path has NO CPU fallback: if the shared library is missing or no gfx950 device is visible, every compute
+entry point raises.  (The CPU restatement lives in oracle/ and is test infrastructure only.)
+"""
+import os
+import ctypes
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, 'libkeynet_hip.so')
+
+KN_OK = 0
+KN_FLAG_RELU = 1
+KN_FLAG_EXACT = 2
+KN_ABI_VERSION = 1
+
+# every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
+SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
+           'kn_convtaps_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_relu',
+           'kn_affine_to_linear', 'kn_linear_to_affine']
+
+
+class KeynetHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises KeynetHipError loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise KeynetHipError('libkeynet_hip.so not found at %s: run `python -c "import __graft_entry__ as g; g.build()"` '
+                                 '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIBPATH)
+        L = ctypes.CDLL(LIBPATH)
+        (i64, p, u32, ci) = (ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int)
+        L.kn_abi_version.restype = ci
+        L.kn_last_error.restype = ctypes.c_char_p
+        L.kn_device_info.argtypes = [p, p, i64]
+        L.kn_csr_create.argtypes = [i64, i64, i64, p, p, p, p]
+        L.kn_tiled_create.argtypes = [i64, i64, i64, p, i64, p, p, p, p, p]
+        L.kn_conv2dtiled_create.argtypes = [i64, i64, p, p, i64, p, i64, p, p, p, p, p]
+        L.kn_convtaps_create.argtypes = [p, p, i64, p, i64, p, p, p, p, p, p]
+        L.kn_destroy.argtypes = [p]
+        L.kn_nnz.argtypes = [p, p]
+        L.kn_nnz_expanded.argtypes = [p, p]
+        L.kn_shape.argtypes = [p, p, p]
+        L.kn_export_csr.argtypes = [p, p, p, p]
+        L.kn_spmm.argtypes = [p, p, i64, i64, p, i64, u32, p]
+        L.kn_relu.argtypes = [p, i64, i64, i64, p]
+        L.kn_affine_to_linear.argtypes = [p, i64, i64, p, i64, p]
+        L.kn_linear_to_affine.argtypes = [p, i64, i64, i64, p, p, p]
+        for s in SYMBOLS:
+            if s not in ('kn_last_error',):
+                getattr(L, s).restype = ci
+        L.kn_last_error.restype = ctypes.c_char_p
+        if L.kn_abi_version() != KN_ABI_VERSION:
+            raise KeynetHipError('libkeynet_hip.so ABI %d != binding ABI %d: rebuild' % (L.kn_abi_version(), KN_ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != KN_OK:
+        msg = lib().kn_last_error()
+        raise KeynetHipError('libkeynet_hip: error %d: %s' % (rc, msg.decode() if msg else ''))
+
+
+def device_info():
+    n = ctypes.c_int(0)
+    buf = ctypes.create_string_buffer(64)
+    check(lib().kn_device_info(ctypes.byref(n), buf, 64))
+    return (n.value, buf.value.decode())
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return (a, a.ctypes.data_as(ctypes.c_void_p))
+
+
+class Operator(object):
+    """Owns one kn_handle_t (a keyed operator resident in HBM)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None) is not None and _lib is not None:
+                _lib.kn_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @staticmethod
+    def csr(shape, indptr, indices, data):
+        (ip, ipp) = _np(indptr, np.int32)
+        (ix, ixp) = _np(indices, np.int32)
+        (dt, dtp) = _np(data, np.float32)
+        h = ctypes.c_void_p()
+        check(lib().kn_csr_create(int(shape[0]), int(shape[1]), int(len(ix)), ipp, ixp, dtp, ctypes.byref(h)))
+        return Operator(h)
+
+    @staticmethod
+    def tiled(shape, blocks, tile_ptr, tile_row, tile_col, tile_val):
+        (bl, blp) = _np(np.asarray(blocks).reshape(-1, 3), np.int64)
+        (tp, tpp) = _np(tile_ptr, np.int64)
+        (tr, trp) = _np(tile_row, np.int32)
+        (tc, tcp) = _np(tile_col, np.int32)
+        (tv, tvp) = _np(tile_val, np.float32)
+        h = ctypes.c_void_p()
+        check(lib().kn_tiled_create(int(shape[0]), int(shape[1]), int(len(bl)), blp, int(len(tp) - 1), tpp, trp, tcp, tvp, ctypes.byref(h)))
+        return Operator(h)
+
+    @staticmethod
+    def conv2dtiled(shape, inshape, outshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias):
+        (bl, blp) = _np(np.asarray(blocks).reshape(-1, 3), np.int64)
+        (tk, tkp) = _np(np.asarray(tile_keys).reshape(-1, 3), np.int64)
+        (ib, ibp) = _np(tile_isbias, np.uint8)
+        (ch, chp) = _np(tile_chan, np.float32)
+        (bs, bsp) = _np(tile_bias, np.float32)
+        (ins, insp) = _np(inshape, np.int64)
+        (outs, outsp) = _np(outshape, np.int64)
+        h = ctypes.c_void_p()
+        check(lib().kn_conv2dtiled_create(int(shape[0]), int(shape[1]), insp, outsp, int(len(bl)), blp, int(len(tk)), tkp, ibp, chp, bsp, ctypes.byref(h)))
+        return Operator(h)
+
+    @staticmethod
+    def convtaps(inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol):
+        (ins, insp) = _np(inshape, np.int64)
+        (outs, outsp) = _np(outshape, np.int64)
+        (tp, tpp) = _np(taps, np.float32)
+        assert tp.ndim == 3 and tp.shape[1] == outs[0] and tp.shape[2] == ins[0], 'taps must be [ntaps, Cout, Cin]'
+        (eo, eop) = _np(ent_out, np.int32)
+        (ei, eip) = _np(ent_in, np.int32)
+        (et, etp) = _np(ent_tap, np.int32)
+        if ent_coef is None:
+            (ec, ecp) = (None, None)
+        else:
+            (ec, ecp) = _np(ent_coef, np.float32)
+        if lastcol is None:
+            (lc, lcp) = (None, None)
+        else:
+            (lc, lcp) = _np(lastcol, np.float32)
+            assert len(lc) == int(outs[0] * outs[1] * outs[2]) + 1
+        h = ctypes.c_void_p()
+        check(lib().kn_convtaps_create(insp, outsp, int(tp.shape[0]), tpp, int(len(eo)), eop, eip, etp, ecp, lcp, ctypes.byref(h)))
+        return Operator(h)
+
+    def nnz(self):
+        n = ctypes.c_int64(0)
+        check(lib().kn_nnz(self._h, ctypes.byref(n)))
+        return n.value
+
+    def nnz_expanded(self):
+        n = ctypes.c_int64(0)
+        check(lib().kn_nnz_expanded(self._h, ctypes.byref(n)))
+        return n.value
+
+    def shape(self):
+        (r, c) = (ctypes.c_int64(0), ctypes.c_int64(0))
+        check(lib().kn_shape(self._h, ctypes.byref(r), ctypes.byref(c)))
+        return (r.value, c.value)
+
+    def export_csr(self):
+        (rows, _) = self.shape()
+        n = self.nnz_expanded()
+        indptr = np.zeros(rows + 1, dtype=np.int32)
+        indices = np.zeros(max(n, 1), dtype=np.int32)
+        data = np.zeros(max(n, 1), dtype=np.float32)
+        check(lib().kn_export_csr(self._h, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p), data.ctypes.data_as(ctypes.c_void_p)))
+        return (indptr, indices[:n], data[:n])
+
+    def spmm(self, x_ptr, ldx, n_vecs, y_ptr, ldy, flags, stream):
+        check(lib().kn_spmm(self._h, x_ptr, int(ldx), int(n_vecs), y_ptr, int(ldy), int(flags), stream))
+
+
+def relu(y_ptr, rows, ld, n_vecs, stream):
+    check(lib().kn_relu(y_ptr, int(rows), int(ld), int(n_vecs), stream))
+
+
+def affine_to_linear(x_ptr, n, d, out_ptr, ldo, stream):
+    check(lib().kn_affine_to_linear(x_ptr, int(n), int(d), out_ptr, int(ldo), stream))
+
+
+def linear_to_affine(y_ptr, ldy, n, d, out_ptr, maxdev_ptr, stream):
+    check(lib().kn_linear_to_affine(y_ptr, int(ldy), int(n), int(d), out_ptr, maxdev_ptr, stream))

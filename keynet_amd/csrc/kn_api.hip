@@ -1,0 +1,520 @@
+// kn_api.hip -- extern "C" surface of libkeynet_hip.so (see include/keynet_hip.h for the reference interface each
+// entry point replaces).  Host-side conversion of the reference's operator containers into HBM-resident formats.
+#include "kn_internal.h"
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <unordered_map>
+
+namespace kn {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+static int ensure_device(int* dev) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(KN_ERR_NODEVICE, "no HIP device visible (libkeynet_hip.so needs an MI355X / gfx950)");
+    KN_HIP(hipGetDevice(dev));
+    return KN_OK;
+}
+
+// canonical (row, col)-sorted CSR from COO, duplicates summed in sorted order (scipy csr_matrix((v,(r,c))) semantics)
+static void coo_to_csr(int64_t rows, std::vector<int64_t>& r, std::vector<int64_t>& c, std::vector<float>& v, std::vector<int32_t>& indptr,
+                       std::vector<int32_t>& indices, std::vector<float>& data) {
+    const size_t n = r.size();
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return r[a] != r[b] ? r[a] < r[b] : c[a] < c[b]; });
+    indptr.assign((size_t)rows + 1, 0);
+    indices.clear();
+    data.clear();
+    indices.reserve(n);
+    data.reserve(n);
+    int64_t pr = -1, pc = -1;
+    for (size_t k = 0; k < n; k++) {
+        const size_t i = order[k];
+        if (r[i] == pr && c[i] == pc) {
+            data.back() = data.back() + v[i];
+        } else {
+            indices.push_back((int32_t)c[i]);
+            data.push_back(v[i]);
+            indptr[(size_t)r[i] + 1]++;
+            pr = r[i];
+            pc = c[i];
+        }
+    }
+    for (int64_t i = 0; i < rows; i++) indptr[(size_t)i + 1] += indptr[(size_t)i];
+}
+
+static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data,
+                           kn_operator** out) {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(rows >= 0 && cols >= 0 && nnz >= 0, KN_ERR_INVALID, "negative size");
+    KN_REQUIRE(rows < INT32_MAX && cols < INT32_MAX && nnz < INT32_MAX, KN_ERR_UNSUPPORTED, "int32 index range exceeded");
+    KN_REQUIRE(indptr && (nnz == 0 || (indices && data)), KN_ERR_INVALID, "NULL CSR array");
+    KN_REQUIRE(indptr[0] == 0 && indptr[rows] == nnz, KN_ERR_INVALID, "indptr does not span nnz");
+    for (int64_t i = 0; i < rows; i++) KN_REQUIRE(indptr[i] <= indptr[i + 1], KN_ERR_INVALID, "indptr not monotone");
+    for (int64_t k = 0; k < nnz; k++) KN_REQUIRE(indices[k] >= 0 && indices[k] < cols, KN_ERR_INVALID, "column index out of range");
+    int dev = 0;
+    int rc = ensure_device(&dev);
+    if (rc) return rc;
+    kn_operator* h = new kn_operator();
+    h->kind = KIND_CSR;
+    h->device = dev;
+    h->rows = rows;
+    h->cols = cols;
+    h->nnz_stored = nnz;
+    h->nnz_expanded = nnz;
+    h->csr.rows = rows;
+    h->csr.cols = cols;
+    h->csr.nnz = nnz;
+    if ((rc = upload(&h->csr.indptr, indptr, (size_t)rows + 1)) || (rc = upload(&h->csr.indices, indices, (size_t)nnz)) ||
+        (rc = upload(&h->csr.data, data, (size_t)nnz)) || (rc = csr_build_groups(h, indptr, indices, data))) {
+        csr_free(h->csr);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return KN_OK;
+}
+
+// expanded canonical CSR of a conv-taps operator (tocsr() of the equivalent Conv2dTiledMatrix)
+static void convtaps_expand(const kn_operator* h, const std::vector<int64_t>& last_rows, const std::vector<float>& last_vals,
+                            std::vector<int32_t>& indptr, std::vector<int32_t>& indices, std::vector<float>& data) {
+    const ConvTapsDev& c = h->ct;
+    const int64_t HoWo = c.Hout * c.Wout, HiWi = c.Hin * c.Win;
+    std::vector<int64_t> r, cc;
+    std::vector<float> v;
+    const size_t n = h->h_ent_out.size() * (size_t)(c.Cout * c.Cin) + last_rows.size();
+    r.reserve(n);
+    cc.reserve(n);
+    v.reserve(n);
+    for (size_t e = 0; e < h->h_ent_out.size(); e++) {
+        const float* T = h->h_taps.data() + (size_t)h->h_ent_tap[e] * (size_t)(c.Cout * c.Cin);
+        const float coef = h->h_ent_coef[e];
+        for (int64_t ic = 0; ic < c.Cout; ic++)
+            for (int64_t jc = 0; jc < c.Cin; jc++) {
+                r.push_back(h->h_ent_out[e] + ic * HoWo);
+                cc.push_back(h->h_ent_in[e] + jc * HiWi);
+                v.push_back(coef == 1.0f ? T[ic * c.Cin + jc] : coef * T[ic * c.Cin + jc]);
+            }
+    }
+    for (size_t k = 0; k < last_rows.size(); k++) {
+        r.push_back(last_rows[k]);
+        cc.push_back(c.Cin * HiWi);
+        v.push_back(last_vals[k]);
+    }
+    coo_to_csr(h->rows, r, cc, v, indptr, indices, data);
+}
+
+struct ConvBuild {
+    int64_t inshape[3], outshape[3];
+    std::vector<float> taps;   // [ntaps][Cout][Cin]
+    std::vector<int32_t> ent_out, ent_in, ent_tap;
+    std::vector<float> ent_coef;
+    bool has_last = false;
+    std::vector<int64_t> last_rows;   // explicit entries of the last column (row, value), may hold explicit zeros
+    std::vector<float> last_vals;
+    int64_t nnz_stored = 0;
+};
+
+static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
+    *out = nullptr;
+    const int64_t Cin = b.inshape[0], Hin = b.inshape[1], Win = b.inshape[2];
+    const int64_t Cout = b.outshape[0], Hout = b.outshape[1], Wout = b.outshape[2];
+    KN_REQUIRE(Cin > 0 && Hin > 0 && Win > 0 && Cout > 0 && Hout > 0 && Wout > 0, KN_ERR_INVALID, "non-positive shape");
+    const int64_t HoWo = Hout * Wout, HiWi = Hin * Win;
+    const int64_t rows = Cout * HoWo + (b.has_last ? 1 : 0), cols = Cin * HiWi + (b.has_last ? 1 : 0);
+    KN_REQUIRE(rows < INT32_MAX && cols < INT32_MAX, KN_ERR_UNSUPPORTED, "int32 index range exceeded");
+    const int64_t ntaps = (int64_t)(b.taps.size() / (size_t)(Cout * Cin));
+    const size_t nent = b.ent_out.size();
+    for (size_t e = 0; e < nent; e++) {
+        KN_REQUIRE(b.ent_out[e] >= 0 && b.ent_out[e] < HoWo, KN_ERR_INVALID, "entry output pixel out of range");
+        KN_REQUIRE(b.ent_in[e] >= 0 && b.ent_in[e] < HiWi, KN_ERR_INVALID, "entry input pixel out of range");
+        KN_REQUIRE(b.ent_tap[e] >= 0 && b.ent_tap[e] < ntaps, KN_ERR_INVALID, "entry tap id out of range");
+    }
+    for (size_t k = 0; k < b.last_rows.size(); k++) KN_REQUIRE(b.last_rows[k] >= 0 && b.last_rows[k] < rows, KN_ERR_INVALID, "last-column row out of range");
+    int dev = 0;
+    int rc = ensure_device(&dev);
+    if (rc) return rc;
+
+    kn_operator* h = new kn_operator();
+    h->kind = KIND_CONVTAPS;
+    h->device = dev;
+    h->rows = rows;
+    h->cols = cols;
+    ConvTapsDev& c = h->ct;
+    c.Cin = Cin; c.Hin = Hin; c.Win = Win; c.Cout = Cout; c.Hout = Hout; c.Wout = Wout;
+    c.ntaps = ntaps;
+    const int64_t KC = Cin >= 16 ? 16 : 4;
+    const int64_t MT = Cout > 64 ? 128 : 64;
+    c.cin_pad = (Cin + KC - 1) / KC * KC;
+    c.cout_pad = (Cout + MT - 1) / MT * MT;
+    c.has_last = b.has_last;
+
+    // transposed, zero-padded taps; zero taps contribute nothing and are dropped from the compute lists
+    std::vector<float> tapsT((size_t)(std::max<int64_t>(ntaps, 1) * c.cin_pad * c.cout_pad), 0.0f);
+    std::vector<char> tap_zero((size_t)std::max<int64_t>(ntaps, 1), 1);
+    for (int64_t t = 0; t < ntaps; t++)
+        for (int64_t co = 0; co < Cout; co++)
+            for (int64_t ci = 0; ci < Cin; ci++) {
+                const float w = b.taps[(size_t)((t * Cout + co) * Cin + ci)];
+                tapsT[(size_t)((t * c.cin_pad + ci) * c.cout_pad + co)] = w;
+                if (w != 0.0f) tap_zero[(size_t)t] = 0;
+            }
+    // slots grouped by output pixel, ascending input pixel inside a pixel
+    std::vector<size_t> order;
+    order.reserve(nent);
+    for (size_t e = 0; e < nent; e++)
+        if (!tap_zero[(size_t)b.ent_tap[e]] && b.ent_coef[e] != 0.0f) order.push_back(e);
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+        return b.ent_out[x] != b.ent_out[y] ? b.ent_out[x] < b.ent_out[y] : b.ent_in[x] < b.ent_in[y];
+    });
+    std::vector<int32_t> pix_ptr((size_t)HoWo + 1, 0), slot_in(order.size()), slot_tap(order.size()), pix_order((size_t)HoWo);
+    std::vector<float> slot_coef(order.size());
+    c.unit_coef = true;
+    for (size_t k = 0; k < order.size(); k++) {
+        const size_t e = order[k];
+        pix_ptr[(size_t)b.ent_out[e] + 1]++;
+        slot_in[k] = b.ent_in[e];
+        slot_tap[k] = b.ent_tap[e];
+        slot_coef[k] = b.ent_coef[e];
+        if (b.ent_coef[e] != 1.0f) c.unit_coef = false;
+    }
+    int mx = 0;
+    for (int64_t o = 0; o < HoWo; o++) {
+        mx = std::max(mx, pix_ptr[(size_t)o + 1]);
+        pix_ptr[(size_t)o + 1] += pix_ptr[(size_t)o];
+    }
+    c.max_slots = mx;
+    c.nslots = (int64_t)order.size();
+    std::iota(pix_order.begin(), pix_order.end(), 0);
+    std::vector<float> lastcol;
+    if (b.has_last) {
+        lastcol.assign((size_t)rows, 0.0f);
+        for (size_t k = 0; k < b.last_rows.size(); k++) lastcol[(size_t)b.last_rows[k]] += b.last_vals[k];
+    }
+    h->h_ent_out = b.ent_out;
+    h->h_ent_in = b.ent_in;
+    h->h_ent_tap = b.ent_tap;
+    h->h_ent_coef = b.ent_coef;
+    h->h_taps = b.taps;
+    // last column kept as explicit (row,value) pairs packed in h_lastcol as [row0,val0,row1,val1,...] bit patterns
+    h->h_lastcol.resize(b.last_rows.size() * 2);
+    for (size_t k = 0; k < b.last_rows.size(); k++) {
+        const int32_t rr = (int32_t)b.last_rows[k];
+        std::memcpy(&h->h_lastcol[2 * k], &rr, 4);
+        h->h_lastcol[2 * k + 1] = b.last_vals[k];
+    }
+    h->nnz_expanded = (int64_t)nent * Cout * Cin + (int64_t)b.last_rows.size();
+    h->nnz_stored = b.nnz_stored > 0 ? b.nnz_stored : ntaps * Cout * Cin + (int64_t)nent + (int64_t)b.last_rows.size();
+
+    if ((rc = upload(&c.tapsT, tapsT.data(), tapsT.size())) || (rc = upload(&c.pix_ptr, pix_ptr.data(), pix_ptr.size())) ||
+        (rc = upload(&c.slot_in, slot_in.data(), slot_in.size())) || (rc = upload(&c.slot_tap, slot_tap.data(), slot_tap.size())) ||
+        (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
+        (rc = upload(&c.lastcol, lastcol.data(), lastcol.size()))) {
+        convtaps_free(c);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return KN_OK;
+}
+
+static void last_pairs(const kn_operator* h, std::vector<int64_t>& rows, std::vector<float>& vals) {
+    const size_t n = h->h_lastcol.size() / 2;
+    rows.resize(n);
+    vals.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        int32_t rr;
+        std::memcpy(&rr, &h->h_lastcol[2 * k], 4);
+        rows[k] = rr;
+        vals[k] = h->h_lastcol[2 * k + 1];
+    }
+}
+
+static int get_exact_twin(kn_operator* h, kn_operator** twin) {
+    std::lock_guard<std::mutex> g(h->lazy_mu);
+    if (!h->exact) {
+        std::vector<int32_t> ip, ix;
+        std::vector<float> dt;
+        std::vector<int64_t> lr;
+        std::vector<float> lv;
+        last_pairs(h, lr, lv);
+        convtaps_expand(h, lr, lv, ip, ix, dt);
+        kn_operator* t = nullptr;
+        int rc = csr_create_impl(h->rows, h->cols, (int64_t)ix.size(), ip.data(), ix.data(), dt.data(), &t);
+        if (rc) return rc;
+        h->exact = t;
+    }
+    *twin = h->exact;
+    return KN_OK;
+}
+
+}  // namespace kn
+
+using namespace kn;
+
+extern "C" {
+
+int kn_abi_version(void) { return KN_ABI_VERSION; }
+
+const char* kn_last_error(void) { return g_err.c_str(); }
+
+int kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (n_devices) *n_devices = n;
+    if (arch_buf && arch_buf_len > 0) {
+        arch_buf[0] = 0;
+        if (n > 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+                std::strncpy(arch_buf, prop.gcnArchName, (size_t)arch_buf_len - 1);
+                arch_buf[arch_buf_len - 1] = 0;
+            }
+        }
+    }
+    return KN_OK;
+}
+
+int kn_csr_create(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data, kn_handle_t* out) {
+    return csr_create_impl(rows, cols, nnz, indptr, indices, data, out);
+}
+
+int kn_tiled_create(int64_t rows, int64_t cols, int64_t nblocks, const int64_t* blocks, int64_t ntiles, const int64_t* tile_ptr,
+                    const int32_t* tile_row, const int32_t* tile_col, const float* tile_val, kn_handle_t* out) {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(rows >= 0 && cols >= 0 && nblocks >= 0 && ntiles >= 0, KN_ERR_INVALID, "negative size");
+    KN_REQUIRE((nblocks == 0 || blocks) && tile_ptr, KN_ERR_INVALID, "NULL tile array");
+    std::vector<int64_t> r, c;
+    std::vector<float> v;
+    int64_t stored = tile_ptr[ntiles] - tile_ptr[0];
+    for (int64_t b = 0; b < nblocks; b++) {
+        const int64_t i = blocks[3 * b], j = blocks[3 * b + 1], k = blocks[3 * b + 2];
+        KN_REQUIRE(k >= 0 && k < ntiles, KN_ERR_INVALID, "block references a missing tile");
+        for (int64_t e = tile_ptr[k]; e < tile_ptr[k + 1]; e++) {
+            const int64_t rr = i + tile_row[e], cc = j + tile_col[e];
+            KN_REQUIRE(rr >= 0 && rr < rows && cc >= 0 && cc < cols, KN_ERR_INVALID, "tile entry outside the matrix");
+            r.push_back(rr);
+            c.push_back(cc);
+            v.push_back(tile_val[e]);
+        }
+    }
+    std::vector<int32_t> ip, ix;
+    std::vector<float> dt;
+    coo_to_csr(rows, r, c, v, ip, ix, dt);
+    int rc = csr_create_impl(rows, cols, (int64_t)ix.size(), ip.data(), ix.data(), dt.data(), out);
+    if (rc == KN_OK) (*out)->nnz_stored = stored;
+    return rc;
+}
+
+int kn_conv2dtiled_create(int64_t rows, int64_t cols, const int64_t inshape[3], const int64_t outshape[3], int64_t nblocks, const int64_t* blocks,
+                          int64_t nent, const int64_t* tile_keys, const uint8_t* tile_isbias, const float* tile_chan, const float* tile_bias,
+                          kn_handle_t* out) {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(inshape && outshape && (nblocks == 0 || blocks) && (nent == 0 || (tile_keys && tile_isbias)), KN_ERR_INVALID, "NULL argument");
+    const int64_t Cin = inshape[0], HiWi = inshape[1] * inshape[2], Cout = outshape[0], HoWo = outshape[1] * outshape[2];
+    const bool has_last = (rows == Cout * HoWo + 1);
+    KN_REQUIRE(rows == Cout * HoWo + (has_last ? 1 : 0) && cols == Cin * HiWi + (has_last ? 1 : 0), KN_ERR_SHAPE,
+               "matrix shape does not match inshape/outshape (keynet/sparse.py:731-736)");
+    ConvBuild b;
+    for (int k = 0; k < 3; k++) {
+        b.inshape[k] = inshape[k];
+        b.outshape[k] = outshape[k];
+    }
+    b.has_last = has_last;
+    // entries by tile id; channel matrices de-duplicated by content
+    std::unordered_map<int64_t, std::vector<int64_t>> by_k;
+    std::vector<int64_t> chan_idx((size_t)nent, -1);
+    int64_t nc = 0, nb = 0;
+    const size_t msz = (size_t)(Cout * Cin);
+    std::map<std::string, int32_t> dedup;
+    std::vector<int32_t> tap_of((size_t)nent, -1);
+    std::vector<float> bias_of((size_t)nent, 0.0f);
+    int64_t stored = 0;
+    for (int64_t e = 0; e < nent; e++) {
+        by_k[tile_keys[3 * e + 2]].push_back(e);
+        if (tile_isbias[e]) {
+            KN_REQUIRE(tile_bias != nullptr, KN_ERR_INVALID, "bias tiles without tile_bias");
+            bias_of[(size_t)e] = tile_bias[nb++];
+            stored += 1;
+        } else {
+            KN_REQUIRE(tile_chan != nullptr, KN_ERR_INVALID, "channel tiles without tile_chan");
+            const float* m = tile_chan + (size_t)nc * msz;
+            nc++;
+            std::string key(reinterpret_cast<const char*>(m), msz * sizeof(float));
+            auto it = dedup.find(key);
+            if (it == dedup.end()) {
+                const int32_t id = (int32_t)dedup.size();
+                dedup.emplace(std::move(key), id);
+                b.taps.insert(b.taps.end(), m, m + msz);
+                tap_of[(size_t)e] = id;
+            } else {
+                tap_of[(size_t)e] = it->second;
+            }
+            stored += (int64_t)msz;
+        }
+    }
+    b.nnz_stored = stored;
+    for (int64_t bl = 0; bl < nblocks; bl++) {
+        const int64_t i = blocks[3 * bl], j = blocks[3 * bl + 1], k = blocks[3 * bl + 2];
+        auto it = by_k.find(k);
+        if (it == by_k.end()) continue;
+        for (int64_t e : it->second) {
+            const int64_t itl = tile_keys[3 * e], jtl = tile_keys[3 * e + 1];
+            if (tile_isbias[e]) {
+                KN_REQUIRE(has_last && j + jtl == Cin * HiWi, KN_ERR_INVALID, "bias tile outside the last column (keynet/sparse.py:773)");
+                KN_REQUIRE(i + itl >= 0 && i + itl < rows, KN_ERR_INVALID, "bias tile row out of range");
+                b.last_rows.push_back(i + itl);
+                b.last_vals.push_back(bias_of[(size_t)e]);
+            } else {
+                KN_REQUIRE(i + itl >= 0 && i + itl < HoWo && j + jtl >= 0 && j + jtl < HiWi, KN_ERR_INVALID,
+                           "spatial tile entry outside the channel-(0,0) plane");
+                b.ent_out.push_back((int32_t)(i + itl));
+                b.ent_in.push_back((int32_t)(j + jtl));
+                b.ent_tap.push_back(tap_of[(size_t)e]);
+                b.ent_coef.push_back(1.0f);
+            }
+        }
+    }
+    return convtaps_create_impl(b, out);
+}
+
+int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int64_t ntaps, const float* taps, int64_t nent, const int32_t* ent_out,
+                       const int32_t* ent_in, const int32_t* ent_tap, const float* ent_coef, const float* lastcol, kn_handle_t* out) {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(inshape && outshape && ntaps >= 0 && nent >= 0, KN_ERR_INVALID, "bad argument");
+    KN_REQUIRE((ntaps == 0 || taps) && (nent == 0 || (ent_out && ent_in && ent_tap)), KN_ERR_INVALID, "NULL array");
+    ConvBuild b;
+    for (int k = 0; k < 3; k++) {
+        b.inshape[k] = inshape[k];
+        b.outshape[k] = outshape[k];
+    }
+    const int64_t Cout = outshape[0], Cin = inshape[0];
+    KN_REQUIRE(Cout > 0 && Cin > 0, KN_ERR_INVALID, "non-positive channels");
+    b.taps.assign(taps, taps + (size_t)(ntaps * Cout * Cin));
+    b.ent_out.assign(ent_out, ent_out + nent);
+    b.ent_in.assign(ent_in, ent_in + nent);
+    b.ent_tap.assign(ent_tap, ent_tap + nent);
+    if (ent_coef) b.ent_coef.assign(ent_coef, ent_coef + nent);
+    else b.ent_coef.assign((size_t)nent, 1.0f);
+    b.has_last = lastcol != nullptr;
+    if (lastcol) {
+        const int64_t rows = Cout * outshape[1] * outshape[2] + 1;
+        for (int64_t r = 0; r < rows; r++)
+            if (lastcol[r] != 0.0f) {
+                b.last_rows.push_back(r);
+                b.last_vals.push_back(lastcol[r]);
+            }
+    }
+    return convtaps_create_impl(b, out);
+}
+
+int kn_destroy(kn_handle_t h) {
+    if (!h) return KN_OK;
+    if (h->exact) kn_destroy(h->exact);
+    csr_free(h->csr);
+    convtaps_free(h->ct);
+    delete h;
+    return KN_OK;
+}
+
+int kn_nnz(kn_handle_t h, int64_t* nnz) {
+    KN_REQUIRE(h && nnz, KN_ERR_INVALID, "NULL argument");
+    *nnz = h->nnz_stored;
+    return KN_OK;
+}
+
+int kn_nnz_expanded(kn_handle_t h, int64_t* nnz) {
+    KN_REQUIRE(h && nnz, KN_ERR_INVALID, "NULL argument");
+    *nnz = h->nnz_expanded;
+    return KN_OK;
+}
+
+int kn_shape(kn_handle_t h, int64_t* rows, int64_t* cols) {
+    KN_REQUIRE(h && rows && cols, KN_ERR_INVALID, "NULL argument");
+    *rows = h->rows;
+    *cols = h->cols;
+    return KN_OK;
+}
+
+int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data) {
+    KN_REQUIRE(h && indptr, KN_ERR_INVALID, "NULL argument");
+    if (h->kind == KIND_CSR) {
+        KN_HIP(hipMemcpy(indptr, h->csr.indptr, sizeof(int32_t) * (size_t)(h->rows + 1), hipMemcpyDeviceToHost));
+        if (h->csr.nnz > 0) {
+            KN_REQUIRE(indices && data, KN_ERR_INVALID, "NULL argument");
+            KN_HIP(hipMemcpy(indices, h->csr.indices, sizeof(int32_t) * (size_t)h->csr.nnz, hipMemcpyDeviceToHost));
+            KN_HIP(hipMemcpy(data, h->csr.data, sizeof(float) * (size_t)h->csr.nnz, hipMemcpyDeviceToHost));
+        }
+        return KN_OK;
+    }
+    std::vector<int32_t> ip, ix;
+    std::vector<float> dt;
+    std::vector<int64_t> lr;
+    std::vector<float> lv;
+    last_pairs(h, lr, lv);
+    convtaps_expand(h, lr, lv, ip, ix, dt);
+    KN_REQUIRE((int64_t)ix.size() == h->nnz_expanded, KN_ERR_UNSUPPORTED, "duplicate (row,col) entries in a conv-taps operator: expanded nnz differs");
+    std::memcpy(indptr, ip.data(), sizeof(int32_t) * ip.size());
+    if (!ix.empty()) {
+        KN_REQUIRE(indices && data, KN_ERR_INVALID, "NULL argument");
+        std::memcpy(indices, ix.data(), sizeof(int32_t) * ix.size());
+        std::memcpy(data, dt.data(), sizeof(float) * dt.size());
+    }
+    return KN_OK;
+}
+
+int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, void* stream) {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    KN_REQUIRE(n_vecs >= 0, KN_ERR_INVALID, "negative n_vecs");
+    if (n_vecs == 0 || h->rows == 0) return KN_OK;
+    KN_REQUIRE(x_dev && y_dev, KN_ERR_INVALID, "NULL activation pointer");
+    KN_REQUIRE(ldx >= n_vecs && ldy >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
+    KN_REQUIRE(n_vecs < INT32_MAX, KN_ERR_UNSUPPORTED, "n_vecs too large");
+    KN_REQUIRE(x_dev != y_dev, KN_ERR_INVALID, "x and y alias");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (h->kind == KIND_CSR) return csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    if (flags & KN_FLAG_EXACT) {
+        kn_operator* t = nullptr;
+        int rc = get_exact_twin(h, &t);
+        if (rc) return rc;
+        return csr_spmm(t->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    }
+    return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+}
+
+int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream) {
+    KN_REQUIRE(y_dev || rows * n_vecs == 0, KN_ERR_INVALID, "NULL pointer");
+    KN_REQUIRE(ld >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
+    return relu_inplace(y_dev, rows, ld, n_vecs, reinterpret_cast<hipStream_t>(stream));
+}
+
+int kn_affine_to_linear(const float* x_dev, int64_t n, int64_t d, float* out_dev, int64_t ldo, void* stream) {
+    KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
+    KN_REQUIRE((x_dev || n * d == 0) && (out_dev || n == 0), KN_ERR_INVALID, "NULL pointer");
+    KN_REQUIRE(ldo >= n, KN_ERR_SHAPE, "leading dimension smaller than n");
+    return affine_to_linear(x_dev, n, d, out_dev, ldo, reinterpret_cast<hipStream_t>(stream));
+}
+
+int kn_linear_to_affine(const float* y_dev, int64_t ldy, int64_t n, int64_t d, float* out_dev, float* maxdev_dev, void* stream) {
+    KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
+    KN_REQUIRE((y_dev || n == 0) && (out_dev || n * d == 0), KN_ERR_INVALID, "NULL pointer");
+    KN_REQUIRE(ldy >= n, KN_ERR_SHAPE, "leading dimension smaller than n");
+    return linear_to_affine(y_dev, ldy, n, d, out_dev, maxdev_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// kn_conv.hip -- keyed block-Toeplitz conv operator on gfx950 matrix cores (f32-input MFMA, exact f32 products).
+//
+// Replaces TiledMatrix.torchdot for a Conv2dTiledMatrix (keynet/sparse.py:603-612 + 781-835).  The reference rebuilds
+// the full CSR from (blocks, tiles) on every call and runs csr_matvecs; the operator it applies is
+//     W[o + co*HoWo, i + ci*HiWi] = sum_{entries e=(o,i)} coef_e * taps[tap_e][co][ci]     (+ last column, + e_last row)
+// i.e. a permuted/keyed im2col convolution.  Here it is an implicit GEMM per OUTPUT PIXEL o:
+//     Y[co, o, b] = sum_{slots s of o} sum_ci  tapsT[tap_s][ci][co] * ( coef_s * X[ci*HiWi + in_s, b] )
+//   M = Cout (tile MT), N = batch columns (tile NB, contiguous in HBM: one gathered X row = one coalesced segment),
+//   K = slots(o) x Cin, walked in chunks of KC input channels of one slot.
+// Per workgroup (4 wavefronts): the tap tile [KC][MT] and the gathered X tile [KC][NB] are staged in LDS (double
+// buffered, one barrier per chunk, next chunk's global loads in flight during the MFMAs); each wavefront owns a
+// (TM*32)x(TN*32) sub-tile as TMxTN accumulators of v_mfma_f32_32x32x2_f32; A/B fragments are conflict-free
+// ds_read_b32 (lane&31 -> consecutive dwords, lane>>5 -> k).  Epilogue fuses the bias column (homogeneous coordinate),
+// ReLU and the store (each accumulator register = two coalesced 128-byte row segments).
+// Work items (pixel, batch tile, Cout tile) are dealt to the 8 XCDs in contiguous chunks with the Cout tile fastest,
+// so the workgroups that share one gathered X tile run on one XCD and hit its L2.
+#include "kn_internal.h"
+
+namespace kn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* tapsT;
+    const int32_t* pix_ptr;
+    const int32_t* slot_in;
+    const int32_t* slot_tap;
+    const float* slot_coef;
+    const int32_t* pix_order;
+    const float* lastcol;
+    const float* X;
+    float* Y;
+    int64_t ldx, ldy;
+    int32_t cin_pad, cout_pad, Cin, Cout, HiWi, HoWo;
+    int32_t n_vecs, relu, unit_coef, vec_ok;
+    int32_t n_mt, n_bt, n_pix;
+    int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
+};
+
+template <int MT, int NB, int KC, int WM, int WN>
+__global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int TM = MT / WM / 32;
+    constexpr int TN = NB / WN / 32;
+    constexpr int A4 = KC * MT / 4;                 // float4s in the A tile
+    constexpr int B4 = KC * NB / 4;
+    constexpr int AL = (A4 + 255) / 256;            // float4 loads per thread
+    constexpr int BL = (B4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB];
+    float* As = lds;                  // [2][KC][MT]
+    float* Bs = lds + 2 * KC * MT;    // [2][KC][NB]
+
+    // ---- work item ------------------------------------------------------------------------------------------
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t item = xl * chunk + (blockIdx.x >> 3);
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    const int mt = (int)(item % p.n_mt);
+    const int64_t t1 = item / p.n_mt;
+    const int pi = (int)(t1 % p.n_pix);
+    const int bt = (int)(t1 / p.n_pix);
+    const int o = p.pix_order[pi];
+    const int m0 = mt * MT;
+    const int b0 = bt * NB;
+    const int s_beg = p.pix_ptr[o];
+    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    const int cpk = p.cin_pad / KC;
+    const int n_chunks = n_slots * cpk;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    float4 ra[AL], rb[BL];
+
+    auto gload = [&](int q) {
+        const int s = s_beg + q / cpk;
+        const int ci0 = (q % cpk) * KC;
+        const int tap = p.slot_tap[s];
+        const int in = p.slot_in[s];
+        const float coef = p.unit_coef ? 1.0f : p.slot_coef[s];
+        const float* abase = p.tapsT + ((int64_t)tap * p.cin_pad + ci0) * p.cout_pad + m0;
+#pragma unroll
+        for (int i = 0; i < AL; i++) {
+            const int f = tid + i * 256;
+            if (A4 % 256 == 0 || f < A4) {
+                const int r = f / (MT / 4);
+                const int c4 = f % (MT / 4);
+                ra[i] = *reinterpret_cast<const float4*>(abase + (int64_t)r * p.cout_pad + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BL; i++) {
+            const int f = tid + i * 256;
+            if (B4 % 256 == 0 || f < B4) {
+                const int r = f / (NB / 4);
+                const int c4 = f % (NB / 4);
+                const int ci = ci0 + r;
+                const int b = b0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ci < p.Cin) {
+                    const float* src = p.X + ((int64_t)ci * p.HiWi + in) * p.ldx + b;
+                    if (p.vec_ok) {
+                        if (b < p.n_vecs) v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (b + 0 < p.n_vecs) v.x = src[0];
+                        if (b + 1 < p.n_vecs) v.y = src[1];
+                        if (b + 2 < p.n_vecs) v.z = src[2];
+                        if (b + 3 < p.n_vecs) v.w = src[3];
+                    }
+                    if (!p.unit_coef) {
+                        v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * KC * MT;
+        float* b = Bs + buf * KC * NB;
+#pragma unroll
+        for (int i = 0; i < AL; i++) {
+            const int f = tid + i * 256;
+            if (A4 % 256 == 0 || f < A4) *reinterpret_cast<float4*>(a + f * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BL; i++) {
+            const int f = tid + i * 256;
+            if (B4 % 256 == 0 || f < B4) *reinterpret_cast<float4*>(b + f * 4) = rb[i];
+        }
+    };
+
+    if (n_chunks > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int arow = lane >> 5;
+    const int acol = wm * (TM * 32) + (lane & 31);
+    const int bcol = wn * (TN * 32) + (lane & 31);
+    for (int q = 0; q < n_chunks; q++) {
+        const int buf = q & 1;
+        if (q + 1 < n_chunks) gload(q + 1);
+        const float* a = As + buf * KC * MT;
+        const float* b = Bs + buf * KC * NB;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = a[(kk + arow) * MT + acol + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = b[(kk + arow) * NB + bcol + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (q + 1 < n_chunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias column (x homogeneous coordinate), ReLU, store --------------------------------------
+    const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx) : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = b0 + wn * (TN * 32) + j * 32 + (lane & 31);
+        if (n >= p.n_vecs) continue;
+        const float xl1 = xlast ? xlast[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Cout) {
+                    const int64_t row = (int64_t)m * p.HoWo + o;
+                    float v = acc[i][j][r];
+                    if (xlast) {
+                        const float bp = p.lastcol[row] * xl1;
+                        v = v + bp;
+                    }
+                    if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+                    p.Y[row * p.ldy + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
+__global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
+                                                           float* __restrict__ ylast, int64_t n_vecs, int relu) {
+    const float w = lastcol[out_last];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vecs; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = w * xlast[i];
+        if (relu) v = (v < 0.0f) ? 0.0f : v;
+        ylast[i] = v;
+    }
+}
+
+void convtaps_free(ConvTapsDev& c) {
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    c = ConvTapsDev();
+}
+
+template <int MT, int NB, int KC, int WM, int WN>
+static void launch_conv(const ConvArgs& a, hipStream_t s) {
+    const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
+    const int64_t grid = ((items + 7) / 8) * 8;
+    hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, a);
+}
+
+int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
+                  uint32_t flags, hipStream_t s) {
+    (void)rows;
+    (void)cols;
+    ConvArgs a;
+    a.tapsT = A.tapsT;
+    a.pix_ptr = A.pix_ptr;
+    a.slot_in = A.slot_in;
+    a.slot_tap = A.slot_tap;
+    a.slot_coef = A.slot_coef;
+    a.pix_order = A.pix_order;
+    a.lastcol = A.has_last ? A.lastcol : nullptr;
+    a.X = x;
+    a.Y = y;
+    a.ldx = ldx;
+    a.ldy = ldy;
+    a.cin_pad = (int32_t)A.cin_pad;
+    a.cout_pad = (int32_t)A.cout_pad;
+    a.Cin = (int32_t)A.Cin;
+    a.Cout = (int32_t)A.Cout;
+    a.HiWi = (int32_t)(A.Hin * A.Win);
+    a.HoWo = (int32_t)(A.Hout * A.Wout);
+    a.n_vecs = (int32_t)n_vecs;
+    a.relu = (flags & KN_FLAG_RELU) ? 1 : 0;
+    a.unit_coef = A.unit_coef ? 1 : 0;
+    a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
+    a.n_pix = a.HoWo;
+    a.last_in_row = A.Cin * A.Hin * A.Win;
+    const bool big_m = A.cout_pad % 128 == 0 && A.Cout > 64;
+    const bool k16 = A.cin_pad % 16 == 0;
+    if (big_m) {
+        a.n_mt = (int32_t)(A.cout_pad / 128);
+        a.n_bt = (int32_t)((n_vecs + 127) / 128);
+        if (k16) launch_conv<128, 128, 16, 2, 2>(a, s);
+        else launch_conv<128, 128, 4, 2, 2>(a, s);
+    } else {
+        a.n_mt = (int32_t)(A.cout_pad / 64);
+        a.n_bt = (int32_t)((n_vecs + 255) / 256);
+        if (k16) launch_conv<64, 256, 16, 1, 4>(a, s);
+        else launch_conv<64, 256, 4, 1, 4>(a, s);
+    }
+    if (A.has_last) {
+        const int64_t out_last = A.Cout * A.Hout * A.Wout;
+        hipLaunchKernelGGL(conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
+                           x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+    }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+}  // namespace kn

@@ -1,0 +1,352 @@
+// kn_csr.hip -- order-preserving CSR x dense-block product for gfx950 (MI355X).
+//
+// Replaces scipy's csr_matvecs behind keynet.sparse.SparseMatrix.torchdot (keynet/sparse.py:488-492):
+//     for each row i, for jj in STORED order:  y[i,:] = y[i,:] + (a_jj * x[col_jj,:])      (f32 mul, then f32 add; no FMA)
+// Parallel over rows and over batch columns, strictly serial over the stored non-zeros of a row, so every output
+// element sees exactly the rounding sequence of the reference (bit-exact; tests/test_parity_gpu.py).
+//
+// HBM/L2 layout: X is feature-major [cols, n_vecs] (batch contiguous): one gathered row of X is one coalesced
+// 64*VEC*4-byte segment per wavefront.  Two kernels:
+//   * csr_rows_kernel   one wavefront per row ("loose" rows): a wave streams the row's (col,val) pairs 64 at a time
+//                       with one coalesced load, broadcasts them with v_readlane, gathers X rows.
+//   * csr_group_kernel  rows that share one column sequence (the Cout rows of a conv output pixel; every row of a
+//                       dense Linear) are processed RB at a time from ONE gather of X: RB*VEC accumulators per lane,
+//                       values streamed as wave-uniform scalars.  Cuts vector-memory traffic per MAC by RB.
+// Work items are dealt to XCDs in contiguous chunks (blockIdx%8 labels the XCD) so that the blocks resident on one
+// XCD share a batch-column tile of X in that XCD's 4 MiB L2.
+#include "kn_internal.h"
+#include <unordered_map>
+#include <algorithm>
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace kn {
+
+static constexpr int WAVES = 4;  // wavefronts (rows / row-bundles) per 256-thread workgroup
+static constexpr int RB = 8;     // rows per bundle in the grouped kernel
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using T = float; };
+template <> struct VecT<2> { using T = float2; };
+template <> struct VecT<4> { using T = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&d)[VEC], const float* p) {
+    if constexpr (VEC == 1) {
+        d[0] = *p;
+    } else if constexpr (VEC == 2) {
+        float2 v = *reinterpret_cast<const float2*>(p);
+        d[0] = v.x; d[1] = v.y;
+    } else {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&d)[VEC]) {
+    if constexpr (VEC == 1) {
+        *p = d[0];
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}
+
+__device__ __forceinline__ float relu_f(float v) { return (v < 0.0f) ? 0.0f : v; }  // torch relu: NaN stays NaN
+
+// item -> (column tile, row block): XCD lane x = bid&7 owns the contiguous item range [x*chunk, (x+1)*chunk)
+__device__ __forceinline__ bool decode_item(int64_t n_items, int64_t& item) {
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t x = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    item = x * chunk + q;
+    const int64_t hi = (x + 1) * chunk < n_items ? (x + 1) * chunk : n_items;
+    return item < hi;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict__ row_list, int64_t n_rows,
+                                                       const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                       const float* __restrict__ data, const float* __restrict__ X, int64_t ldx,
+                                                       float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu, int64_t n_rb) {
+    const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
+    int64_t item;
+    if (!decode_item(n_ct * n_rb, item)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t ri = rb * WAVES + wave;
+    if (ri >= n_rows) return;
+    const int row = row_list ? row_list[ri] : (int)ri;
+    const int64_t c = ct * (64 * VEC) + (int64_t)lane * VEC;
+    const bool active = c < n_vecs;        // n_vecs % VEC == 0 is guaranteed by the launcher
+    const int start = indptr[row];
+    const int end = indptr[row + 1];
+    const float* xc = X + (active ? c : 0);
+
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) acc[v] = 0.0f;
+
+    for (int base = start; base < end; base += 64) {
+        const int n = (end - base) < 64 ? (end - base) : 64;   // wave-uniform
+        int mycol = 0;
+        float myval = 0.0f;
+        if (lane < n) {
+            mycol = indices[base + lane];
+            myval = data[base + lane];
+        }
+        int i = 0;
+        for (; i + 8 <= n; i += 8) {
+            float xv[8][VEC];
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int col = __builtin_amdgcn_readlane(mycol, i + u);
+                a[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), i + u));
+                load_vec<VEC>(xv[u], xc + (int64_t)col * ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const float p = a[u] * xv[u][v];
+                    acc[v] = acc[v] + p;
+                }
+            }
+        }
+        for (; i < n; i++) {
+            const int col = __builtin_amdgcn_readlane(mycol, i);
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), i));
+            float xv[VEC];
+            load_vec<VEC>(xv, xc + (int64_t)col * ldx);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const float p = a * xv[v];
+                acc[v] = acc[v] + p;
+            }
+        }
+    }
+    if (active) {
+        if (relu) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[v] = relu_f(acc[v]);
+        }
+        store_vec<VEC>(Y + (int64_t)row * ldy + c, acc);
+    }
+}
+
+// Grouped rows: work item w = RB member rows [r0, r0+RB) of group g; all share the column sequence grp_cols[colptr[g]..].
+// grp_vals layout per group: [j][Rpad] (Rpad = members rounded up to RB), so the RB values of column j are contiguous.
+template <int VEC>
+__global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
+                                                        const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
+                                                        const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
+                                                        const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
+                                                        const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                        int64_t n_vecs, int relu, int64_t n_rb) {
+    const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
+    int64_t item;
+    if (!decode_item(n_ct * n_rb, item)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = rb * WAVES + wave;
+    if (w >= n_work) return;
+    const int g = work_grp[w];
+    const int r0 = work_r0[w];
+    const int cbeg = grp_colptr[g];
+    const int ncol = grp_colptr[g + 1] - cbeg;
+    const int rbeg = grp_rowptr[g];
+    const int nmem = grp_rowptr[g + 1] - rbeg;
+    const int rpad = (nmem + RB - 1) / RB * RB;
+    const float* vals = grp_vals + grp_valptr[g] + r0;
+    const int32_t* cols = grp_cols + cbeg;
+    const int64_t c = ct * (64 * VEC) + (int64_t)lane * VEC;
+    const bool active = c < n_vecs;
+    const float* xc = X + (active ? c : 0);
+
+    float acc[RB][VEC];
+#pragma unroll
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
+
+    int j = 0;
+    for (; j + 4 <= ncol; j += 4) {
+        float xv[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; u++) load_vec<VEC>(xv[u], xc + (int64_t)cols[j + u] * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float* a = vals + (int64_t)(j + u) * rpad;   // wave-uniform: scalar loads
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const float ar = a[r];
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const float p = ar * xv[u][v];
+                    acc[r][v] = acc[r][v] + p;
+                }
+            }
+        }
+    }
+    for (; j < ncol; j++) {
+        float xv[VEC];
+        load_vec<VEC>(xv, xc + (int64_t)cols[j] * ldx);
+        const float* a = vals + (int64_t)j * rpad;
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const float ar = a[r];
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const float p = ar * xv[v];
+                acc[r][v] = acc[r][v] + p;
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            if (r0 + r < nmem) {
+                const int row = grp_rows[rbeg + r0 + r];
+                if (relu) {
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) acc[r][v] = relu_f(acc[r][v]);
+                }
+                store_vec<VEC>(Y + (int64_t)row * ldy + c, acc[r]);
+            }
+        }
+    }
+}
+
+void csr_free(CsrDev& c) {
+    void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
+                    c.work_grp, c.work_r0, c.loose_rows};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c = CsrDev();
+}
+
+// Host analysis: bucket rows by their exact column sequence.  Groups need >= 2 members and >= 1 column.
+int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data) {
+    CsrDev& A = h->csr;
+    const int64_t rows = A.rows;
+    std::unordered_map<uint64_t, std::vector<int32_t>> buckets;   // hash -> group ids with that hash
+    std::vector<std::vector<int32_t>> members;                    // group -> rows (ascending)
+    std::vector<int32_t> rep;                                     // group -> representative row
+    buckets.reserve((size_t)rows);
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t s = indptr[r], e = indptr[r + 1];
+        if (e <= s) continue;
+        uint64_t hsh = 1469598103934665603ull ^ (uint64_t)(e - s);
+        for (int32_t k = s; k < e; k++) {
+            hsh ^= (uint64_t)(uint32_t)indices[k];
+            hsh *= 1099511628211ull;
+        }
+        auto& cand = buckets[hsh];
+        int32_t found = -1;
+        for (int32_t g : cand) {
+            const int32_t rs = indptr[rep[g]], re = indptr[rep[g] + 1];
+            if (re - rs == e - s && std::memcmp(indices + rs, indices + s, sizeof(int32_t) * (size_t)(e - s)) == 0) {
+                found = g;
+                break;
+            }
+        }
+        if (found < 0) {
+            found = (int32_t)members.size();
+            members.emplace_back();
+            rep.push_back((int32_t)r);
+            cand.push_back(found);
+        }
+        members[found].push_back((int32_t)r);
+    }
+    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, loose;
+    std::vector<int64_t> valptr{0};
+    std::vector<float> vals;
+    int64_t grouped_nnz = 0;
+    std::vector<char> in_group((size_t)rows, 0);
+    for (size_t g = 0; g < members.size(); g++) {
+        const auto& m = members[g];
+        if (m.size() < 2) continue;
+        const int32_t s = indptr[rep[g]], e = indptr[rep[g] + 1];
+        const int32_t ncol = e - s;
+        const int32_t gid = (int32_t)(colptr.size() - 1);
+        cols.insert(cols.end(), indices + s, indices + e);
+        colptr.push_back((int32_t)cols.size());
+        grows.insert(grows.end(), m.begin(), m.end());
+        rowptr.push_back((int32_t)grows.size());
+        const int64_t rpad = ((int64_t)m.size() + RB - 1) / RB * RB;
+        const int64_t v0 = (int64_t)vals.size();
+        vals.resize((size_t)(v0 + rpad * ncol), 0.0f);
+        for (size_t mi = 0; mi < m.size(); mi++) {
+            const int32_t rs = indptr[m[mi]];
+            for (int32_t j = 0; j < ncol; j++) vals[(size_t)(v0 + (int64_t)j * rpad + (int64_t)mi)] = data[rs + j];
+            in_group[(size_t)m[mi]] = 1;
+        }
+        valptr.push_back((int64_t)vals.size());
+        for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += RB) {
+            wgrp.push_back(gid);
+            wr0.push_back((int32_t)r0);
+        }
+        grouped_nnz += (int64_t)m.size() * ncol;
+    }
+    for (int64_t r = 0; r < rows; r++)
+        if (!in_group[(size_t)r]) loose.push_back((int32_t)r);   // includes empty rows (they must still be zeroed)
+    A.n_groups = (int64_t)colptr.size() - 1;
+    A.n_work = (int64_t)wgrp.size();
+    A.n_loose = (int64_t)loose.size();
+    A.grouped_nnz = grouped_nnz;
+    int rc;
+    if ((rc = upload(&A.grp_colptr, colptr.data(), colptr.size()))) return rc;
+    if ((rc = upload(&A.grp_cols, cols.data(), cols.size()))) return rc;
+    if ((rc = upload(&A.grp_rowptr, rowptr.data(), rowptr.size()))) return rc;
+    if ((rc = upload(&A.grp_rows, grows.data(), grows.size()))) return rc;
+    if ((rc = upload(&A.grp_valptr, valptr.data(), valptr.size()))) return rc;
+    if ((rc = upload(&A.grp_vals, vals.data(), vals.size()))) return rc;
+    if ((rc = upload(&A.work_grp, wgrp.data(), wgrp.size()))) return rc;
+    if ((rc = upload(&A.work_r0, wr0.data(), wr0.size()))) return rc;
+    if ((rc = upload(&A.loose_rows, loose.data(), loose.size()))) return rc;
+    return KN_OK;
+}
+
+template <int VEC>
+static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
+    if (A.n_work > 0) {
+        const int64_t n_rb = (A.n_work + WAVES - 1) / WAVES;
+        const int64_t items = n_ct * n_rb;
+        const int64_t grid = ((items + 7) / 8) * 8;
+        hipLaunchKernelGGL(csr_group_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
+    }
+    if (A.n_loose > 0) {
+        const int64_t n_rb = (A.n_loose + WAVES - 1) / WAVES;
+        const int64_t items = n_ct * n_rb;
+        const int64_t grid = ((items + 7) / 8) * 8;
+        hipLaunchKernelGGL(csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
+                           y, ldy, n_vecs, relu, n_rb);
+    }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
+    const int relu = (flags & KN_FLAG_RELU) ? 1 : 0;
+    auto aligned = [&](int v) {
+        return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0);
+    };
+    // Prefer 8 or more column tiles (one per XCD) before widening the per-lane vector.
+    if (aligned(4) && n_vecs >= 8 * 256) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (aligned(2) && n_vecs >= 8 * 128) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (aligned(4) && n_vecs >= 256) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (aligned(2) && n_vecs >= 128) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
+}
+
+}  // namespace kn

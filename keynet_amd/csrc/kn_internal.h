@@ -1,0 +1,112 @@
+// kn_internal.h -- private to libkeynet_hip.so (gfx950 only; no CUDA / multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/keynet_hip.h"
+
+namespace kn {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define KN_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            return kn::fail(KN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+        }                                                                                              \
+    } while (0)
+
+#define KN_REQUIRE(cond, code, msg)                                                                    \
+    do {                                                                                               \
+        if (!(cond)) return kn::fail((code), std::string(msg) + " [" #cond "]");                       \
+    } while (0)
+
+enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1 };
+
+// Order-preserving CSR resident in HBM.
+struct CsrDev {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    int32_t* indptr = nullptr;   // [rows+1]
+    int32_t* indices = nullptr;  // [nnz]  stored order
+    float* data = nullptr;       // [nnz]
+    // pattern groups (rows sharing one column sequence, e.g. the Cout rows of one conv output pixel, or all rows of a
+    // dense Linear): see kn_csr.hip.  Rows not in any group are listed in `loose_rows`.
+    int64_t n_groups = 0;
+    int32_t* grp_colptr = nullptr;   // [n_groups+1] into grp_cols
+    int32_t* grp_cols = nullptr;     // shared column sequence of each group
+    int32_t* grp_rowptr = nullptr;   // [n_groups+1] into grp_rows
+    int32_t* grp_rows = nullptr;     // member rows
+    int64_t* grp_valptr = nullptr;   // [n_groups+1] into grp_vals (layout [col j][member r], r padded to RB)
+    float* grp_vals = nullptr;
+    int32_t* work_grp = nullptr;     // work items: (group, first member) pairs of RB rows
+    int32_t* work_r0 = nullptr;
+    int64_t n_work = 0;
+    int32_t* loose_rows = nullptr;
+    int64_t n_loose = 0;
+    int64_t grouped_nnz = 0;
+};
+
+// Factored conv operator  W = sum_e coef_e * taps[tap_e] (x) E[out_e,in_e] + lastcol + e_last.
+struct ConvTapsDev {
+    int64_t Cin = 0, Hin = 0, Win = 0, Cout = 0, Hout = 0, Wout = 0;
+    int64_t ntaps = 0;
+    int64_t cin_pad = 0, cout_pad = 0;  // padded dims of tapsT
+    float* tapsT = nullptr;             // [ntaps][cin_pad][cout_pad]  (co contiguous; zero padded)
+    int64_t nslots = 0;                 // compute entries (zero taps dropped)
+    int32_t* pix_ptr = nullptr;         // [HoWo+1]
+    int32_t* slot_in = nullptr;         // [nslots] input pixel
+    int32_t* slot_tap = nullptr;        // [nslots]
+    float* slot_coef = nullptr;         // [nslots]
+    int32_t* pix_order = nullptr;       // [HoWo] processing order of output pixels (locality)
+    float* lastcol = nullptr;           // [Cout*HoWo+1] or null
+    bool has_last = false;
+    bool unit_coef = true;
+    int max_slots = 0;
+};
+
+}  // namespace kn
+
+struct kn_operator {
+    int kind = kn::KIND_CSR;
+    int device = 0;
+    int64_t rows = 0, cols = 0;
+    int64_t nnz_stored = 0;     // what the reference's nnz() reports
+    int64_t nnz_expanded = 0;   // nnz of tocsr()
+    kn::CsrDev csr;
+    kn::ConvTapsDev ct;
+    // host description of a conv-taps operator (export / lazy exact CSR)
+    std::vector<int32_t> h_ent_out, h_ent_in, h_ent_tap;
+    std::vector<float> h_ent_coef, h_taps, h_lastcol;
+    std::mutex lazy_mu;
+    kn_operator* exact = nullptr;  // lazily expanded CSR twin (KN_FLAG_EXACT on a conv-taps operator)
+};
+
+namespace kn {
+// kernels (kn_csr.hip / kn_conv.hip / kn_elementwise.hip)
+int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
+int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
+                  uint32_t flags, hipStream_t s);
+int relu_inplace(float* y, int64_t rows, int64_t ld, int64_t n_vecs, hipStream_t s);
+int affine_to_linear(const float* x, int64_t n, int64_t d, float* out, int64_t ldo, hipStream_t s);
+int linear_to_affine(const float* y, int64_t ldy, int64_t n, int64_t d, float* out, float* maxdev, hipStream_t s);
+void csr_free(CsrDev& c);
+void convtaps_free(ConvTapsDev& c);
+
+template <typename T>
+inline int upload(T** dptr, const T* h, size_t n) {
+    *dptr = nullptr;
+    if (n == 0) n = 1;  // keep pointers non-null
+    hipError_t e = hipMalloc((void**)dptr, n * sizeof(T));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KN_ERR_NOMEM : KN_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (h) {
+        e = hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(KN_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
+    }
+    return KN_OK;
+}
+}  // namespace kn

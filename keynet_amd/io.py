@@ -1,0 +1,130 @@
+"""Neutral on-disk container for keyed networks (.npz of plain arrays), replacing the reference's whole-object pickles
+(test/test_keynet.py:106, demo/challenge.ipynb cell 1), which need the reference's classes to load.
+
+Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_golden.py from the reference's objects):
+    layer_names                      nn.Sequential order
+    L.<name>.kind                    'relu' | 'csr' | 'tiled' | 'diagtiled' | 'conv2dtiled' | 'convtaps'
+    L.<name>.layertype               str(type(module)) of the source layer ('ReLU' in it => keyed ReLU)
+    csr:          shape, indptr, indices, data           (STORED order)
+    tiled:        shape, tileshape, blocks, tile_shapes, tile_ptr, tile_row, tile_col, tile_val
+    conv2dtiled:  shape, inshape, outshape, tileshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias
+    convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol
+    outshape                         (C,1,1) of the logits
+"""
+from collections import OrderedDict
+import numpy as np
+import scipy.sparse
+from torch import nn
+
+from . import sparse as ksp
+from .layer import KeyedLayer
+from .system import KeyedModel, KeyedSensor
+
+
+def operator_from_arrays(z, p):
+    kind = str(z[p + 'kind'])
+    if kind == 'convtaps':
+        g = (lambda k: z[p + k] if (p + k) in z.files and z[p + k].size > 0 else None)
+        return ksp.Conv2dTiledMatrix.fromtaps(tuple(int(v) for v in z[p + 'inshape']), tuple(int(v) for v in z[p + 'outshape']), z[p + 'taps'],
+                                              z[p + 'ent_out'], z[p + 'ent_in'], z[p + 'ent_tap'], g('ent_coef'), g('lastcol'))
+    shape = tuple(int(v) for v in z[p + 'shape'])
+    if kind == 'csr':
+        data = z[p + 'data']
+        M = scipy.sparse.csr_matrix((data.astype(np.float32) if data.dtype != np.float32 else data, z[p + 'indices'], z[p + 'indptr']), shape=shape)
+        return ksp.SparseMatrix(M)
+    if kind in ('tiled', 'diagtiled'):
+        W = ksp.TiledMatrix.__new__(ksp.TiledMatrix)
+        (W.shape, W.dtype, W.ndim, W._op) = (shape, np.float32, 2, None)
+        W._tileshape = tuple(int(v) for v in z[p + 'tileshape'])
+        W._blocks = [tuple(int(v) for v in b) for b in z[p + 'blocks']]
+        ptr = z[p + 'tile_ptr']
+        W._tiles = [scipy.sparse.coo_matrix((z[p + 'tile_val'][ptr[k]:ptr[k + 1]], (z[p + 'tile_row'][ptr[k]:ptr[k + 1]], z[p + 'tile_col'][ptr[k]:ptr[k + 1]])),
+                                            shape=tuple(int(v) for v in z[p + 'tile_shapes'][k])) for k in range(len(ptr) - 1)]
+        return W
+    if kind == 'conv2dtiled':
+        W = ksp.Conv2dTiledMatrix.__new__(ksp.Conv2dTiledMatrix)
+        (W.shape, W.dtype, W.ndim, W._op, W._taps) = (shape, np.float32, 2, None, None)
+        W._inshape = tuple(int(v) for v in z[p + 'inshape'])
+        W._outshape = tuple(int(v) for v in z[p + 'outshape'])
+        W._tileshape = tuple(int(v) for v in z[p + 'tileshape'])
+        W._blocks = [tuple(int(v) for v in b) for b in z[p + 'blocks']]
+        W._tiles = OrderedDict()
+        (nc, nb) = (0, 0)
+        for (key, isb) in zip(z[p + 'tile_keys'], z[p + 'tile_isbias']):
+            if isb:
+                W._tiles[tuple(int(v) for v in key)] = np.array(z[p + 'tile_bias'][nb], dtype=np.float32).reshape(1, 1)
+                nb += 1
+            else:
+                W._tiles[tuple(int(v) for v in key)] = np.asarray(z[p + 'tile_chan'][nc], dtype=np.float32)
+                nc += 1
+        return W
+    raise ValueError('unknown operator kind "%s"' % kind)
+
+
+def operator_to_arrays(W, p, out):
+    if isinstance(W, ksp.Conv2dTiledMatrix):
+        if W._taps is not None:
+            out[p + 'kind'] = np.array('convtaps')
+            (out[p + 'inshape'], out[p + 'outshape']) = (np.array(W._inshape, dtype=np.int64), np.array(W._outshape, dtype=np.int64))
+            for (k, v) in W._taps.items():
+                out[p + k] = v if v is not None else np.zeros(0, np.float32)
+            return
+        out[p + 'kind'] = np.array('conv2dtiled')
+        (bl, tk, ib, ch, bs) = W._golden_arrays()
+        for (k, v) in (('shape', np.array(W.shape, dtype=np.int64)), ('inshape', np.array(W._inshape, dtype=np.int64)), ('outshape', np.array(W._outshape, dtype=np.int64)),
+                       ('tileshape', np.array(W._tileshape, dtype=np.int64)), ('blocks', bl), ('tile_keys', tk), ('tile_isbias', ib.astype(bool)), ('tile_chan', ch), ('tile_bias', bs)):
+            out[p + k] = v
+    elif isinstance(W, ksp.TiledMatrix):
+        out[p + 'kind'] = np.array('tiled')
+        (ptr, tr, tc, tv) = W._tile_arrays()
+        for (k, v) in (('shape', np.array(W.shape, dtype=np.int64)), ('tileshape', np.array(W._tileshape, dtype=np.int64)), ('blocks', np.array(list(W), dtype=np.int64).reshape(-1, 3)),
+                       ('tile_shapes', np.array([t.shape for t in W._tiles], dtype=np.int64).reshape(-1, 2)), ('tile_ptr', ptr), ('tile_row', tr), ('tile_col', tc), ('tile_val', tv)):
+            out[p + k] = v
+    else:
+        out[p + 'kind'] = np.array('csr')
+        (ip, ix, dt) = ksp._stored_order_csr(W._matrix if ksp.is_scipy_sparse(W._matrix) else scipy.sparse.csr_matrix(W._matrix))
+        for (k, v) in (('shape', np.array(W.shape, dtype=np.int64)), ('indptr', ip), ('indices', ix), ('data', dt)):
+            out[p + k] = v
+
+
+def keynet_from_arrays(z):
+    """KeyedModel (public: no keys) from a neutral archive / golden file."""
+    layers = OrderedDict()
+    for name in [str(n) for n in z['layer_names']]:
+        p = 'L.%s.' % name
+        if str(z[p + 'kind']) == 'relu':
+            layers[name] = nn.ReLU()
+        else:
+            layers[name] = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']))
+    last = [l for l in layers.values() if isinstance(l, KeyedLayer)][-1]
+    outshape = tuple(int(v) for v in z['outshape']) if 'outshape' in z.files else (last.W.shape[0] - 1, 1, 1)
+    return KeyedModel.fromlayers(layers, outshape)
+
+
+def sensor_from_arrays(z, inshape):
+    shape = tuple(int(v) for v in z['sensor.shape'])
+    enc = scipy.sparse.csr_matrix((z['sensor.enc.data'], z['sensor.enc.indices'], z['sensor.enc.indptr']), shape=shape)
+    dec = scipy.sparse.csr_matrix((z['sensor.dec.data'], z['sensor.dec.indices'], z['sensor.dec.indptr']), shape=shape)
+    return KeyedSensor(tuple(inshape), (enc, dec))
+
+
+def save_keynet(knet, filename, sensor=None):
+    out = {'layer_names': np.array([n for (n, _) in knet._keynet.named_children()]), 'outshape': np.array(knet._outshape, dtype=np.int64)}
+    for (name, c) in knet._keynet.named_children():
+        p = 'L.%s.' % name
+        if isinstance(c, KeyedLayer):
+            operator_to_arrays(c.W, p, out)
+            out[p + 'layertype'] = np.array(c._layertype)
+        else:
+            out[p + 'kind'] = np.array('relu')
+    if sensor is not None:
+        for (tag, M) in (('enc', sensor._encryptkey), ('dec', sensor._decryptkey)):
+            (ip, ix, dt) = ksp._stored_order_csr(M.tocsr() if M.format not in ('csr', 'coo', 'csc') else M)
+            (out['sensor.%s.indptr' % tag], out['sensor.%s.indices' % tag], out['sensor.%s.data' % tag]) = (ip, ix, dt)
+        out['sensor.shape'] = np.array(sensor._encryptkey.shape, dtype=np.int64)
+    np.savez_compressed(filename, **out)
+    return filename
+
+
+def load_keynet(filename):
+    return keynet_from_arrays(np.load(filename, allow_pickle=False))

@@ -1,0 +1,583 @@
+"""Operator containers of the keyed forward, HIP-backed: the objects stored in KeyedLayer.W.
+
+Mirror of the reference's operator interface (keynet/sparse.py:419-835): SparseMatrix, TiledMatrix, DiagonalTiledMatrix,
+Conv2dTiledMatrix with torchdot / dot / nnz / shape / tocoo / tocsr / transpose / clone.  The host keeps the defining
+arrays (scipy matrix or blocks+tiles) for the structural methods and pickling; `torchdot` -- the hot path -- always runs
+in libkeynet_hip.so on an MI355X (there is no CPU route: a missing library or device raises).
+
+Build-time (host, offline) constructors live here too, restated and vectorised: Toeplitz matrices of conv / avgpool
+layers (keynet/sparse.py:122-212) and the tilers (keynet/sparse.py:519-571, 692-776).
+"""
+import copy
+import numpy as np
+import scipy.sparse
+import torch
+
+from . import _capi
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# helpers
+def is_scipy_sparse(A):
+    return scipy.sparse.issparse(A)
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _stored_order_csr(M):
+    """(indptr, indices, data) whose per-row order equals the accumulation order of scipy's matvec for M's format:
+    CSR as stored (csr_matvecs); COO in entry order (coo_matmat_dense); CSC column-major (csc_matvecs).  Nothing is
+    sorted or summed -- keyed matrices are non-canonical and the order is part of the result."""
+    if M.format == 'csr':
+        return (np.asarray(M.indptr, dtype=np.int32), np.asarray(M.indices, dtype=np.int32), np.asarray(M.data, dtype=np.float32))
+    if M.format == 'csc':
+        cols = np.repeat(np.arange(M.shape[1], dtype=np.int64), np.diff(M.indptr))
+        (rows, vals) = (np.asarray(M.indices, dtype=np.int64), M.data)
+    else:
+        C = M if M.format == 'coo' else M.tocoo()
+        (rows, cols, vals) = (np.asarray(C.row, dtype=np.int64), np.asarray(C.col, dtype=np.int64), C.data)
+    order = np.argsort(rows, kind='stable')
+    indptr = np.zeros(M.shape[0] + 1, dtype=np.int64)
+    np.add.at(indptr, rows + 1, 1)
+    return (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), np.asarray(vals, dtype=np.float32)[order])
+
+
+def _run_torchdot(op, shape, x, relu=False, exact=True):
+    """Y = W.X on the GPU.  x: torch tensor [cols, N] (any device / strides).  Returns [rows, N] on x's device."""
+    assert shape[1] == x.shape[0], 'Non-conformal shape for W=%s, x=%s' % (str(shape), str(tuple(x.shape)))
+    if not torch.cuda.is_available():
+        raise _capi.KeynetHipError('keynet_amd: no MI355X visible -- the keyed forward has no CPU fallback')
+    src_device = x.device
+    xd = x.detach()
+    if xd.dtype != torch.float32:
+        xd = xd.float()          # the reference coerces to FloatTensor silently (keynet/sparse.py:489-491)
+    if not xd.is_cuda:
+        xd = xd.cuda()
+    if not xd.is_contiguous():
+        xd = xd.contiguous()
+    n = xd.shape[1]
+    y = torch.empty((shape[0], n), dtype=torch.float32, device=xd.device)
+    flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if exact else 0)
+    with torch.cuda.device(xd.device):
+        op.spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr())
+    return y if src_device.type == 'cuda' else y.to(src_device)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class SparseMatrix(object):
+    """scipy-sparse (or dense ndarray) operator applied by order-preserving CSR SpMM kernels (keynet/sparse.py:419-514)."""
+
+    def __init__(self, A=None):
+        assert A is None or is_scipy_sparse(A) or isinstance(A, np.ndarray), 'Invalid input - %s' % (str(type(A)))
+        self.shape = A.shape if A is not None else (0, 0)
+        self._matrix = A
+        self.dtype = A.dtype if A is not None else None
+        self.ndim = 2
+        self._op = None
+
+    def __repr__(self):
+        return str('<keynet_amd.SparseMatrix: H=%d, W=%d, backend=hip>' % (self.shape[0], self.shape[1]))
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d['_op'] = None   # device handles do not pickle; rebuilt lazily
+        return d
+
+    def __add__(self, other):
+        assert isinstance(other, SparseMatrix) and self.shape == other.shape, 'Invalid input'
+        self._matrix = self._matrix + other._matrix
+        self._op = None
+        return self
+
+    # -- device side
+    def _device_op(self):
+        if self._op is None:
+            M = self._matrix
+            if isinstance(M, np.ndarray):
+                M = scipy.sparse.csr_matrix((np.asarray(M, dtype=np.float32).ravel(), np.tile(np.arange(M.shape[1]), M.shape[0]),
+                                             np.arange(0, M.size + 1, M.shape[1])), shape=M.shape)
+            (ip, ix, dt) = _stored_order_csr(M)
+            self._op = _capi.Operator.csr(self.shape, ip, ix, dt)
+        return self._op
+
+    def torchdot(self, x_torch, relu=False):
+        """W . x for x of shape [W.shape[1], N]: the hot path (keynet/sparse.py:488-492), bit-exact with scipy."""
+        return _run_torchdot(self._device_op(), self.shape, x_torch, relu=relu, exact=True)
+
+    def dot(self, x_numpy):
+        assert isinstance(x_numpy, np.ndarray)
+        return self.torchdot(torch.as_tensor(np.asarray(x_numpy))).cpu().numpy()
+
+    # -- structure (host)
+    def new(self):
+        return SparseMatrix()
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def from_torch_dense(self, A):
+        return SparseMatrix(A.detach().numpy())
+
+    def from_scipy_sparse(self, A):
+        assert is_scipy_sparse(A)
+        return SparseMatrix(A)
+
+    def matmul(self, A):
+        """In-place sparse x sparse product on the host (keynet/sparse.py:472-480); not on the forward path."""
+        assert isinstance(A, SparseMatrix) or is_scipy_sparse(A)
+        self._matrix = self._matrix.dot(A._matrix if isinstance(A, SparseMatrix) else A)
+        self.shape = self._matrix.shape
+        self._op = None
+        return self
+
+    def nnz(self):
+        return self._matrix.nnz if is_scipy_sparse(self._matrix) else self._matrix.size
+
+    def transpose(self):
+        self._matrix = self._matrix.transpose()
+        self.shape = self._matrix.shape
+        self._op = None
+        return self
+
+    def tocoo(self):
+        return self._matrix.tocoo() if is_scipy_sparse(self._matrix) else scipy.sparse.coo_matrix(self._matrix)
+
+    def tocsr(self):
+        self._matrix = self._matrix.tocsr()
+        self._op = None
+        return self
+
+    def tocsc(self):
+        self._matrix = self._matrix.tocsc()
+        self._op = None
+        return self
+
+    def from_torch_conv2d(self, inshape, w, b, stride):
+        return SparseMatrix(sparse_toeplitz_conv2d(inshape, w.detach().numpy(), bias=b.detach().numpy(), stride=stride))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _structure_preserving(vals64):
+    """The reference stores tile values as ((v + off) - off) with off = |min v| + 1 computed in float64, then casts to
+    float32 (keynet/sparse.py:562-566, 582): reproduced so tile contents match bit for bit."""
+    off = np.abs(np.min(vals64)) + 1.0
+    return ((vals64 + off) - off).astype(np.float32)
+
+
+class TiledMatrix(SparseMatrix):
+    """Sparse matrix stored as de-duplicated h x w tiles + a block list (keynet/sparse.py:517-653).
+
+    The tile dictionary is storage compression; on the device the operator is expanded ONCE to canonical CSR (the
+    reference re-expands it on every torchdot call, keynet/sparse.py:610) because per non-zero the 8 bytes of (col,val)
+    are negligible next to the n_vecs*4-byte activation row it gathers."""
+
+    def __init__(self, T, tileshape):
+        assert is_scipy_sparse(T), 'input must be a scipy sparse matrix'
+        assert isinstance(tileshape, tuple) and len(tileshape) == 2 and tileshape[0] > 0 and tileshape[1] > 0, 'tileshape must be tuple (tileheight, tilewidth) > 0'
+        self._tileshape = tileshape
+        self.dtype = T.dtype
+        self.shape = (T.shape[0], T.shape[1])
+        self.ndim = 2
+        self._op = None
+        (self._blocks, self._tiles) = _tile_sparse(T, tileshape)
+
+    def __repr__(self):
+        return str('<keynet_amd.TiledMatrix: H=%d, W=%d, tileshape=%s, tiles=%d>' % (self.shape[0], self.shape[1], str(self.tileshape()), len(self.tiles())))
+
+    def __iter__(self):
+        for (i, j, k) in self._blocks:
+            yield (i, j, k)
+
+    def tileshape(self):
+        return self._tileshape
+
+    def tiles(self):
+        return self._tiles
+
+    def blocks(self):
+        return list(self.__iter__())
+
+    def _tile_arrays(self):
+        tiles = [t.tocoo() for t in self._tiles]
+        ptr = np.cumsum([0] + [t.nnz for t in tiles]).astype(np.int64)
+        cat = (lambda L, dt: np.concatenate(L).astype(dt) if len(L) else np.zeros(0, dt))
+        return (ptr, cat([t.row for t in tiles], np.int32), cat([t.col for t in tiles], np.int32), cat([t.data for t in tiles], np.float32))
+
+    def _device_op(self):
+        if self._op is None:
+            (ptr, tr, tc, tv) = self._tile_arrays()
+            self._op = _capi.Operator.tiled(self.shape, np.array(list(self), dtype=np.int64).reshape(-1, 3), ptr, tr, tc, tv)
+        return self._op
+
+    def torchdot(self, x, relu=False):
+        """[cols, N] -> [rows, N] (keynet/sparse.py:603-612)."""
+        if isinstance(x, np.ndarray):
+            x = torch.as_tensor(x)
+        return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=True)
+
+    def dot(self, x):
+        assert isinstance(x, np.ndarray)
+        return self.torchdot(torch.as_tensor(x)).cpu().numpy()
+
+    def copy(self, blocks, tiles):
+        (self._blocks, self._tiles, self._op) = (blocks, tiles, None)
+        return self
+
+    def transpose(self):
+        self._blocks = [(j, i, k) for (i, j, k) in self._blocks] if self._blocks is not None else self._blocks
+        self._tiles = [t.transpose() for t in self._tiles]
+        self._tileshape = (self._tileshape[1], self._tileshape[0])
+        self.shape = (self.shape[1], self.shape[0])
+        self._op = None
+        return self
+
+    def tosparse(self, format='coo'):
+        """Expanded operator as scipy csr/coo/csc (keynet/sparse.py:621-641); host side, small matrices / tests."""
+        tiles = [t.tocoo() for t in self._tiles]
+        (R, C, V) = ([], [], [])
+        for (i, j, k) in self.__iter__():
+            R.append(i + tiles[k].row.astype(np.int64))
+            C.append(j + tiles[k].col.astype(np.int64))
+            V.append(tiles[k].data)
+        cat = (lambda L, dt: np.concatenate(L) if len(L) else np.zeros(0, dt))
+        return _from_coo(format, cat(V, np.float32), cat(R, np.int64), cat(C, np.int64), self.shape)
+
+    def tocsr(self):
+        return self.tosparse(format='csr')
+
+    def tocoo(self):
+        return self.tosparse(format='coo')
+
+    def nnz(self):
+        return sum([t.nnz for t in self._tiles])
+
+
+def _from_coo(format, vals, rows, cols, shape):
+    if format == 'csr':
+        return scipy.sparse.csr_matrix((vals, (rows, cols)), shape=shape)
+    if format == 'coo':
+        return scipy.sparse.coo_matrix((vals, (rows, cols)), shape=shape)
+    if format == 'csc':
+        return scipy.sparse.csc_matrix((vals, (rows, cols)), shape=shape)
+    raise ValueError('Invalid format "%s" - must be ["coo", "csr", "csc"]' % format)
+
+
+def _tile_sparse(T, tileshape):
+    """Vectorised restatement of the TiledMatrix tiler (keynet/sparse.py:543-571).
+
+    Returns (blocks, tiles): blocks = [(row0, col0, k)] row-major; tiles[k] = scipy COO (float32) of the k-th distinct
+    tile.  Tile ids follow first occurrence in COO order; entries inside a tile are (row, col)-sorted (the reference's
+    float64 -> float32 astype canonicalises the COO); two blocks share a tile iff their (i,j,v) sets and block shapes
+    are identical (the reference hashes str(sorted(ijv))+str(shape))."""
+    T = T.tocoo()
+    (h, w) = tileshape
+    (H, W) = T.shape
+    if T.nnz == 0:
+        return ([], [])
+    (r, c) = (np.asarray(T.row, dtype=np.int64), np.asarray(T.col, dtype=np.int64))
+    v = np.asarray(T.data, dtype=np.float64)
+    (bi, bj) = (r // h, c // w)
+    nbj = (W + w - 1) // w
+    key = bi * nbj + bj
+    order = np.argsort(key, kind='stable')
+    ks = key[order]
+    starts = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1])))
+    ends = np.concatenate((starts[1:], [len(ks)]))
+    first_seen = order[starts]                     # original COO index of each block's first entry
+    tiles = []
+    blocks = []
+    seen = {}
+    for b in np.argsort(first_seen, kind='stable'):
+        idx = order[starts[b]:ends[b]]
+        (kbi, kbj) = (int(ks[starts[b]] // nbj), int(ks[starts[b]] % nbj))
+        (ii, jj, vv) = (r[idx] - kbi * h, c[idx] - kbj * w, v[idx])
+        bshape = (h if (kbi * h + h) <= H else (H - kbi * h), w if (kbj * w + w) <= W else (W - kbj * w))
+        s = np.lexsort((jj, ii))
+        sig = (ii[s].tobytes(), jj[s].tobytes(), vv[s].tobytes(), bshape)
+        k = seen.get(sig)
+        if k is None:
+            k = len(tiles)
+            seen[sig] = k
+            tiles.append(scipy.sparse.coo_matrix((_structure_preserving(vv)[s], (ii[s], jj[s])), shape=bshape))
+        blocks.append((kbi * h, kbj * w, k))
+    blocks.sort(key=lambda x: (x[0], x[1]))
+    return (blocks, tiles)
+
+
+class DiagonalTiledMatrix(TiledMatrix):
+    """One block repeated down the main diagonal, identity remainder (keynet/sparse.py:657-687)."""
+
+    def __init__(self, B, shape):
+        assert B.ndim == 2, 'Invalid block, must be 2D'
+        assert isinstance(shape, tuple) and len(shape) == 2, 'invalid shape'
+        if B.shape[0] > shape[0] or B.shape[1] > shape[1]:
+            B = B.tocsr()[0:shape[0], 0:shape[1]]
+        if not scipy.sparse.issparse(B):
+            off = np.abs(np.min(B)) + 1.0
+            B = scipy.sparse.coo_matrix(B + off)
+            B.data -= off
+            B = B.tocsr()
+        self._tileshape = B.shape
+        self.shape = shape
+        self.dtype = B.dtype
+        self.ndim = 2
+        self._op = None
+        (H, W) = shape
+        (h, w) = self._tileshape
+        self._tiles = [B.astype(np.float32)]
+        self._blocks = None
+        if (H % h != 0) or (W % w != 0):
+            self._tiles.append(scipy.sparse.eye(max(h, w)).tocsr()[0:H % h, 0:W % w].astype(np.float32))
+
+    def __iter__(self):
+        ((H, W), (h, w)) = (self.shape, self._tileshape)
+        for (i, j) in zip(range(0, H, h), range(0, W, w)):
+            yield (i, j, 0) if (i + h < H and j + w < W) else (i, j, len(self._tiles) - 1)
+
+
+class Conv2dTiledMatrix(TiledMatrix):
+    """Keyed conv operator as spatial blocks x dense channel matrices (keynet/sparse.py:690-835).
+
+    _blocks = [(i, j, k)] over the channel-(0,0) plane (+ bias blocks at column Cin*Hin*Win);
+    _tiles  = {(it, jt, k): float32[Cout, Cin]} (+ {(it, 0, k): [[b]]} for bias tiles).
+    On the device the channel matrices are de-duplicated into `taps` and the forward is an implicit GEMM per output
+    pixel on f32 MFMA (csrc/kn_conv.hip); `exact=True` in torchdot selects the order-preserving CSR path instead."""
+
+    def __init__(self, T, inshape, outshape, tileshape, bias, sanitycheck=True):
+        (Cin, Hin, Win) = inshape
+        (Cout, Hout, Wout) = outshape
+        self._inshape = inshape
+        self._outshape = outshape
+        self._tileshape = tileshape
+        self.shape = T.shape
+        self.dtype = T.dtype
+        self.ndim = 2
+        self._op = None
+        self._taps = None
+        assert tileshape[0] <= T.shape[0] and tileshape[1] <= T.shape[1]
+        if bias:
+            assert T.shape[0] == np.prod(outshape) + 1 and T.shape[1] == np.prod(inshape) + 1
+            assert (self.shape[0] - 1) % tileshape[0] == 0 and (self.shape[1] - 1) % tileshape[1] == 0
+        else:
+            assert T.shape[0] == np.prod(outshape) and T.shape[1] == np.prod(inshape)
+            assert self.shape[0] % tileshape[0] == 0 and self.shape[1] % tileshape[1] == 0
+        T = T.tocsr()
+        (HoWo, HiWi) = (Hout * Wout, Hin * Win)
+        T_00 = T[0:HoWo, 0:HiWi]
+        if sanitycheck and Cout > 1 and Cin > 1:
+            T_10 = T[HoWo:2 * HoWo, 0:HiWi]
+            T_01 = T[0:HoWo, HiWi:2 * HiWi]
+            assert ((T_00 != 0) != (T_10 != 0)).nnz == 0 and ((T_00 != 0) != (T_01 != 0)).nnz == 0, 'channel-inconsistent sparsity'
+        (blocks, _) = _tile_sparse(T_00, tileshape)
+        T_lastcol = None
+        if bias:
+            T_lastcol = T[:, -1]
+            T = T[0:-1, 0:-1]
+        self._tiles = _conv_tiler(T.tocoo(), blocks, inshape, outshape, tileshape)
+        self._blocks = list(blocks)
+        if bias:
+            (bblocks, btiles) = _tile_sparse(T_lastcol, (tileshape[0], 1))
+            k_offset = len(self._tiles)
+            for (kt, t) in enumerate(btiles):
+                for (i, j, v) in zip(t.row, t.col, t.data):
+                    self._tiles[(int(i), int(j), int(k_offset + kt))] = np.array(v).reshape(1, 1).astype(np.float32)
+            self._blocks += [(i, Cin * HiWi, k_offset + k) for (i, j, k) in bblocks]
+        self._blocks = sorted(self._blocks, key=lambda x: (x[0], x[1]))
+
+    @classmethod
+    def fromtaps(cls, inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef=None, lastcol=None, tileshape=None):
+        """Direct construction in factored form (never materialises the Toeplitz matrix): see kn_convtaps_create."""
+        self = cls.__new__(cls)
+        (self._inshape, self._outshape, self._tileshape) = (tuple(inshape), tuple(outshape), tileshape)
+        has_last = lastcol is not None
+        self.shape = (int(np.prod(outshape)) + (1 if has_last else 0), int(np.prod(inshape)) + (1 if has_last else 0))
+        self.dtype = np.float32
+        self.ndim = 2
+        self._op = None
+        (self._blocks, self._tiles) = (None, None)
+        self._taps = dict(taps=np.ascontiguousarray(taps, dtype=np.float32), ent_out=np.asarray(ent_out, dtype=np.int32), ent_in=np.asarray(ent_in, dtype=np.int32),
+                          ent_tap=np.asarray(ent_tap, dtype=np.int32), ent_coef=None if ent_coef is None else np.asarray(ent_coef, dtype=np.float32),
+                          lastcol=None if lastcol is None else np.asarray(lastcol, dtype=np.float32))
+        return self
+
+    def __repr__(self):
+        return str('<keynet_amd.Conv2dTiledMatrix: H=%d, W=%d, tileshape=%s, backend=hip>' % (self.shape[0], self.shape[1], str(self._tileshape)))
+
+    def __iter__(self):
+        assert self._blocks is not None, 'operator was built in factored form (fromtaps): no block list'
+        for (i, j, k) in self._blocks:
+            yield (i, j, k)
+
+    def _golden_arrays(self):
+        """(blocks, tile_keys, tile_isbias, tile_chan, tile_bias) in the layout of kn_conv2dtiled_create."""
+        (Cout, Cin) = (self._outshape[0], self._inshape[0])
+        lastcol_at = Cin * self._inshape[1] * self._inshape[2]
+        biask = set(int(b[2]) for b in self._blocks if b[1] == lastcol_at and self.shape[1] == lastcol_at + 1)
+        keys = list(self._tiles.keys())
+        isbias = np.array([k[2] in biask for k in keys], dtype=np.uint8)
+        chan = [np.asarray(self._tiles[k], dtype=np.float32) for (k, b) in zip(keys, isbias) if not b]
+        bvals = [float(np.asarray(self._tiles[k]).reshape(())) for (k, b) in zip(keys, isbias) if b]
+        return (np.array(self._blocks, dtype=np.int64).reshape(-1, 3), np.array(keys, dtype=np.int64).reshape(-1, 3), isbias,
+                np.stack(chan) if len(chan) else np.zeros((0, Cout, Cin), np.float32), np.array(bvals, dtype=np.float32))
+
+    def _device_op(self):
+        if self._op is None:
+            if self._taps is not None:
+                t = self._taps
+                self._op = _capi.Operator.convtaps(self._inshape, self._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'], t['ent_coef'], t['lastcol'])
+            else:
+                (bl, tk, ib, ch, bs) = self._golden_arrays()
+                self._op = _capi.Operator.conv2dtiled(self.shape, self._inshape, self._outshape, bl, tk, ib, ch, bs)
+        return self._op
+
+    def torchdot(self, x, relu=False, exact=False):
+        """[cols, N] -> [rows, N].  Default: f32 MFMA path (within 1e-5 of the reference); exact=True: the reference's
+        accumulation order and rounding via the expanded CSR (small operators / parity tests)."""
+        if isinstance(x, np.ndarray):
+            x = torch.as_tensor(x)
+        return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=exact)
+
+    def nnz(self):
+        if self._tiles is None:
+            return self._device_op().nnz()
+        return sum([v.size for v in self._tiles.values()])
+
+    def transpose(self):
+        raise NotImplementedError('transpose of a Conv2dTiledMatrix is not on the forward path')
+
+    def tosparse(self, format='coo'):
+        """Expansion rule of keynet/sparse.py:802-812, vectorised."""
+        if self._tiles is None:
+            (ip, ix, dt) = self._device_op().export_csr()
+            return scipy.sparse.csr_matrix((dt, ix, ip), shape=self.shape).asformat(format)
+        (Cout, Hout, Wout) = self._outshape
+        (Cin, Hin, Win) = self._inshape
+        bykey = {}
+        for ((it, jt, k), m) in self._tiles.items():
+            bykey.setdefault(k, []).append((it, jt, m))
+        (R, C, V) = ([], [], [])
+        for (i, j, k) in self._blocks:
+            for (it, jt, m) in bykey.get(k, []):
+                (ic, jc) = np.meshgrid(np.arange(m.shape[0]), np.arange(m.shape[1]), indexing='ij')
+                R.append((i + it + ic * Hout * Wout).ravel())
+                C.append((j + jt + jc * Hin * Win).ravel())
+                V.append(np.asarray(m, dtype=np.float32).ravel())
+        return _from_coo(format, np.concatenate(V), np.concatenate(R), np.concatenate(C), self.shape)
+
+
+def _conv_tiler(T, blocks, inshape, outshape, tileshape):
+    """Vectorised restatement of Conv2dTiledMatrix.__tiler__ (keynet/sparse.py:692-717): returns the ordered dict
+    {(it, jt, k): float32[Cout, Cin]}; where several blocks share a tile id the LAST entry in COO order wins."""
+    (Cin, Hin, Win) = inshape
+    (Cout, Hout, Wout) = outshape
+    (h, w) = tileshape
+    (HoWo, HiWi) = (Hout * Wout, Hin * Win)
+    tiles = {}
+    loc = {}
+    for (ib, jb, kt) in blocks:
+        loc[(ib, jb)] = kt
+        tiles[(0, 0, kt)] = np.zeros((Cout, Cin), dtype=np.float32)
+    if T.nnz == 0:
+        return tiles
+    (i, j, v) = (np.asarray(T.row, dtype=np.int64), np.asarray(T.col, dtype=np.int64), np.asarray(T.data, dtype=np.float32))
+    (ip, jp) = (i % HoWo, j % HiWi)
+    (ib, jb) = (h * (ip // h), w * (jp // w))
+    nbj = HiWi // w + 1
+    lut = {}
+    bkeys = ib // h * nbj + jb // w
+    for ((bi_, bj_), kt) in loc.items():
+        lut[bi_ // h * nbj + bj_ // w] = kt
+    (ub, inv) = np.unique(bkeys, return_inverse=True)
+    kt_of = np.array([lut.get(int(b), -1) for b in ub], dtype=np.int64)[inv]
+    keep = kt_of >= 0
+    (i, j, v, ip, jp, ib, jb, kt_of) = (i[keep], j[keep], v[keep], ip[keep], jp[keep], ib[keep], jb[keep], kt_of[keep])
+    (it, jt, ic, jc) = (ip - ib, jp - jb, i // HoWo, j // HiWi)
+    tkey = (kt_of * h + it) * w + jt                      # (it, jt, kt) flattened
+    (utk, first_idx, tinv) = np.unique(tkey, return_index=True, return_inverse=True)
+    for u in np.argsort(first_idx, kind='stable'):          # dict insertion order = first appearance in COO order
+        k3 = (int(utk[u] // w % h), int(utk[u] % w), int(utk[u] // (w * h)))
+        if k3 not in tiles:
+            tiles[k3] = np.zeros((Cout, Cin), dtype=np.float32)
+    # assign; later entries overwrite earlier ones (numpy fancy assignment keeps the last for repeated indices)
+    stack = np.zeros((len(utk), Cout, Cin), dtype=np.float32)
+    stack[tinv, ic, jc] = v
+    for (u, tk) in enumerate(utk):
+        k3 = (int(tk // w % h), int(tk % w), int(tk // (w * h)))
+        tiles[k3] = stack[u]
+    return tiles
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Build-time constructors (host, offline)
+def sparse_toeplitz_conv2d(inshape, f, bias=None, as_correlation=True, stride=1, format='csr'):
+    """Explicit sparse matrix of a 'same'-padded, odd, square conv layer acting on the flattened CxUxV image, with the
+    bias column and homogeneous row when `bias` is given: conv2d(img, f) == W.dot(img.flatten()).
+
+    Restates keynet/sparse.py:122-203 without the per-entry Python loop.  Rows are (cout, u/stride, v/stride), columns
+    (cin, u+p, v+q); taps falling outside the image are omitted.  Values are fl32(fl32(w + off) - off) with
+    off = |min w| + 1 exactly as the reference's sparsity-preserving round trip leaves them (SURVEY 8c iv)."""
+    assert len(inshape) == 3 and f.ndim == 4
+    assert f.shape[1] == inshape[0] and f.shape[2] == f.shape[3] and f.shape[2] % 2 == 1
+    assert as_correlation, 'only the correlation form is on the keyed path'
+    (C, U, V) = inshape
+    (M, _, P, Q) = f.shape
+    f = np.asarray(f, dtype=np.float32)
+    (Us, Vs) = (U // stride, V // stride)
+    (ku, kv) = np.meshgrid(np.arange(Us), np.arange(Vs), indexing='ij')
+    (u, v) = (np.arange(0, U, stride)[ku], np.arange(0, V, stride)[kv])
+    (R, Cc, D) = ([], [], [])
+    (cin, cout) = np.meshgrid(np.arange(C), np.arange(M), indexing='ij')
+    for (i, p) in enumerate(range(-((P - 1) // 2), ((P - 1) // 2) + 1)):
+        for (j, q) in enumerate(range(-((Q - 1) // 2), ((Q - 1) // 2) + 1)):
+            ok = ((u + p) >= 0) & ((u + p) < U) & ((v + q) >= 0) & ((v + q) < V)
+            (opix, ipix) = ((ku * Vs + kv)[ok], ((u + p) * V + (v + q))[ok])
+            R.append((cout.reshape(1, -1) * (Us * Vs) + opix.reshape(-1, 1)).ravel())
+            Cc.append((cin.reshape(1, -1) * (U * V) + ipix.reshape(-1, 1)).ravel())
+            D.append(np.broadcast_to(f[cout, cin, i, j].reshape(1, -1), (len(opix), C * M)).ravel())
+    (rows, cols, data) = (np.concatenate(R), np.concatenate(Cc), np.concatenate(D).astype(np.float32))
+    off = np.float32(np.abs(np.min(data)) + np.float32(1.0))
+    data = (data + off) - off
+    A = scipy.sparse.coo_matrix((data, (rows, cols)), shape=(M * Us * Vs, C * U * V))
+    if bias is not None:
+        bias = np.asarray(bias, dtype=np.float32)
+        assert bias.ndim == 1 and bias.shape[0] == M
+        offb = np.float32(np.abs(np.min(bias)) + np.float32(1.0))
+        bcol = ((np.repeat(bias, Us * Vs) + offb) - offb).astype(np.float32)
+        lastcol = scipy.sparse.coo_matrix((bcol, (np.arange(M * Us * Vs), np.zeros(M * Us * Vs, dtype=np.int64))), shape=(A.shape[0], 1))
+        lastrow = scipy.sparse.coo_matrix(([1], ([0], [A.shape[1]])), shape=(1, A.shape[1] + 1), dtype=np.float32)
+        A = scipy.sparse.vstack((scipy.sparse.hstack((A, lastcol)), lastrow))
+    return A.tocsr() if format == 'csr' else A
+
+
+def sparse_toeplitz_avgpool2d(inshape, filtershape, stride):
+    """Average pooling as a conv with a (1/k^2)-filled diagonal filter and a zero bias (keynet/sparse.py:206-212):
+    k x k window, `stride`, zero padding (k-1)/2 counted in the mean -- independent of the source module's padding."""
+    (outchannel, inchannel, k, _) = filtershape
+    F = np.zeros(filtershape, dtype=np.float32)
+    F[np.arange(outchannel), np.arange(outchannel), :, :] = 1.0 / (k * k)
+    return sparse_toeplitz_conv2d(inshape, F, bias=np.zeros(outchannel, dtype=np.float32), stride=stride)
+
+
+def sparse_affine_to_linear(A, bias=None, dtype=np.float32):
+    """[[A, b], [0, 1]] (keynet/sparse.py:87-96)."""
+    assert is_scipy_sparse(A)
+    if bias is not None:
+        assert bias.shape[0] == A.shape[0] and bias.shape[1] == 1
+        lastcol = scipy.sparse.coo_matrix(bias)
+    else:
+        lastcol = scipy.sparse.coo_matrix((A.shape[0], 1), dtype=dtype)
+    lastrow = scipy.sparse.coo_matrix(([1], ([0], [A.shape[1]])), shape=(1, A.shape[1] + 1), dtype=dtype)
+    return scipy.sparse.vstack((scipy.sparse.hstack((A, lastcol)), lastrow))
+
+
+def sparse_identity_matrix(n, dtype=np.float32):
+    return scipy.sparse.eye(n, dtype=dtype)
+
+
+def sparse_permutation_matrix(n, dtype=np.float32, withinverse=False):
+    """Random permutation matrix from numpy's GLOBAL RNG, one np.random.permutation(n) draw (keynet/sparse.py:280-285)."""
+    col_ind = np.random.permutation(list(range(0, n)))
+    P = scipy.sparse.csr_matrix((np.ones(n).astype(dtype), (list(range(0, n)), col_ind)), shape=(n, n))
+    return (P, P.transpose()) if withinverse else P

@@ -1,0 +1,56 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/keynet_hip.h declares (no compute calls)."""
+import os
+import re
+import ctypes
+import pytest
+from keynet_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'keynet_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(kn_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert len(syms) >= 16
+    assert sorted(_capi.SYMBOLS) == syms, 'binding list and header disagree'
+    L = ctypes.CDLL(_capi.LIBPATH)
+    for s in syms:
+        assert hasattr(L, s), 'libkeynet_hip.so does not export %s' % s
+
+
+def test_abi_version_and_error_channel():
+    L = _capi.lib()
+    assert L.kn_abi_version() == _capi.KN_ABI_VERSION
+    (n, arch) = _capi.device_info()
+    assert n >= 0
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without an MI355X the product must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import numpy as np
+    import scipy.sparse
+    from keynet_amd.sparse import SparseMatrix
+    W = SparseMatrix(scipy.sparse.eye(4, dtype=np.float32).tocsr())
+    with pytest.raises(_capi.KeynetHipError):
+        W.torchdot(torch.ones(4, 2))
+    with pytest.raises(_capi.KeynetHipError):
+        _capi.Operator.csr((2, 2), [0, 1, 2], [0, 1], [1.0, 2.0])
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under keynet_amd/ may import or reference it."""
+    pkg = os.path.join(ROOT, 'keynet_amd')
+    for (d, _, files) in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+                assert 'kn_oracle' not in src, f

@@ -1,0 +1,228 @@
+"""Parity of the HIP path (through the C ABI) against the reference's vectors and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import scipy.sparse
+
+import oracle
+from keynet_amd import io as kio
+from keynet_amd import sparse as ksp
+from keynet_amd import system as ksys
+from keynet_amd import _capi
+from keynet_amd.layer import KeyedLayer
+from keynet_amd.torch import affine_to_linear, linear_to_affine
+from nets import LeNet_AvgPool, MiniNet, TinyAllConv, load_weights
+
+pytestmark = pytest.mark.gpu
+
+EXACT_NETS = ['lenet_perm.npz', 'allconv_tiny_perm.npz']
+TILED_NETS = ['mini_tiled_identity.npz', 'mini_tiled_permutation.npz', 'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz']
+TOL = 1e-5   # north_star: within 1e-5 for float keyed layers (MFMA path); bit-exact elsewhere
+
+
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def close(a, b, tol=TOL):
+    return float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max()))
+
+
+def test_device_is_gfx950():
+    (n, arch) = _capi.device_info()
+    assert n >= 1 and 'gfx950' in arch, arch
+
+
+@pytest.mark.parametrize('name', EXACT_NETS)
+def test_permutation_keynet_bit_exact_per_layer(golden, name):
+    """Order-preserving CSR kernels == reference outputs (scipy csr_matvecs), bit for bit, every layer, batch > 1."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    y = torch.as_tensor(z['x_cipher']).to(dev())
+    for (lname, child) in knet._keynet.named_children():
+        if isinstance(child, KeyedLayer):
+            y = child.forward(y)
+        else:
+            y = ksys._relu_block(y)
+        assert np.array_equal(y.cpu().numpy(), z['Y.%s' % lname]), 'layer %s of %s' % (lname, name)
+    # fused-ReLU forward gives the same final logits
+    out = knet.forward_linear(torch.as_tensor(z['x_cipher']).to(dev())).cpu().numpy()
+    assert np.array_equal(out, z['Y.%s' % [str(n) for n in z['layer_names']][-1]])
+    assert np.array_equal(out, oracle.keynet_forward(oracle.load_golden_layers(z), z['x_cipher']))
+
+
+@pytest.mark.parametrize('name', TILED_NETS)
+def test_tiled_keynet_layers(golden, name):
+    """Conv2dTiledMatrix on f32 MFMA: within 1e-5; with exact=True (order-preserving path) and for TiledMatrix /
+    SparseMatrix layers: bit for bit.  Inputs to each layer are the reference's own previous-layer outputs."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    names = [str(n) for n in z['layer_names']]
+    prev = z['x_cipher']
+    for (lname, child) in knet._keynet.named_children():
+        ref = z['Y.%s' % lname]
+        if isinstance(child, KeyedLayer):
+            xin = torch.as_tensor(prev).to(dev())
+            y = child.forward(xin).cpu().numpy()
+            if isinstance(child.W, ksp.Conv2dTiledMatrix):
+                assert close(y, ref), 'MFMA layer %s of %s: %g' % (lname, name, np.abs(y - ref).max())
+                ye = child.W.torchdot(xin.t(), exact=True).t().cpu().numpy()
+                assert np.array_equal(ye, ref), 'exact path, layer %s of %s' % (lname, name)
+                # export == the reference's tocsr()
+                c = child.W.tocsr()
+                p = 'L.%s.' % lname
+                assert c.nnz == len(z[p + 'data']) and child.W.nnz() == int(z[p + 'nnz'])
+            else:
+                assert np.array_equal(y, ref), 'layer %s of %s' % (lname, name)
+        prev = ref
+    out = knet.forward_linear(torch.as_tensor(z['x_cipher']).to(dev())).cpu().numpy()
+    assert close(out, z['Y.%s' % names[-1]], tol=2e-5)
+    assert np.allclose(out[:, :-1], z['logits_plain'], atol=1e-4)
+
+
+def test_export_csr_matches_reference_tocsr(golden):
+    z = golden('mini_tiled_permutation.npz')
+    for lname in ('conv1', 'conv2', 'pool1'):
+        p = 'L.%s.' % lname
+        W = kio.operator_from_arrays(z, p)
+        (ip, ix, dt) = W._device_op().export_csr()
+        assert np.array_equal(ip, z[p + 'indptr']) and np.array_equal(ix, z[p + 'indices']) and np.array_equal(dt, z[p + 'data']), lname
+        assert W._device_op().nnz() == int(z[p + 'nnz'])
+        assert W._device_op().shape() == tuple(int(v) for v in z[p + 'shape'])
+
+
+def test_full_stack_seeded_permutation_keynet(golden):
+    """README.md:27-34 flow on the GPU: factory under the seed -> sensor.encrypt -> model.forward == reference."""
+    z = golden('lenet_perm.npz')
+    net = load_weights(LeNet_AvgPool(), z)
+    np.random.seed(0)
+    (sensor, knet) = ksys.PermutationKeynet((1, 28, 28), net)
+    x = torch.as_tensor(z['x_plain'])
+    xc = sensor.fromtensor(x.to(dev())).encrypt().astensor()
+    assert np.array_equal(xc.cpu().numpy(), z['x_cipher'])           # permutation sensor = exact gather
+    y = knet.forward(xc)
+    assert tuple(y.shape) == (8, 10, 1, 1)
+    assert np.array_equal(y.reshape(8, 10).cpu().numpy(), z['logits_keyed'])
+    assert np.allclose(y.reshape(8, 10).cpu().numpy(), z['logits_plain'], atol=1e-5)   # the reference's own criterion
+    # N == 1 API shape and CPU-tensor round trip (drop-in for callers that pass CPU tensors)
+    y1 = knet.forward(sensor.fromtensor(x[0:1]).encrypt().astensor())
+    assert tuple(y1.shape) == (10, 1, 1) and not y1.is_cuda
+    assert np.array_equal(y1.numpy(), z['forward_n1'])
+    # decrypt round trip (permutation key: exact)
+    back = sensor.fromtensor(x).encrypt().decrypt().astensor()
+    assert np.array_equal(back.numpy(), z['x_plain'])
+    # config 1: owl.jpg 28x28
+    yo = knet.forward(torch.as_tensor(z['owl_cipher']).to(dev()))
+    assert np.array_equal(yo.cpu().numpy(), z['owl_forward'])
+
+
+def test_full_stack_tiled_permutation(golden):
+    z = golden('mini_tiled_permutation.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    (sensor, knet) = ksys.TiledPermutationKeynet((2, 16, 16), net, 4)
+    xc = sensor.fromtensor(torch.as_tensor(z['x_plain']).to(dev())).encrypt().astensor()
+    assert np.array_equal(xc.cpu().numpy(), z['x_cipher'])
+    y = knet.forward(xc).reshape(4, 10).cpu().numpy()
+    assert close(y, z['logits_keyed'], tol=2e-5)
+    assert np.allclose(y, z['logits_plain'], atol=1e-4)
+
+
+def test_challenge_known_answer(golden):
+    """demo/challenge.ipynb cell 5 (float64 operators in the pickle -> f32 on the device): all 4 printed decimals."""
+    z = golden('challenge_kat.npz')
+    knet = kio.keynet_from_arrays(z)
+    y = knet.forward_linear(torch.as_tensor(z['x_linear']).to(dev())).cpu().numpy().flatten()[:-1]
+    assert np.array_equal(np.round(y.astype(np.float64), 4), z['published'])
+
+
+def test_tiled_cases(golden):
+    """test/test_sparse.py:122-199 shapes through the device operators."""
+    z = golden('tiled_cases.npz')
+    names = sorted({k.split('.')[1] for k in z.files if k.startswith('C.')})
+    for n in names:
+        p = 'C.%s.' % n
+        W = kio.operator_from_arrays(z, p)
+        x = torch.as_tensor(z[p + 'x']).to(dev())
+        if isinstance(W, ksp.Conv2dTiledMatrix):
+            y = W.torchdot(x).cpu().numpy()
+            assert close(y, z[p + 'y']), n
+            assert np.array_equal(W.torchdot(x, exact=True).cpu().numpy(), z[p + 'y']), n
+            assert np.array_equal(W.dot(z[p + 'x']).shape, z[p + 'y'].shape)
+        else:
+            assert np.array_equal(W.torchdot(x).cpu().numpy(), z[p + 'y']), n
+    # dense / COO SparseMatrix (test_sparse.py:304-329)
+    for M in (z['D.W'], scipy.sparse.coo_matrix(z['D.W'])):
+        A = ksp.SparseMatrix(M)
+        assert np.allclose(A.dot(z['D.x']), z['D.W'].dot(z['D.x']), atol=1e-5)
+        assert np.allclose(A.torchdot(torch.as_tensor(z['D.x'])).numpy(), z['D.W'].dot(z['D.x']), atol=1e-5)
+
+
+@pytest.mark.parametrize('n_vecs', [1, 3, 64, 130, 256, 1024, 2048])
+def test_csr_kernel_vs_oracle_random(n_vecs):
+    """Random non-canonical CSR (unsorted, duplicate columns, empty rows, one long row, repeated patterns) vs the oracle,
+    for every vector width / column-tile path of the kernel."""
+    rng = np.random.RandomState(n_vecs)
+    (m, n) = (301, 157)
+    rows = []
+    for r in range(m):
+        if r % 17 == 0:
+            rows.append(np.zeros(0, dtype=np.int32))                      # empty row
+        elif r == 5:
+            rows.append(rng.randint(0, n, 3000).astype(np.int32))         # long row with duplicates
+        elif r % 3 == 0:
+            rows.append(np.array([7, 3, 99, 3, 150, 0, 42, 41, 40], dtype=np.int32))   # shared pattern -> grouped kernel
+        else:
+            rows.append(rng.randint(0, n, rng.randint(1, 40)).astype(np.int32))
+    indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+    indices = np.concatenate(rows)
+    data = rng.randn(len(indices)).astype(np.float32)
+    X = rng.randn(n, n_vecs).astype(np.float32)
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+    y = W.torchdot(torch.as_tensor(X).to(dev())).cpu().numpy()
+    assert np.array_equal(y, ref)
+    yr = W.torchdot(torch.as_tensor(X).to(dev()), relu=True).cpu().numpy()
+    assert np.array_equal(yr, np.maximum(ref, 0))
+    # non-contiguous input view (what x_affine.t() is for a row-major batch)
+    Xt = torch.as_tensor(np.ascontiguousarray(X.T)).to(dev())
+    assert np.array_equal(W.torchdot(Xt.t()).cpu().numpy(), ref)
+
+
+def test_batch_columns_are_independent(golden):
+    """Size-independent property: column b of a batched forward is bit-identical to the single-image forward."""
+    z = golden('lenet_perm.npz')
+    knet = kio.keynet_from_arrays(z)
+    rng = np.random.RandomState(0)
+    X = np.concatenate([z['x_cipher']] * 128 + [z['x_cipher'][:3]], axis=0)      # 1027 images: ragged tail
+    X[:, :-1] += rng.randn(*X[:, :-1].shape).astype(np.float32) * 0.1
+    yb = knet.forward_linear(torch.as_tensor(X).to(dev())).cpu().numpy()
+    for b in (0, 511, 1026):
+        y1 = knet.forward_linear(torch.as_tensor(X[b:b + 1]).to(dev())).cpu().numpy()
+        assert np.array_equal(yb[b:b + 1], y1)
+    ref = oracle.keynet_forward(oracle.load_golden_layers(z), X[:64])
+    assert np.array_equal(yb[:64], ref)
+
+
+def test_homogeneous_helpers_on_device():
+    x = torch.rand(5, 2, 3, 7)
+    xl = affine_to_linear(x.to(dev()))
+    assert xl.shape == (5, 43) and xl.t().is_contiguous()
+    assert np.array_equal(xl.cpu().numpy(), affine_to_linear(x).numpy())
+    back = linear_to_affine(xl, (5, 2, 3, 7))
+    assert np.array_equal(back.cpu().numpy(), x.numpy())
+    bad = xl.t().contiguous()
+    bad[-1, 2] = 1.01
+    with pytest.raises(ValueError):
+        linear_to_affine(bad.t())
+
+
+def test_error_conventions():
+    W = ksp.SparseMatrix(scipy.sparse.eye(4, dtype=np.float32).tocsr())
+    with pytest.raises(AssertionError):
+        W.torchdot(torch.ones(5, 2).to(dev()))                 # non-conformal (keynet/sparse.py:605)
+    with pytest.raises(_capi.KeynetHipError):
+        _capi.Operator.csr((2, 2), [0, 1, 2], [0, 5], [1.0, 2.0])   # column out of range
+    y = W.torchdot(torch.ones(4, 2, dtype=torch.float64).to(dev()))   # silent f32 coercion (sparse.py:489-491)
+    assert y.dtype == torch.float32
