@@ -11,12 +11,17 @@ import torch.nn.functional as F
 
 from .globals import verbose
 from . import sparse as ksp
+from . import direct as kdirect
 from .sparse import SparseMatrix, sparse_toeplitz_conv2d, sparse_toeplitz_avgpool2d
 from .torch import affine_to_linear_matrix
 
 
 class KeyedLayer(nn.Module):
-    def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None):
+    DIRECT_THRESHOLD = 20000000   # Toeplitz entries above which tiled conv/pool layers are keyed in factored form
+
+    def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None, direct=None):
+        """`direct`: None = automatic (factored, Toeplitz-free keying for tiled conv/avgpool layers whose Toeplitz matrix
+        would exceed DIRECT_THRESHOLD entries -- the reference route cannot build those at all); True / False force it."""
         super(KeyedLayer, self).__init__()
         self._layertype = str(type(module))
         self._tileshape = tileshape
@@ -30,10 +35,16 @@ class KeyedLayer(nn.Module):
             assert module.padding[0] == module.kernel_size[0] // 2 and module.padding[1] == module.kernel_size[1] // 2, 'Padding is assumed to be equal to (kernelsize-1)/2'
             stride = module.stride[0]
             self._repr = 'Conv2d: in_channels=%d, out_channels=%d, kernel_size=%s, stride=%s' % (module.in_channels, module.out_channels, str(module.kernel_size), str(stride))
-            W = sparse_toeplitz_conv2d(inshape, module.weight.detach().numpy(), bias=module.bias.detach().numpy(), stride=stride)
-            W = A.dot(W).dot(Ainv)    # the key: same association as the reference so the stored order matches (keynet/layer.py:35)
-            if tileshape is not None:
-                W = ksp.Conv2dTiledMatrix(W, self._inshape, self._outshape, self._tileshape, bias=True, sanitycheck=False)
+            if direct is None:
+                direct = tileshape is not None and kdirect.toeplitz_entries('conv', inshape, outshape, module.kernel_size[0]) > self.DIRECT_THRESHOLD
+            if direct:
+                kw = kdirect.keyed_conv_taps(module.weight.detach().numpy(), module.bias.detach().numpy(), inshape, outshape, stride, A, Ainv)
+                W = ksp.Conv2dTiledMatrix.fromtaps(tileshape=tileshape, **kw)
+            else:
+                W = sparse_toeplitz_conv2d(inshape, module.weight.detach().numpy(), bias=module.bias.detach().numpy(), stride=stride)
+                W = A.dot(W).dot(Ainv)    # the key: same association as the reference so the stored order matches (keynet/layer.py:35)
+                if tileshape is not None:
+                    W = ksp.Conv2dTiledMatrix(W, self._inshape, self._outshape, self._tileshape, bias=True, sanitycheck=False)
             self.W = W
 
         elif isinstance(module, nn.ReLU):
@@ -47,8 +58,13 @@ class KeyedLayer(nn.Module):
             stride = module.stride if isinstance(module.stride, int) else module.stride[0]
             kernel_size = module.kernel_size if isinstance(module.kernel_size, int) else module.kernel_size[0]
             self._repr = 'AvgPool2d: kernel_size=%s, stride=%s' % (str(kernel_size), str(stride))
-            W = sparse_toeplitz_avgpool2d(inshape, (inshape[0], inshape[0], kernel_size, kernel_size), stride)
-            W = A.dot(W).dot(Ainv) if A is not None else W.dot(Ainv)
+            if direct is None:
+                direct = tileshape is not None and kdirect.toeplitz_entries('pool', inshape, (inshape[0],) + tuple(outshape[1:]), kernel_size) > self.DIRECT_THRESHOLD
+            if direct:
+                W = kdirect.keyed_avgpool_csr(inshape[0], (inshape[1], inshape[2]), kernel_size, stride, A, Ainv)
+            else:
+                W = sparse_toeplitz_avgpool2d(inshape, (inshape[0], inshape[0], kernel_size, kernel_size), stride)
+                W = A.dot(W).dot(Ainv) if A is not None else W.dot(Ainv)
             if tileshape is not None:
                 W = ksp.TiledMatrix(W, self._tileshape)
             self.W = W

@@ -439,9 +439,31 @@ class Conv2dTiledMatrix(TiledMatrix):
             x = torch.as_tensor(x)
         return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=exact)
 
+    def _expand_taps_host(self):
+        """Canonical CSR of a factored operator, on the host (small operators / tests; kn_export_csr does the same)."""
+        t = self._taps
+        (Cout, Hout, Wout) = self._outshape
+        (Cin, Hin, Win) = self._inshape
+        (HoWo, HiWi) = (Hout * Wout, Hin * Win)
+        coef = t['ent_coef'] if t['ent_coef'] is not None else np.ones(len(t['ent_out']), np.float32)
+        (ic, jc) = np.meshgrid(np.arange(Cout), np.arange(Cin), indexing='ij')
+        rows = (t['ent_out'].astype(np.int64)[:, None, None] + (ic * HoWo)[None]).ravel()
+        cols = (t['ent_in'].astype(np.int64)[:, None, None] + (jc * HiWi)[None]).ravel()
+        tv = t['taps'][t['ent_tap']]
+        vals = np.where(coef[:, None, None] == 1.0, tv, coef[:, None, None] * tv).astype(np.float32).ravel()
+        if t['lastcol'] is not None:
+            nz = np.flatnonzero(t['lastcol'])
+            rows = np.concatenate((rows, nz))
+            cols = np.concatenate((cols, np.full(len(nz), Cin * HiWi, dtype=np.int64)))
+            vals = np.concatenate((vals, t['lastcol'][nz]))
+        return scipy.sparse.csr_matrix((vals, (rows, cols)), shape=self.shape)
+
     def nnz(self):
+        """Stored parameters: sum of tile sizes (keynet/sparse.py:778) -- or, for a factored operator, taps + entries +
+        last column (what is actually stored)."""
         if self._tiles is None:
-            return self._device_op().nnz()
+            t = self._taps
+            return int(t['taps'].size + len(t['ent_out']) + (np.count_nonzero(t['lastcol']) if t['lastcol'] is not None else 0))
         return sum([v.size for v in self._tiles.values()])
 
     def transpose(self):
@@ -450,8 +472,7 @@ class Conv2dTiledMatrix(TiledMatrix):
     def tosparse(self, format='coo'):
         """Expansion rule of keynet/sparse.py:802-812, vectorised."""
         if self._tiles is None:
-            (ip, ix, dt) = self._device_op().export_csr()
-            return scipy.sparse.csr_matrix((dt, ix, ip), shape=self.shape).asformat(format)
+            return self._expand_taps_host().asformat(format)
         (Cout, Hout, Wout) = self._outshape
         (Cin, Hin, Win) = self._inshape
         bykey = {}

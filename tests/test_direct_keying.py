@@ -1,0 +1,48 @@
+"""Direct-to-tiled keying (keynet_amd/direct.py) builds the SAME operators as the reference route (Toeplitz -> SpGEMM ->
+tiler), entry for entry, on the golden mini-nets.  CPU only."""
+import numpy as np
+import pytest
+
+import keynet_amd.system as ksys
+import keynet_amd.sparse as ksp
+from keynet_amd.layer import KeyedLayer
+from nets import MiniNet, load_weights
+
+
+@pytest.mark.parametrize('tag,tilesize', [('identity', 4), ('permutation', 4), ('permutation8', 8)])
+def test_direct_equals_reference_route(golden, tag, tilesize):
+    z = golden('mini_tiled_%s.npz' % tag)
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    factory = ksys.TiledIdentityKeynet if tag == 'identity' else ksys.TiledPermutationKeynet
+    (sensor, knet) = factory((2, 16, 16), net, tilesize, direct=True)
+    for (name, child) in knet._keynet.named_children():
+        if not isinstance(child, KeyedLayer):
+            continue
+        p = 'L.%s.' % name
+        c = child.W.tocsr() if isinstance(child.W, ksp.TiledMatrix) else child.W._matrix.tocsr()
+        c.sort_indices()
+        kind = str(z[p + 'kind'])
+        if kind == 'conv2dtiled':
+            assert child.W._taps is not None, 'conv layer was not built in factored form'
+            # the reference's tiled expansion holds the dense channel matrices incl. zero-padded taps at the image border:
+            # compare after dropping explicit zeros on both sides
+            import scipy.sparse
+            ref = scipy.sparse.csr_matrix((z[p + 'data'], z[p + 'indices'], z[p + 'indptr']), shape=c.shape)
+            ref.eliminate_zeros()
+            c.eliminate_zeros()
+            assert np.array_equal(c.indptr, ref.indptr) and np.array_equal(c.indices, ref.indices) and np.array_equal(c.data, ref.data), name
+        elif kind == 'tiled':
+            assert np.array_equal(c.indptr, z[p + 'indptr']) and np.array_equal(c.indices, z[p + 'indices']) and np.array_equal(c.data, z[p + 'data']), name
+            assert np.array_equal(np.array(child.W._blocks), z[p + 'blocks']) and child.W.nnz() == int(z[p + 'nnz'])
+
+
+def test_direct_refuses_global_permutation(golden):
+    """A global permutation is not channel-replicated: the factored route must refuse, not silently mis-key."""
+    from keynet_amd import direct
+    z = golden('lenet_perm.npz')
+    import scipy.sparse
+    shape = tuple(int(v) for v in z['sensor.shape'])
+    A = scipy.sparse.csr_matrix((z['sensor.enc.data'], z['sensor.enc.indices'], z['sensor.enc.indptr']), shape=shape)
+    with pytest.raises((ValueError, AssertionError)):
+        direct.spatial_key(scipy.sparse.block_diag((A[:-1, :-1], A[:-1, :-1].T, [[1]])).tocsr(), 2, 784)   # channel 1 keyed differently
