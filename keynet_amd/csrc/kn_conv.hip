@@ -19,6 +19,7 @@
 namespace kn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of HIP's float4 struct are not promoted to registers
 
 struct ConvArgs {
     const float* tapsT;
@@ -37,8 +38,10 @@ struct ConvArgs {
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
 };
 
-template <int MT, int NB, int KC, int WM, int WN>
-__global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
+// FAST = (batch 16-byte aligned and a multiple of the batch tile NB) && (all coefficients 1: identity / permutation keys) && (Cin % KC == 0):
+// the loaders are straight-line code, so the next chunk's global loads stay in flight in registers during the MFMAs.
+template <int MT, int NB, int KC, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int TM = MT / WM / 32;
     constexpr int TN = NB / WN / 32;
@@ -82,14 +85,14 @@ __global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    float4 ra[AL], rb[BL];
+    f32x4 ra[AL], rb[BL];
 
     auto gload = [&](int q) {
         const int s = s_beg + q / cpk;
         const int ci0 = (q % cpk) * KC;
         const int tap = p.slot_tap[s];
         const int in = p.slot_in[s];
-        const float coef = p.unit_coef ? 1.0f : p.slot_coef[s];
+        const float coef = (FAST || p.unit_coef) ? 1.0f : p.slot_coef[s];
         const float* abase = p.tapsT + ((int64_t)tap * p.cin_pad + ci0) * p.cout_pad + m0;
 #pragma unroll
         for (int i = 0; i < AL; i++) {
@@ -97,8 +100,21 @@ __global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
             if (A4 % 256 == 0 || f < A4) {
                 const int r = f / (MT / 4);
                 const int c4 = f % (MT / 4);
-                ra[i] = *reinterpret_cast<const float4*>(abase + (int64_t)r * p.cout_pad + c4 * 4);
+                ra[i] = *reinterpret_cast<const f32x4*>(abase + (int64_t)r * p.cout_pad + c4 * 4);
             }
+        }
+        if constexpr (FAST) {
+            const float* xbase = p.X + ((int64_t)ci0 * p.HiWi + in) * p.ldx + b0;
+#pragma unroll
+            for (int i = 0; i < BL; i++) {
+                const int f = tid + i * 256;
+                if (B4 % 256 == 0 || f < B4) {
+                    const int r = f / (NB / 4);
+                    const int c4 = f % (NB / 4);
+                    rb[i] = *reinterpret_cast<const f32x4*>(xbase + (int64_t)r * p.HiWi * p.ldx + c4 * 4);
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int i = 0; i < BL; i++) {
@@ -108,20 +124,18 @@ __global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
                 const int c4 = f % (NB / 4);
                 const int ci = ci0 + r;
                 const int b = b0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (ci < p.Cin) {
                     const float* src = p.X + ((int64_t)ci * p.HiWi + in) * p.ldx + b;
                     if (p.vec_ok) {
-                        if (b < p.n_vecs) v = *reinterpret_cast<const float4*>(src);
+                        if (b < p.n_vecs) v = *reinterpret_cast<const f32x4*>(src);
                     } else {
                         if (b + 0 < p.n_vecs) v.x = src[0];
                         if (b + 1 < p.n_vecs) v.y = src[1];
                         if (b + 2 < p.n_vecs) v.z = src[2];
                         if (b + 3 < p.n_vecs) v.w = src[3];
                     }
-                    if (!p.unit_coef) {
-                        v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
-                    }
+                    if (!p.unit_coef) v = v * coef;
                 }
                 rb[i] = v;
             }
@@ -133,12 +147,12 @@ __global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < AL; i++) {
             const int f = tid + i * 256;
-            if (A4 % 256 == 0 || f < A4) *reinterpret_cast<float4*>(a + f * 4) = ra[i];
+            if (A4 % 256 == 0 || f < A4) *reinterpret_cast<f32x4*>(a + f * 4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BL; i++) {
             const int f = tid + i * 256;
-            if (B4 % 256 == 0 || f < B4) *reinterpret_cast<float4*>(b + f * 4) = rb[i];
+            if (B4 % 256 == 0 || f < B4) *reinterpret_cast<f32x4*>(b + f * 4) = rb[i];
         }
     };
 
@@ -155,17 +169,27 @@ __global__ __launch_bounds__(256) void convtaps_mfma_kernel(ConvArgs p) {
         if (q + 1 < n_chunks) gload(q + 1);
         const float* a = As + buf * KC * MT;
         const float* b = Bs + buf * KC * NB;
+        // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk execute (register double buffer)
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = a[arow * MT + acol + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = b[arow * NB + bcol + j * 32];
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
-            float af[TM], bf[TN];
+            const int cur = (kk >> 1) & 1;
+            if (kk + 2 < KC) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = a[(kk + arow) * MT + acol + i * 32];
+                for (int i = 0; i < TM; i++) af[cur ^ 1][i] = a[(kk + 2 + arow) * MT + acol + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = b[(kk + arow) * NB + bcol + j * 32];
+                for (int j = 0; j < TN; j++) bf[cur ^ 1][j] = b[(kk + 2 + arow) * NB + bcol + j * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (q + 1 < n_chunks) lstore(buf ^ 1);
         __syncthreads();
@@ -220,7 +244,9 @@ template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t grid = ((items + 7) / 8) * 8;
-    hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0);
+    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,

@@ -341,12 +341,15 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     auto aligned = [&](int v) {
         return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0);
     };
-    // Prefer 8 or more column tiles (one per XCD) before widening the per-lane vector.
-    if (aligned(4) && n_vecs >= 8 * 256) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (aligned(2) && n_vecs >= 8 * 128) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (aligned(4) && n_vecs >= 256) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (aligned(2) && n_vecs >= 128) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    // Widest per-lane vector that still gives the chip enough wavefronts (>= 4096: 4 per SIMD); a dense Linear at
+    // n_vecs = 256 is ONE pattern group of ~500 row bundles, so it must be split over batch columns instead.
+    const int64_t bundles = (A.n_work + WAVES - 1) / WAVES * WAVES + (A.n_loose + WAVES - 1) / WAVES * WAVES;
+    auto waves = [&](int v) { return bundles * ((n_vecs + 64 * v - 1) / (64 * v)); };
+    if (aligned(4) && waves(4) >= 4096) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (aligned(2) && waves(2) >= 4096) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (n_vecs <= 64 || !aligned(2)) return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (waves(1) >= 2 * waves(2)) return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
 }
 
 }  // namespace kn
