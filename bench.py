@@ -106,6 +106,18 @@ def time_layers(knet, x_cipher, table, iters):
     return table
 
 
+def committed_traffic(workload):
+    """HBM bytes per forward of the dominant kernel from the committed PMC passes (profiles/rNN_<workload>_*_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, FETCH doubled per the guide's gfx950
+    note).  bench.py cannot collect PMC counters on itself; None when no such file is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_*traffic.json' % workload)))
+    if not files:
+        return (None, None)
+    t = json.load(open(files[-1]))
+    return (t.get('convtaps_hbm_bytes_per_forward'), os.path.relpath(files[-1], ROOT))
+
+
 def cpu_baseline(knet, batch_total_nnz, budget_cols=64):
     """CPU oracle (oracle/kn_oracle.c: scipy csr_matvecs restated, 1 thread) on a bounded sample of the workload:
     256 output pixels x all output channels of the largest conv layer (realistic gather pattern), the first pooling
@@ -227,8 +239,10 @@ def main():
         dom_ms = sum(r['ms'] for r in dom)
         if dom_kind == 'mfma':
             ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
-            roof = dict(bound='mfma', kernel='convtaps_mfma_kernel (13 launches/forward)', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, ms_per_forward=dom_ms)
+            (traffic, tsrc) = committed_traffic(args.workload) if batch == 256 else (None, None)
+            roof = dict(bound='mfma', kernel='convtaps_mfma_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc,
+                        algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
         else:
             ach = sum(r['bytes'] for r in dom) / dom_ms / 1e6
             roof = dict(bound='hbm', kernel='csr_group_kernel/csr_rows_kernel', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,

@@ -8,7 +8,8 @@
 //   M = Cout (tile MT), N = batch columns (tile NB, contiguous in HBM: one gathered X row = one coalesced segment),
 //   K = slots(o) x Cin, walked in chunks of KC input channels of one slot.
 // Per workgroup (4 wavefronts): the tap tile [KC][MT] and the gathered X tile [KC][NB] are staged in LDS (double
-// buffered, one barrier per chunk, next chunk's global loads in flight during the MFMAs); each wavefront owns a
+// buffered, one barrier per chunk; 3-stage software pipeline: chunk q in LDS, chunk q+1 in registers and written to the
+// other LDS buffer mid-chunk, chunk q+2's global loads issued right after); each wavefront owns a
 // (TM*32)x(TN*32) sub-tile as TMxTN accumulators of v_mfma_f32_32x32x2_f32; A/B fragments are conflict-free
 // ds_read_b32 (lane&31 -> consecutive dwords, lane>>5 -> k).  Epilogue fuses the bias column (homogeneous coordinate),
 // ReLU and the store (each accumulator register = two coalesced 128-byte row segments).
@@ -49,6 +50,8 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     constexpr int B4 = KC * NB / 4;
     constexpr int AL = (A4 + 255) / 256;            // float4 loads per thread
     constexpr int BL = (B4 + 255) / 256;
+    constexpr int LS_AT = (KC >= 8) ? KC / 2 - 2 : 0;   // k-step at which chunk q+1 is written to LDS ...
+    constexpr int GL_AT = KC / 2;                        // ... and the one at which chunk q+2's global loads are issued
     __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB];
     float* As = lds;                  // [2][KC][MT]
     float* Bs = lds + 2 * KC * MT;    // [2][KC][NB]
@@ -141,6 +144,46 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
             }
         }
     };
+    // FAST path: running pointers.  Within a slot consecutive chunks advance KC input channels (constant strides); the
+    // slot's (tap, input pixel) are re-read only when the slot changes, so the steady state has no scalar loads,
+    // divisions or 64-bit multiplies.  Per-thread element offsets are computed once.
+    uint32_t a_off[AL], b_off[BL];      // element offsets inside one chunk (< 2^31: checked by the launcher)
+#pragma unroll
+    for (int i = 0; i < AL; i++) {
+        const int f = tid + i * 256;
+        a_off[i] = (uint32_t)((f / (MT / 4)) * p.cout_pad + (f % (MT / 4)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < BL; i++) {
+        const int f = tid + i * 256;
+        b_off[i] = (uint32_t)((int64_t)(f / (NB / 4)) * p.HiWi * p.ldx + (f % (NB / 4)) * 4);
+    }
+    const int64_t a_step = (int64_t)KC * p.cout_pad;
+    const int64_t b_step = (int64_t)KC * p.HiWi * p.ldx;
+    const float* a_ptr = nullptr;
+    const float* b_ptr = nullptr;
+    int f_slot = s_beg - 1, f_left = 0;      // next slot to open, chunks left in the open slot
+    auto gload_fast = [&]() {
+        if (f_left == 0) {
+            f_slot++;
+            f_left = cpk;
+            a_ptr = p.tapsT + (int64_t)p.slot_tap[f_slot] * p.cin_pad * p.cout_pad + m0;
+            b_ptr = p.X + (int64_t)p.slot_in[f_slot] * p.ldx + b0;
+        }
+        f_left--;
+#pragma unroll
+        for (int i = 0; i < AL; i++)
+            if (A4 % 256 == 0 || tid + i * 256 < A4) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr + a_off[i]);
+#pragma unroll
+        for (int i = 0; i < BL; i++)
+            if (B4 % 256 == 0 || tid + i * 256 < B4) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr + b_off[i]);
+        a_ptr += a_step;
+        b_ptr += b_step;
+    };
+    auto LOAD = [&](int q) {
+        if constexpr (FAST) gload_fast();     // chunks are requested strictly in order 0,1,2,...
+        else gload(q);
+    };
     auto lstore = [&](int buf) {
         float* a = As + buf * KC * MT;
         float* b = Bs + buf * KC * NB;
@@ -156,17 +199,23 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
         }
     };
 
+    // Software pipeline over K chunks (3 stages): chunk q is consumed from LDS buffer q&1 while chunk q+1 sits in registers
+    // (global loads in flight) and is written to the other LDS buffer in the MIDDLE of chunk q's MFMAs, immediately
+    // followed by the issue of chunk q+2's global loads.  The only work between two chunks' MFMAs is one s_barrier and
+    // the first fragment read, so the co-resident wavefronts of a SIMD do not all leave the matrix pipe idle together.
+    // (LDS WAR: the last readers of buffer (q+1)&1 are chunk q-1's fragment reads, all retired before the barrier that
+    // ended chunk q-1.)
     if (n_chunks > 0) {
-        gload(0);
+        LOAD(0);
         lstore(0);
     }
+    if (n_chunks > 1) LOAD(1);
     __syncthreads();
     const int arow = lane >> 5;
     const int acol = wm * (TM * 32) + (lane & 31);
     const int bcol = wn * (TN * 32) + (lane & 31);
     for (int q = 0; q < n_chunks; q++) {
         const int buf = q & 1;
-        if (q + 1 < n_chunks) gload(q + 1);
         const float* a = As + buf * KC * MT;
         const float* b = Bs + buf * KC * NB;
         // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk execute (register double buffer)
@@ -178,6 +227,8 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
             const int cur = (kk >> 1) & 1;
+            if (kk == LS_AT && q + 1 < n_chunks) lstore(buf ^ 1);
+            if (kk == GL_AT && q + 2 < n_chunks) LOAD(q + 2);
             if (kk + 2 < KC) {
 #pragma unroll
                 for (int i = 0; i < TM; i++) af[cur ^ 1][i] = a[(kk + 2 + arow) * MT + acol + i * 32];
@@ -191,7 +242,6 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (q + 1 < n_chunks) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -244,7 +294,7 @@ template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t grid = ((items + 7) / 8) * 8;
-    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0);
+    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31);
     if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
 }

@@ -177,24 +177,38 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
 
+    // U columns per step; the next step's U gathers are issued before this step's arithmetic (a dense Linear is ONE
+    // group of ~500 bundles, i.e. 1-2 wavefronts per SIMD: latency must be hidden inside the wavefront).
+    constexpr int U = (VEC == 4) ? 4 : 8;
     int j = 0;
-    for (; j + 4 <= ncol; j += 4) {
-        float xv[4][VEC];
+    float xcur[U][VEC], xnxt[U][VEC];
+    if (ncol >= U) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) load_vec<VEC>(xv[u], xc + (int64_t)cols[j + u] * ldx);
+        for (int u = 0; u < U; u++) load_vec<VEC>(xcur[u], xc + (int64_t)cols[u] * ldx);
+    }
+#pragma unroll 2
+    for (; j + U <= ncol; j += U) {
+        if (j + 2 * U <= ncol) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) load_vec<VEC>(xnxt[u], xc + (int64_t)cols[j + U + u] * ldx);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
             const float* a = vals + (int64_t)(j + u) * rpad;   // wave-uniform: scalar loads
 #pragma unroll
             for (int r = 0; r < RB; r++) {
                 const float ar = a[r];
 #pragma unroll
                 for (int v = 0; v < VEC; v++) {
-                    const float p = ar * xv[u][v];
+                    const float p = ar * xcur[u][v];
                     acc[r][v] = acc[r][v] + p;
                 }
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int v = 0; v < VEC; v++) xcur[u][v] = xnxt[u][v];
     }
     for (; j < ncol; j++) {
         float xv[VEC];
