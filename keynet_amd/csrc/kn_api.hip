@@ -195,7 +195,37 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     }
     c.max_slots = mx;
     c.nslots = (int64_t)order.size();
-    std::iota(pix_order.begin(), pix_order.end(), 0);
+    // Processing order of the output pixels: breadth-first over "shares an input pixel" (Cuthill-McKee without the degree
+    // sort).  For a keyed (spatially permuted) conv this recovers the locality the key destroyed: consecutive pixels of
+    // the order share most of their gathered input rows, and consecutive work items run on one XCD at the same time.
+    {
+        std::vector<int32_t> in_ptr((size_t)HiWi + 1, 0), in_outs(order.size());
+        for (size_t k = 0; k < order.size(); k++) in_ptr[(size_t)slot_in[k] + 1]++;
+        for (int64_t i = 0; i < HiWi; i++) in_ptr[(size_t)i + 1] += in_ptr[(size_t)i];
+        std::vector<int32_t> fill(in_ptr.begin(), in_ptr.end() - 1);
+        for (int64_t o = 0; o < HoWo; o++)
+            for (int32_t k = pix_ptr[(size_t)o]; k < pix_ptr[(size_t)o + 1]; k++) in_outs[(size_t)fill[(size_t)slot_in[(size_t)k]]++] = (int32_t)o;
+        std::vector<char> seen((size_t)HoWo, 0);
+        size_t head = 0, tail = 0;
+        for (int64_t seed = 0; seed < HoWo; seed++) {
+            if (seen[(size_t)seed]) continue;
+            seen[(size_t)seed] = 1;
+            pix_order[tail++] = (int32_t)seed;
+            while (head < tail) {
+                const int32_t o = pix_order[head++];
+                for (int32_t k = pix_ptr[(size_t)o]; k < pix_ptr[(size_t)o + 1]; k++) {
+                    const int32_t i = slot_in[(size_t)k];
+                    for (int32_t q = in_ptr[(size_t)i]; q < in_ptr[(size_t)i + 1]; q++) {
+                        const int32_t o2 = in_outs[(size_t)q];
+                        if (!seen[(size_t)o2]) {
+                            seen[(size_t)o2] = 1;
+                            pix_order[tail++] = o2;
+                        }
+                    }
+                }
+            }
+        }
+    }
     std::vector<float> lastcol;
     if (b.has_last) {
         lastcol.assign((size_t)rows, 0.0f);

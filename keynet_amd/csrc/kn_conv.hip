@@ -20,6 +20,7 @@
 namespace kn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+static constexpr int MAX_FAST_SLOTS = 64;   // slots per output pixel the FAST path keeps in LDS (3x3 .. 7x7 windows)
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of HIP's float4 struct are not promoted to registers
 
 struct ConvArgs {
@@ -35,7 +36,7 @@ struct ConvArgs {
     int64_t ldx, ldy;
     int32_t cin_pad, cout_pad, Cin, Cout, HiWi, HoWo;
     int32_t n_vecs, relu, unit_coef, vec_ok;
-    int32_t n_mt, n_bt, n_pix;
+    int32_t n_mt, n_bt, n_pix, max_slots, ntaps;
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
 };
 
@@ -52,9 +53,11 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     constexpr int BL = (B4 + 255) / 256;
     constexpr int LS_AT = (KC >= 8) ? KC / 2 - 2 : 0;   // k-step at which chunk q+1 is written to LDS ...
     constexpr int GL_AT = KC / 2;                        // ... and the one at which chunk q+2's global loads are issued
-    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB];
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 2 * MAX_FAST_SLOTS];
     float* As = lds;                  // [2][KC][MT]
     float* Bs = lds + 2 * KC * MT;    // [2][KC][NB]
+    int32_t* s_aoff = reinterpret_cast<int32_t*>(lds + 2 * KC * MT + 2 * KC * NB);   // FAST: per-slot tap offset (elements)
+    int32_t* s_boff = s_aoff + MAX_FAST_SLOTS;                                       //       per-slot input-pixel row offset
 
     // ---- work item ------------------------------------------------------------------------------------------
     const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
@@ -158,27 +161,35 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
         const int f = tid + i * 256;
         b_off[i] = (uint32_t)((int64_t)(f / (NB / 4)) * p.HiWi * p.ldx + (f % (NB / 4)) * 4);
     }
+    // K order: input-channel chunk OUTER, slot INNER.  Workgroups of neighbouring output pixels (which share most of
+    // their input pixels, at different slot positions) then touch the same activation tile within a few chunk-times,
+    // so the second use hits the XCD's L2 instead of going back to the fabric.
     const int64_t a_step = (int64_t)KC * p.cout_pad;
     const int64_t b_step = (int64_t)KC * p.HiWi * p.ldx;
-    const float* a_ptr = nullptr;
-    const float* b_ptr = nullptr;
-    int f_slot = s_beg - 1, f_left = 0;      // next slot to open, chunks left in the open slot
-    auto gload_fast = [&]() {
-        if (f_left == 0) {
-            f_slot++;
-            f_left = cpk;
-            a_ptr = p.tapsT + (int64_t)p.slot_tap[f_slot] * p.cin_pad * p.cout_pad + m0;
-            b_ptr = p.X + (int64_t)p.slot_in[f_slot] * p.ldx + b0;
+    const float* a_base = p.tapsT + m0;
+    const float* b_base = p.X + b0;
+    int f_slot = 0;
+    if constexpr (FAST) {
+        if (tid < n_slots) {
+            s_aoff[tid] = p.slot_tap[s_beg + tid] * p.cin_pad * p.cout_pad;
+            s_boff[tid] = p.slot_in[s_beg + tid] * (int32_t)p.ldx;
         }
-        f_left--;
+        __syncthreads();
+    }
+    auto gload_fast = [&]() {
+        const float* a_ptr = a_base + s_aoff[f_slot];
+        const float* b_ptr = b_base + s_boff[f_slot];
 #pragma unroll
         for (int i = 0; i < AL; i++)
             if (A4 % 256 == 0 || tid + i * 256 < A4) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr + a_off[i]);
 #pragma unroll
         for (int i = 0; i < BL; i++)
             if (B4 % 256 == 0 || tid + i * 256 < B4) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr + b_off[i]);
-        a_ptr += a_step;
-        b_ptr += b_step;
+        if (++f_slot == n_slots) {
+            f_slot = 0;
+            a_base += a_step;
+            b_base += b_step;
+        }
     };
     auto LOAD = [&](int q) {
         if constexpr (FAST) gload_fast();     // chunks are requested strictly in order 0,1,2,...
@@ -294,7 +305,8 @@ template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t grid = ((items + 7) / 8) * 8;
-    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31);
+    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
+                      a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
 }
@@ -326,6 +338,8 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.unit_coef = A.unit_coef ? 1 : 0;
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
+    a.max_slots = A.max_slots;
+    a.ntaps = (int32_t)A.ntaps;
     a.last_in_row = A.Cin * A.Hin * A.Win;
     const bool big_m = A.cout_pad % 128 == 0 && A.Cout > 64;
     const bool k16 = A.cin_pad % 16 == 0;
