@@ -97,6 +97,15 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3],
                        const float* lastcol,
                        kn_handle_t* out);
 
+/* A DENSE operator (keyed nn.Linear: keynet/layer.py:67-70 stores it as a sparse matrix whose every entry is present)
+ * for callers that accept the float-key tolerance (1e-5) instead of scipy's exact accumulation order -- i.e. the tiled
+ * key-nets, whose conv layers already run on the matrix cores.  W is the full keyed matrix, HOST, row-major
+ * [rows][cols] INCLUDING the homogeneous row (e_last) and the bias column; rows-1 outputs, cols-1 inputs.
+ * kn_spmm computes it as a split-K f32-MFMA GEMM (K slices = pseudo-pixels of the conv-taps kernel) followed by an
+ * ordered reduction over the slices (deterministic: no atomics).  Returns KN_ERR_UNSUPPORTED when cols-1 is not a
+ * multiple of 256 (use kn_csr_create then).  KN_FLAG_EXACT is refused on such a handle. */
+int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out);
+
 int kn_destroy(kn_handle_t h);
 
 /* SparseMatrix.nnz / TiledMatrix.nnz / Conv2dTiledMatrix.nnz (keynet/sparse.py:494,649,778): stored parameters. */

@@ -17,7 +17,7 @@ KN_ABI_VERSION = 1
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_relu',
+           'kn_convtaps_create', 'kn_dense_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -51,6 +51,7 @@ def lib():
         L.kn_tiled_create.argtypes = [i64, i64, i64, p, i64, p, p, p, p, p]
         L.kn_conv2dtiled_create.argtypes = [i64, i64, p, p, i64, p, i64, p, p, p, p, p]
         L.kn_convtaps_create.argtypes = [p, p, i64, p, i64, p, p, p, p, p, p]
+        L.kn_dense_create.argtypes = [i64, i64, p, p]
         L.kn_destroy.argtypes = [p]
         L.kn_nnz.argtypes = [p, p]
         L.kn_nnz_expanded.argtypes = [p, p]
@@ -159,6 +160,14 @@ class Operator(object):
             assert len(lc) == int(outs[0] * outs[1] * outs[2]) + 1
         h = ctypes.c_void_p()
         check(lib().kn_convtaps_create(insp, outsp, int(tp.shape[0]), tpp, int(len(eo)), eop, eip, etp, ecp, lcp, ctypes.byref(h)))
+        return Operator(h)
+
+    @staticmethod
+    def dense(W):
+        (w, wp) = _np(W, np.float32)
+        assert w.ndim == 2
+        h = ctypes.c_void_p()
+        check(lib().kn_dense_create(int(w.shape[0]), int(w.shape[1]), wp, ctypes.byref(h)))
         return Operator(h)
 
     def nnz(self):

@@ -453,9 +453,66 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int6
     return convtaps_create_impl(b, out);
 }
 
+int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out) {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(rows >= 2 && cols >= 2 && W != nullptr, KN_ERR_INVALID, "bad argument");
+    const int64_t outs = rows - 1, ins = cols - 1;
+    KN_REQUIRE(ins % 256 == 0, KN_ERR_UNSUPPORTED, "dense operator needs (cols-1) % 256 == 0");
+    for (int64_t c = 0; c < ins; c++) KN_REQUIRE(W[(size_t)(outs * cols + c)] == 0.0f, KN_ERR_INVALID, "last row is not homogeneous (e_last)");
+    // K slices: feature f = ci*S + s  <->  (input channel ci, pseudo-pixel s); S chosen so a launch has >= ~1000 workgroups
+    int64_t S = 16;
+    while (S > 1 && ins % (16 * S) != 0) S >>= 1;
+    const int64_t cinp = ins / S;
+    ConvBuild b;
+    b.inshape[0] = cinp; b.inshape[1] = 1; b.inshape[2] = S;
+    b.outshape[0] = outs; b.outshape[1] = 1; b.outshape[2] = S;
+    b.has_last = false;
+    b.taps.resize((size_t)(S * outs * cinp));
+    for (int64_t s = 0; s < S; s++)
+        for (int64_t co = 0; co < outs; co++) {
+            const float* wr = W + (size_t)(co * cols);
+            float* t = b.taps.data() + (size_t)((s * outs + co) * cinp);
+            for (int64_t ci = 0; ci < cinp; ci++) t[ci] = wr[ci * S + s];
+        }
+    for (int64_t s = 0; s < S; s++) {
+        b.ent_out.push_back((int32_t)s);
+        b.ent_in.push_back((int32_t)s);
+        b.ent_tap.push_back((int32_t)s);
+        b.ent_coef.push_back(1.0f);
+    }
+    kn_operator* sub = nullptr;
+    int rc = convtaps_create_impl(b, &sub);
+    if (rc) return rc;
+    kn_operator* h = new kn_operator();
+    h->kind = KIND_DENSE;
+    h->device = sub->device;
+    h->rows = rows;
+    h->cols = cols;
+    h->dense_sub = sub;
+    h->dense_splits = S;
+    std::vector<float> lastcol((size_t)rows);
+    int64_t nnz = 0;
+    for (int64_t r = 0; r < rows; r++) {
+        lastcol[(size_t)r] = W[(size_t)(r * cols + ins)];
+        for (int64_t c = 0; c < cols; c++) nnz += (W[(size_t)(r * cols + c)] != 0.0f);
+    }
+    h->nnz_stored = nnz;
+    h->nnz_expanded = nnz;
+    if ((rc = upload(&h->dense_lastcol, lastcol.data(), lastcol.size()))) {
+        kn_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return KN_OK;
+}
+
 int kn_destroy(kn_handle_t h) {
     if (!h) return KN_OK;
     if (h->exact) kn_destroy(h->exact);
+    if (h->dense_sub) kn_destroy(h->dense_sub);
+    if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
+    if (h->dense_ws) (void)hipFree(h->dense_ws);
     csr_free(h->csr);
     convtaps_free(h->ct);
     delete h;
@@ -492,6 +549,7 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
         }
         return KN_OK;
     }
+    KN_REQUIRE(h->kind == KIND_CONVTAPS, KN_ERR_UNSUPPORTED, "kn_export_csr: dense operators are exported by their creator (the host keeps the matrix)");
     std::vector<int32_t> ip, ix;
     std::vector<float> dt;
     std::vector<int64_t> lr;
@@ -518,6 +576,23 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
     KN_REQUIRE(x_dev != y_dev, KN_ERR_INVALID, "x and y alias");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (h->kind == KIND_CSR) return csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    if (h->kind == KIND_DENSE) {
+        KN_REQUIRE(!(flags & KN_FLAG_EXACT), KN_ERR_UNSUPPORTED, "KN_FLAG_EXACT on a dense (MFMA) operator: create it with kn_csr_create instead");
+        const int64_t outs = h->rows - 1, S = h->dense_splits;
+        {
+            // partial-sum workspace, grown on demand (not capturable the first time a larger batch is seen)
+            std::lock_guard<std::mutex> g(h->lazy_mu);
+            if (h->dense_ws_vecs < n_vecs) {
+                if (h->dense_ws) KN_HIP(hipFree(h->dense_ws));
+                h->dense_ws = nullptr;
+                KN_HIP(hipMalloc((void**)&h->dense_ws, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs));
+                h->dense_ws_vecs = n_vecs;
+            }
+        }
+        int rc = convtaps_spmm(h->dense_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, h->dense_ws, n_vecs, 0, s);
+        if (rc) return rc;
+        return dense_reduce(h->dense_ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
+    }
     if (flags & KN_FLAG_EXACT) {
         kn_operator* t = nullptr;
         int rc = get_exact_twin(h, &t);

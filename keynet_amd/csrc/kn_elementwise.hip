@@ -65,6 +65,34 @@ __global__ __launch_bounds__(256) void fill_row_kernel(float* __restrict__ row, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) row[i] = v;
 }
 
+// y[o, b] = (sum_s z[o*S + s, b], s ascending) + lastcol[o] * xlast[b]   (+ReLU);  y[outs, b] = lastcol[outs] * xlast[b]
+__global__ __launch_bounds__(256) void dense_reduce_kernel(const float* __restrict__ z, int64_t ldz, int64_t outs, int splits, const float* __restrict__ lastcol,
+                                                           const float* __restrict__ xlast, float* __restrict__ y, int64_t ldy, int64_t n_vecs, int relu) {
+    const int64_t total = (outs + 1) * n_vecs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o = i / n_vecs;
+        const int64_t b = i - o * n_vecs;
+        float acc = 0.0f;
+        if (o < outs) {
+            const float* zp = z + (o * splits) * ldz + b;
+            for (int s = 0; s < splits; s++) acc = acc + zp[(int64_t)s * ldz];
+        }
+        const float bp = lastcol[o] * xlast[b];
+        acc = acc + bp;
+        if (relu) acc = (acc < 0.0f) ? 0.0f : acc;
+        y[o * ldy + b] = acc;
+    }
+}
+
+int dense_reduce(const float* z, int64_t ldz, int64_t outs, int64_t splits, const float* lastcol, const float* xlast, float* y, int64_t ldy, int64_t n_vecs,
+                 int relu, hipStream_t s) {
+    const int64_t total = (outs + 1) * n_vecs;
+    const int64_t grid = std::min<int64_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, z, ldz, outs, (int)splits, lastcol, xlast, y, ldy, n_vecs, relu);
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
 int affine_to_linear(const float* x, int64_t n, int64_t d, float* out, int64_t ldo, hipStream_t s) {
     if (n <= 0) return KN_OK;
     if (d > 0) {

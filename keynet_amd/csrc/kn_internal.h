@@ -25,7 +25,7 @@ int fail(int code, const std::string& msg);
         if (!(cond)) return kn::fail((code), std::string(msg) + " [" #cond "]");                       \
     } while (0)
 
-enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1 };
+enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2 };
 
 // Order-preserving CSR resident in HBM.
 struct CsrDev {
@@ -83,6 +83,12 @@ struct kn_operator {
     std::vector<float> h_ent_coef, h_taps, h_lastcol;
     std::mutex lazy_mu;
     kn_operator* exact = nullptr;  // lazily expanded CSR twin (KN_FLAG_EXACT on a conv-taps operator)
+    // dense (Linear) operator: split-K conv-taps sub-operator + ordered reduction
+    kn_operator* dense_sub = nullptr;
+    int64_t dense_splits = 0;
+    float* dense_lastcol = nullptr;   // [rows] bias column incl. the homogeneous 1
+    float* dense_ws = nullptr;        // [ (rows-1) * splits, ws_vecs ] partial sums
+    int64_t dense_ws_vecs = 0;
 };
 
 namespace kn {
@@ -92,6 +98,8 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
                   uint32_t flags, hipStream_t s);
 int relu_inplace(float* y, int64_t rows, int64_t ld, int64_t n_vecs, hipStream_t s);
+int dense_reduce(const float* z, int64_t ldz, int64_t outs, int64_t splits, const float* lastcol, const float* xlast, float* y, int64_t ldy, int64_t n_vecs,
+                 int relu, hipStream_t s);
 int affine_to_linear(const float* x, int64_t n, int64_t d, float* out, int64_t ldo, hipStream_t s);
 int linear_to_affine(const float* y, int64_t ldy, int64_t n, int64_t d, float* out, float* maxdev, hipStream_t s);
 void csr_free(CsrDev& c);

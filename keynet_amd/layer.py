@@ -19,10 +19,14 @@ from .torch import affine_to_linear_matrix
 class KeyedLayer(nn.Module):
     DIRECT_THRESHOLD = 20000000   # Toeplitz entries above which tiled conv/pool layers are keyed in factored form
 
-    def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None, direct=None):
+    def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None, direct=None, exact=None):
         """`direct`: None = automatic (factored, Toeplitz-free keying for tiled conv/avgpool layers whose Toeplitz matrix
-        would exceed DIRECT_THRESHOLD entries -- the reference route cannot build those at all); True / False force it."""
+        would exceed DIRECT_THRESHOLD entries -- the reference route cannot build those at all); True / False force it.
+        `exact`: True = every product in the reference's accumulation order and rounding (bit-exact with scipy);
+        False = float-key tolerance (1e-5): conv-taps and large dense operators run on the matrix cores.  None = exact
+        for untiled layers (the permutation key-nets), tolerance for tiled ones (BASELINE north_star)."""
         super(KeyedLayer, self).__init__()
+        self._exact = (tileshape is None) if exact is None else bool(exact)
         self._layertype = str(type(module))
         self._tileshape = tileshape
         self._inshape = inshape
@@ -85,10 +89,11 @@ class KeyedLayer(nn.Module):
             self.W = SparseMatrix(self.W)
 
     @classmethod
-    def fromoperator(cls, W, layertype, inshape=None, outshape=None, repr_=None):
+    def fromoperator(cls, W, layertype, inshape=None, outshape=None, repr_=None, exact=None):
         """Wrap an already keyed operator (a public key-net loaded from a neutral file, a fixture, a direct build)."""
         self = cls.__new__(cls)
         nn.Module.__init__(self)
+        self._exact = (not isinstance(W, ksp.Conv2dTiledMatrix)) if exact is None else bool(exact)
         (self._layertype, self._tileshape, self._inshape, self._outshape) = (layertype, None, inshape, outshape)
         self._repr = repr_ if repr_ is not None else layertype
         self.W = W if isinstance(W, SparseMatrix) else SparseMatrix(W)
@@ -106,7 +111,7 @@ class KeyedLayer(nn.Module):
         that follows this layer in the key-net (keynet/system.py:92) into the kernel epilogue."""
         if verbose():
             print('[keynet_amd.layer]: forward %s' % str(self))
-        y = self.W.torchdot(x_affine.t(), relu=(fuse_relu or self.iskeyedrelu())).t()
+        y = self.W.torchdot(x_affine.t(), relu=(fuse_relu or self.iskeyedrelu()), exact=getattr(self, '_exact', True)).t()
         return y
 
     def decrypt(self, Ainv, x_affine):

@@ -76,6 +76,7 @@ class SparseMatrix(object):
         self.dtype = A.dtype if A is not None else None
         self.ndim = 2
         self._op = None
+        self._op_dense = None
 
     def __repr__(self):
         return str('<keynet_amd.SparseMatrix: H=%d, W=%d, backend=hip>' % (self.shape[0], self.shape[1]))
@@ -83,6 +84,7 @@ class SparseMatrix(object):
     def __getstate__(self):
         d = dict(self.__dict__)
         d['_op'] = None   # device handles do not pickle; rebuilt lazily
+        d['_op_dense'] = None
         return d
 
     def __add__(self, other):
@@ -102,8 +104,32 @@ class SparseMatrix(object):
             self._op = _capi.Operator.csr(self.shape, ip, ix, dt)
         return self._op
 
-    def torchdot(self, x_torch, relu=False):
-        """W . x for x of shape [W.shape[1], N]: the hot path (keynet/sparse.py:488-492), bit-exact with scipy."""
+    DENSE_MIN_ELEMENTS = 1 << 20
+
+    def _dense_device_op(self):
+        """kn_dense_create handle for a (nearly) dense operator such as a keyed nn.Linear, or None when not eligible."""
+        if getattr(self, '_op_dense', None) is None:
+            M = self._matrix
+            (r, c) = self.shape
+            ok = (M is not None and r * c >= self.DENSE_MIN_ELEMENTS and (c - 1) % 256 == 0 and
+                  (M.nnz if is_scipy_sparse(M) else M.size) >= 0.5 * r * c)
+            if ok:
+                D = np.asarray(M.todense() if is_scipy_sparse(M) else M, dtype=np.float32)
+                ok = bool(np.all(D[-1, :-1] == 0))
+                if ok:
+                    self._op_dense = _capi.Operator.dense(D)
+            if not ok:
+                self._op_dense = False
+        return self._op_dense or None
+
+    def torchdot(self, x_torch, relu=False, exact=True):
+        """W . x for x of shape [W.shape[1], N]: the hot path (keynet/sparse.py:488-492).  exact=True (default): bit-exact
+        with scipy (order-preserving CSR kernels).  exact=False: a large dense operator (keyed nn.Linear) may run as a
+        split-K f32-MFMA GEMM instead (within 1e-5; used by the tiled key-nets whose conv layers are on MFMA anyway)."""
+        if not exact:
+            op = self._dense_device_op()
+            if op is not None:
+                return _run_torchdot(op, self.shape, x_torch, relu=relu, exact=False)
         return _run_torchdot(self._device_op(), self.shape, x_torch, relu=relu, exact=True)
 
     def dot(self, x_numpy):
@@ -129,7 +155,7 @@ class SparseMatrix(object):
         assert isinstance(A, SparseMatrix) or is_scipy_sparse(A)
         self._matrix = self._matrix.dot(A._matrix if isinstance(A, SparseMatrix) else A)
         self.shape = self._matrix.shape
-        self._op = None
+        (self._op, self._op_dense) = (None, None)
         return self
 
     def nnz(self):
@@ -138,7 +164,7 @@ class SparseMatrix(object):
     def transpose(self):
         self._matrix = self._matrix.transpose()
         self.shape = self._matrix.shape
-        self._op = None
+        (self._op, self._op_dense) = (None, None)
         return self
 
     def tocoo(self):
@@ -211,8 +237,8 @@ class TiledMatrix(SparseMatrix):
             self._op = _capi.Operator.tiled(self.shape, np.array(list(self), dtype=np.int64).reshape(-1, 3), ptr, tr, tc, tv)
         return self._op
 
-    def torchdot(self, x, relu=False):
-        """[cols, N] -> [rows, N] (keynet/sparse.py:603-612)."""
+    def torchdot(self, x, relu=False, exact=True):
+        """[cols, N] -> [rows, N] (keynet/sparse.py:603-612); always the order-preserving path (bit-exact)."""
         if isinstance(x, np.ndarray):
             x = torch.as_tensor(x)
         return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=True)

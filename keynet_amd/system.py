@@ -276,14 +276,16 @@ class PublicKeyedSensor(KeyedSensor):
 BACKENDS = ('hip',)
 
 
-def layergen(module, inshape, outshape, A, Ainv, tileshape=None, backend='hip', direct=None):
+def layergen(module, inshape, outshape, A, Ainv, tileshape=None, backend='hip', direct=None, exact=None):
     """The plug-in seam of the reference (keynet/system.py:303-314): snaps the requested tile to divisors of the
     layer's spatial sizes, then dispatches on `backend`.  The reference accepts only 'scipy'; this build registers
     'hip'.  Anything else raises ValueError('invalid backend ...') exactly like the reference."""
+    if exact is None:
+        exact = tileshape is None       # untiled key-nets: bit-exact; tiled key-nets: float-key tolerance (MFMA)
     if tileshape is not None:
         tileshape = (find_closest_positive_divisor(outshape[1], tileshape[0]), find_closest_positive_divisor(inshape[1], tileshape[1]))
     if backend == 'hip':
-        return klayer.KeyedLayer(module, inshape, outshape, A, Ainv, tileshape=tileshape, direct=direct)
+        return klayer.KeyedLayer(module, inshape, outshape, A, Ainv, tileshape=tileshape, direct=direct, exact=exact)
     raise ValueError('invalid backend "%s"' % backend)
 
 
@@ -400,12 +402,12 @@ def diagonal_affine_to_linear(A, bias=None, withinverse=False, dtype=np.float32)
 
 def Keynet(inshape, net=None, backend='hip', global_photometric='identity', local_photometric='identity', global_geometric='identity',
            local_geometric='identity', memoryorder='channel', do_output_encryption=False, alpha=None, beta=None, gamma=None,
-           hierarchical_blockshape=None, hierarchical_permute_at_level=None, blocksize=None, tileshape=None, direct=None):
+           hierarchical_blockshape=None, hierarchical_permute_at_level=None, blocksize=None, tileshape=None, direct=None, exact=None):
     """(sensor, model) for `net` under the chosen key family (keynet/system.py:472-486).  ReLU outputs only admit keys
     that commute with ReLU: a 'relu*' layer keeps identity where identity was asked and otherwise falls back to the
     positive-gain / permutation members of the family (keynet/system.py:476-480)."""
     def f_layergen(module, inshape_, outshape_, A, Ainv):
-        return layergen(module, inshape_, outshape_, A, Ainv, tileshape=tileshape, backend=backend, direct=direct)
+        return layergen(module, inshape_, outshape_, A, Ainv, tileshape=tileshape, backend=backend, direct=direct, exact=exact)
 
     def f_keypair(layername, shape):
         isrelu = 'relu' in layername
@@ -432,9 +434,9 @@ def PermutationKeynet(inshape, net, do_output_encryption=False):
     return Keynet(inshape, net, global_geometric='permutation', do_output_encryption=do_output_encryption)
 
 
-def TiledIdentityKeynet(inshape, net, tilesize, direct=None):
-    return Keynet(inshape, net, tileshape=(tilesize, tilesize), direct=direct)
+def TiledIdentityKeynet(inshape, net, tilesize, direct=None, exact=None):
+    return Keynet(inshape, net, tileshape=(tilesize, tilesize), direct=direct, exact=exact)
 
 
-def TiledPermutationKeynet(inshape, net, tilesize, direct=None):
-    return Keynet(inshape, net, local_geometric='permutation', tileshape=(tilesize, tilesize), blocksize=tilesize, direct=direct)
+def TiledPermutationKeynet(inshape, net, tilesize, direct=None, exact=None):
+    return Keynet(inshape, net, local_geometric='permutation', tileshape=(tilesize, tilesize), blocksize=tilesize, direct=direct, exact=exact)

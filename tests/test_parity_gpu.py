@@ -179,6 +179,36 @@ def test_tiled_cases(golden):
         assert np.allclose(A.torchdot(torch.as_tensor(z['D.x'])).numpy(), z['D.W'].dot(z['D.x']), atol=1e-5)
 
 
+@pytest.mark.parametrize('n_vecs', [4, 256, 200])
+def test_dense_linear_mfma_vs_oracle(n_vecs):
+    """A keyed nn.Linear as a split-K f32-MFMA GEMM (kn_dense_create; tolerance mode of the tiled key-nets) vs the oracle;
+    the same operator with exact=True stays bit-exact."""
+    rng = np.random.RandomState(7)
+    (outs, ins) = (1100, 1024)
+    D = np.zeros((outs + 1, ins + 1), dtype=np.float32)
+    D[:-1, :-1] = (rng.randn(outs, ins) / np.sqrt(ins)).astype(np.float32)
+    D[:-1, -1] = rng.randn(outs).astype(np.float32)
+    D[-1, -1] = 1.0
+    perm = rng.permutation(ins)
+    M = scipy.sparse.csr_matrix(D)
+    M = scipy.sparse.csr_matrix((M.data, np.where(M.indices < ins, perm[np.minimum(M.indices, ins - 1)], M.indices).astype(np.int32), M.indptr), shape=M.shape)  # unsorted columns
+    W = ksp.SparseMatrix(M)
+    X = np.vstack((rng.randn(ins, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data, X)
+    xd = torch.as_tensor(X).to(dev())
+    assert np.array_equal(W.torchdot(xd).cpu().numpy(), ref)                       # default: exact
+    assert W._dense_device_op() is not None
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu, exact=False).cpu().numpy()
+        r = np.maximum(ref, 0) if relu else ref
+        assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), np.abs(y - r).max()
+        assert close(y, r, tol=2e-5)
+    Ms = scipy.sparse.csr_matrix(D[:65, :])
+    small = ksp.SparseMatrix(Ms)
+    assert small._dense_device_op() is None                                       # not eligible -> exact CSR path
+    assert np.array_equal(small.torchdot(xd, exact=False).cpu().numpy(), oracle.csr_matvecs(Ms.shape, Ms.indptr, Ms.indices, Ms.data, X))
+
+
 @pytest.mark.parametrize('n_vecs', [1, 3, 64, 130, 256, 1024, 2048])
 def test_csr_kernel_vs_oracle_random(n_vecs):
     """Random non-canonical CSR (unsorted, duplicate columns, empty rows, one long row, repeated patterns) vs the oracle,
