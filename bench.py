@@ -34,7 +34,7 @@ from keynet_amd import sparse as ksp           # noqa: E402
 from keynet_amd import io as kio               # noqa: E402
 from keynet_amd import dist as kdist           # noqa: E402
 from keynet_amd.layer import KeyedLayer        # noqa: E402
-from keynet_amd.models import VGG16, LeNet_AvgPool   # noqa: E402
+from keynet_amd.models import VGG16, LeNet_AvgPool, AllConvNet   # noqa: E402
 from keynet_amd.torch import affine_to_linear  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32-input MFMA = f32 vector peak)
@@ -60,6 +60,12 @@ def build_workload(name, rank, world):
         np.random.seed(0)
         (sensor, knet) = ksys.PermutationKeynet((1, 28, 28), net)
         (inshape, batch, desc) = ((1, 28, 28), 1024, 'PermutationKeynet LeNet_AvgPool 1x28x28')
+    elif name == 'allconv':
+        torch.manual_seed(0)
+        net = AllConvNet(batchnorm=False).eval()
+        np.random.seed(0)
+        (sensor, knet) = ksys.PermutationKeynet((3, 32, 32), net)
+        (inshape, batch, desc) = ((3, 32, 32), 4096, 'PermutationKeynet AllConvNet 3x32x32 (BASELINE configs[2])')
     else:
         raise ValueError('unknown workload "%s"' % name)
     log('[bench rank %d] keyed %s on the host in %.1f s' % (rank, name, time.time() - t0))
@@ -175,7 +181,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'lenet'])
+    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=3)
@@ -250,7 +256,7 @@ def main():
         total_bytes = sum(r['bytes'] for r in table)
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
-            'metric': 'encrypted images/sec (whole node), keyed %s' % ('VGG-16 224x224' if args.workload == 'vgg16' else 'LeNet_AvgPool 28x28'),
+            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
             'value': batch * world * args.steps / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,

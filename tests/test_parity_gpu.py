@@ -276,3 +276,36 @@ def test_error_conventions():
         _capi.Operator.csr((2, 2), [0, 1, 2], [0, 5], [1.0, 2.0])   # column out of range
     y = W.torchdot(torch.ones(4, 2, dtype=torch.float64).to(dev()))   # silent f32 coercion (sparse.py:489-491)
     assert y.dtype == torch.float32
+
+
+def test_allconvnet_permutation_keynet_reduced_width():
+    """BASELINE configs[2] (PermutationKeynet AllConvNet 3x32x32) at reduced channel width (24/48 instead of 96/192; the
+    full width is `bench.py --workload allconv`): full stack on the GPU, bit-exact vs the CPU oracle, equal to the plain
+    net within the reference's own 1e-5 (test/test_keynet.py:222-261), batch columns independent at batch 512."""
+    from keynet_amd.models import AllConvNet
+    torch.manual_seed(0)
+    net = AllConvNet(batchnorm=False, width=24).eval()
+    np.random.seed(0)
+    (sensor, knet) = ksys.PermutationKeynet((3, 32, 32), net)
+    assert knet.num_parameters() > 16000000
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(512, 3, 32, 32, generator=g)
+    xc = sensor.fromtensor(x.to(dev())).encrypt().astensor()
+    y = knet.forward(xc).reshape(512, 10).cpu().numpy()
+    with torch.no_grad():
+        yp = net(x).numpy()
+    assert np.allclose(y, yp, atol=1e-5), np.abs(y - yp).max()
+    # oracle on the first 4 images, layer operators taken from the host-side scipy matrices in stored order
+    layers = []
+    for (name, c) in knet._keynet.named_children():
+        if isinstance(c, KeyedLayer):
+            M = c.W._matrix
+            layers.append((name, (M.shape, M.indptr, M.indices, M.data), False))
+        else:
+            layers.append((name, 'relu', False))
+    ref = oracle.keynet_forward(layers, xc[:4].cpu().numpy())
+    out4 = knet.forward_linear(xc[:4]).cpu().numpy()
+    assert np.array_equal(out4, ref)
+    assert np.array_equal(knet.forward_linear(xc).cpu().numpy()[:4], ref)      # batch 512 vs batch 4: identical columns
+    back = sensor.fromtensor(x[:2]).encrypt().decrypt().astensor()
+    assert np.array_equal(back.numpy(), x[:2].numpy())
