@@ -191,11 +191,20 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    # Test-only override (single-GPU boxes): KN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so the N>1
+    # control flow (sharding, barriers, gather, max-over-ranks timing) can be smoke-tested without 8 GPUs.  Never set by
+    # the driver; the real path is one rank per GPU over RCCL.
+    share = os.environ.get('KN_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
     assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world)
 
     (sensor, knet, inshape, batch, desc) = build_workload(args.workload, rank, world)
@@ -213,7 +222,11 @@ def main():
 
     def step():
         yl = knet.forward_linear(x_cipher)[:, :-1]
-        return kdist.gather_logits(yl, total=batch * world) if world > 1 else yl
+        if world == 1:
+            return yl
+        if share:   # gloo has no device all_gather_into_tensor: bounce through the host (test-only path)
+            return kdist.gather_logits(yl.cpu(), total=batch * world).to(dev)
+        return kdist.gather_logits(yl, total=batch * world)
 
     for _ in range(args.warmup):
         step()
@@ -228,7 +241,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cpu') if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == batch * world and bool(torch.isfinite(out).all())
