@@ -23,6 +23,7 @@ from . import _capi
 from .globals import verbose
 from .util import find_closest_positive_divisor
 from .sparse import sparse_permutation_matrix, sparse_identity_matrix, sparse_affine_to_linear, DiagonalTiledMatrix
+from . import keys as kkeys
 
 
 class KeyedModel(object):
@@ -294,14 +295,16 @@ def _diag_repeat(block, shape):
     return DiagonalTiledMatrix(block, shape=shape).tocoo().astype(np.float32)
 
 
+def _tolist(x):
+    return list(x) if isinstance(x, (list, tuple)) else [x]
+
+
 def keygen(shape, global_geometric, local_geometric, global_photometric, local_photometric, memoryorder='channel', alpha=None, beta=None,
            gamma=None, seed=None, hierarchical_blockshape=None, hierarchical_permute_at_level=None, blocksize=None, tileshape=None, strict=False):
-    """(A, Ainv) = C^-1 . p . g . P . G . C for one layer output of `shape` (keynet/system.py:317-469).
-
-    Families built here: identity everywhere, global 'permutation', local 'permutation' (block-repeated), global
-    photometric 'uniform_random_gain' / 'uniform_random_bias' / 'uniform_random_affine'.  The remaining families of the
-    reference (hierarchical permutation / rotation, Givens, doubly-stochastic, block memory order) are SURVEY 8f "next"
-    row 4 and raise NotImplementedError here rather than silently doing something else."""
+    """(A, Ainv) = C^-1 . p . g . P . G . C for one layer output of `shape` (keynet/system.py:317-469): memory-order
+    change C, global geometric G, global photometric P, local (block-repeated) geometric g and photometric p.  Same
+    option names, same validation, same order of RNG draws and scipy formats as the reference, so a seeded call returns
+    the reference's matrices bit for bit (tests/test_keygen_families.py)."""
     (channels, height, width) = shape
     N = int(np.prod(shape))
     if seed is not None:
@@ -318,17 +321,35 @@ def keygen(shape, global_geometric, local_geometric, global_photometric, local_p
                 blocksize = find_closest_positive_divisor(height, blocksize)
             (H, blocknumel) = (height * width, blocksize * blocksize)
 
-    if memoryorder != 'channel':
-        raise NotImplementedError("memoryorder '%s' (SURVEY 8f next #4)" % memoryorder)
-    (C, Cinv) = (sparse_affine_to_linear(sparse_identity_matrix(N)), sparse_affine_to_linear(sparse_identity_matrix(N)))
+    if memoryorder == 'channel':
+        (c, cinv) = (sparse_identity_matrix(N), sparse_identity_matrix(N))
+    elif memoryorder == 'block':
+        assert blocksize is not None
+        (c, cinv) = kkeys.channelorder_to_blockorder_matrix(shape, blocksize, withinverse=True)
+    else:
+        raise ValueError("Invalid memory order '%s' - must be in ['channel', 'block']" % memoryorder)
+    (C, Cinv) = (sparse_affine_to_linear(c), sparse_affine_to_linear(cinv))
 
     if global_geometric == 'identity':
         (G, Ginv) = (sparse_identity_matrix(N), sparse_identity_matrix(N))
     elif global_geometric == 'permutation':
         assert tileshape is None, 'Global permutation is not tile compressible'
         (G, Ginv) = sparse_permutation_matrix(N, withinverse=True)
-    elif global_geometric in ('hierarchical_permutation', 'hierarchical_rotation', 'givens_orthogonal'):
-        raise NotImplementedError("global_geometric '%s' (SURVEY 8f next #4)" % global_geometric)
+    elif global_geometric in ('hierarchical_permutation', 'hierarchical_rotation'):
+        assert hierarchical_blockshape is not None and hierarchical_permute_at_level is not None
+        levels = _tolist(hierarchical_permute_at_level)
+        levels = levels if max(height, width) / np.power(2, max(levels)) >= 8 else []
+        levels = [] if (height == 1 and width == 1) else levels
+        (Ap, Apinv) = kkeys.channelorder_to_pixelorder_matrix((channels, height, width), withinverse=True)
+        (G, Ginv) = kkeys.hierarchical_block_permutation_matrix((height, width, channels), hierarchical_blockshape, levels, min_blocksize=8, seed=seed,
+                                                                twist=(global_geometric == 'hierarchical_rotation'), withinverse=True, strict=False)
+        (G, Ginv) = (Apinv.dot(G).dot(Ap), Apinv.dot(Ginv).dot(Ap))     # CxHxW -> HxWxC -> permute -> CxHxW
+        if memoryorder != 'channel':
+            (G, Ginv) = (c.dot(G).dot(cinv), c.dot(Ginv).dot(cinv))
+    elif global_geometric == 'givens_orthogonal':
+        assert alpha is not None
+        assert tileshape is None, 'Global givens rotation orthogonal matrix is not tile compressible'
+        (G, Ginv) = kkeys.givens_orthogonal(N, int(alpha), withinverse=True)
     else:
         raise ValueError("Invalid global geometric transform '%s'" % global_geometric)
     (G, Ginv) = (sparse_affine_to_linear(G), sparse_affine_to_linear(Ginv))
@@ -339,34 +360,71 @@ def keygen(shape, global_geometric, local_geometric, global_photometric, local_p
         assert blocksize is not None and height == width
         g = _diag_repeat(_diag_repeat(sparse_permutation_matrix(blocknumel), (H, H)), (N, N))   # spatial repeat, then channel repeat
         ginv = g.transpose()
-    elif local_geometric in ('doubly_stochastic', 'givens_orthogonal'):
-        raise NotImplementedError("local_geometric '%s' (SURVEY 8f next #4)" % local_geometric)
+    elif local_geometric == 'doubly_stochastic':
+        assert blocksize is not None and alpha is not None and height == width
+        assert blocksize < 8192, 'Blocksize %d must be less than 8192, since doubly_stochastic requires the direct inverse of a dense matrix' % blocksize
+        (g, ginv) = kkeys.diagonally_dominant_doubly_stochastic(blocknumel, int(alpha), withinverse=True)
+        g = DiagonalTiledMatrix(DiagonalTiledMatrix(g, shape=(H, H)).tocoo(), shape=(N, N)).tocoo()
+        ginv = DiagonalTiledMatrix(DiagonalTiledMatrix(ginv, shape=(H, H)).tocoo(), shape=(N, N)).tocoo()
+    elif local_geometric == 'givens_orthogonal':
+        assert alpha is not None and blocksize is not None and height == width
+        (g, ginv) = kkeys.givens_orthogonal(blocknumel, int(alpha), withinverse=True)
+        (Ap, Apinv) = sparse_permutation_matrix(blocknumel, withinverse=True)
+        (g, ginv) = (Ap.dot(g), ginv.dot(Apinv))
+        g = _diag_repeat(DiagonalTiledMatrix(g, shape=(H, H)).tocoo(), (N, N))
+        ginv = _diag_repeat(DiagonalTiledMatrix(ginv, shape=(H, H)).tocoo(), (N, N))
     else:
         raise ValueError("Invalid local geometric transform '%s'" % local_geometric)
     (g, ginv) = (sparse_affine_to_linear(g), sparse_affine_to_linear(ginv))
 
+    eye_lin = (lambda: sparse_affine_to_linear(sparse_identity_matrix(N)))
     if global_photometric == 'identity':
-        (P, Pinv) = (sparse_affine_to_linear(sparse_identity_matrix(N)), sparse_affine_to_linear(sparse_identity_matrix(N)))
+        (P, Pinv) = (eye_lin(), eye_lin())
     elif global_photometric == 'uniform_random_gain':
-        assert tileshape is None and beta is not None and beta > 0
-        (P, Pinv) = ksp_uniform_random_diagonal(N, beta, bias=1)
+        assert tileshape is None, 'Global permutation is not tile compressible'
+        assert beta is not None and beta > 0
+        (P, Pinv) = kkeys.uniform_random_diagonal(N, beta, bias=1, withinverse=True)
         (P, Pinv) = (sparse_affine_to_linear(P), sparse_affine_to_linear(Pinv))
     elif global_photometric == 'uniform_random_bias':
         assert gamma is not None and gamma > 0
         (P, Pinv) = diagonal_affine_to_linear(sparse_identity_matrix(N), gamma * np.random.rand(N, 1), withinverse=True)
+    elif global_photometric == 'linear_bias':
+        assert gamma is not None and gamma > 0
+        (P, Pinv) = diagonal_affine_to_linear(sparse_identity_matrix(N), (gamma / float(N)) * np.array(range(0, N)).reshape(N, 1), withinverse=True)
     elif global_photometric == 'uniform_random_affine':
-        assert tileshape is None and beta is not None and beta > 0 and gamma is not None and gamma > 0
-        (Pd, _) = ksp_uniform_random_diagonal(N, beta, bias=1)
+        assert tileshape is None, 'Global permutation is not tile compressible'
+        assert beta is not None and beta > 0 and gamma is not None and gamma > 0
+        Pd = kkeys.uniform_random_diagonal(N, beta, bias=1)
         (P, Pinv) = diagonal_affine_to_linear(Pd, gamma * np.random.rand(N, 1), withinverse=True)
-    elif global_photometric in ('constant_bias', 'linear_bias', 'blockwise_constant_bias'):
-        raise NotImplementedError("global_photometric '%s' (SURVEY 8f next #4)" % global_photometric)
+    elif global_photometric == 'blockwise_constant_bias':
+        assert gamma is not None and gamma > 0
+        assert blocksize is not None
+        bias = gamma * np.random.rand(int(np.ceil(N // blocksize)), 1).dot(np.ones((1, blocknumel))).flatten()[0:N].reshape(N, 1)
+        (P, Pinv) = diagonal_affine_to_linear(sparse_identity_matrix(N), bias, withinverse=True)
     else:
         raise ValueError("Invalid global photometric transform '%s'" % global_photometric)
 
     if local_photometric == 'identity':
-        (p, pinv) = (sparse_affine_to_linear(sparse_identity_matrix(N)), sparse_affine_to_linear(sparse_identity_matrix(N)))
-    elif local_photometric in ('uniform_random_gain', 'uniform_random_bias', 'uniform_random_affine'):
-        raise NotImplementedError("local_photometric '%s' (SURVEY 8f next #4)" % local_photometric)
+        (p, pinv) = (eye_lin(), eye_lin())
+    elif local_photometric == 'uniform_random_gain':
+        assert blocksize is not None
+        assert beta is not None and beta > 0
+        (p, pinv) = kkeys.uniform_random_diagonal(blocknumel, beta, bias=1, withinverse=True)
+        (p, pinv) = (kkeys.block_diagonal(p, (N, N)), kkeys.block_diagonal(pinv, (N, N)))
+        (p, pinv) = (sparse_affine_to_linear(p), sparse_affine_to_linear(pinv))
+    elif local_photometric == 'uniform_random_bias':
+        assert blocksize is not None
+        assert gamma is not None and gamma > 0
+        bias = np.tile(gamma * np.random.rand(blocknumel), int(np.ceil(N / blocknumel)))[0:N].reshape(N, 1)
+        (p, pinv) = diagonal_affine_to_linear(sparse_identity_matrix(N), bias=bias, withinverse=True)
+    elif local_photometric == 'uniform_random_affine':
+        assert blocksize is not None
+        assert beta is not None and beta > 0 and gamma is not None and gamma > 0
+        pd = kkeys.uniform_random_diagonal(blocknumel, beta, bias=1)
+        bias = np.tile(gamma * np.random.rand(blocknumel), int(np.ceil(N / blocknumel)))[0:N].reshape(N, 1)
+        (p, pinv) = diagonal_affine_to_linear(kkeys.block_diagonal(pd, (N, N)), bias=bias, withinverse=True)
+    elif local_photometric == 'blockwise_constant_bias':
+        raise ValueError('blockwise_constant_bias supported for global_photometric testing only')
     else:
         raise ValueError("Invalid local photometric transform '%s'" % local_photometric)
 
@@ -432,6 +490,15 @@ def IdentityKeynet(inshape, net, backend='hip'):
 
 def PermutationKeynet(inshape, net, do_output_encryption=False):
     return Keynet(inshape, net, global_geometric='permutation', do_output_encryption=do_output_encryption)
+
+
+def TiledOrthogonalKeynet(inshape, net, tilesize, hierarchical_permute_at_level=(0, 1), direct=None, exact=None):
+    """Hierarchical block permutation + block-local Givens rotations + block-local affine photometric key, block memory
+    order (keynet/system.py:504-510): the float-key family (1e-5 contract)."""
+    return Keynet(inshape, net, tileshape=(tilesize, tilesize), global_geometric='hierarchical_permutation', hierarchical_blockshape=(2, 2),
+                  hierarchical_permute_at_level=hierarchical_permute_at_level, global_photometric='identity', local_geometric='givens_orthogonal',
+                  alpha=tilesize, blocksize=tilesize, local_photometric='uniform_random_affine', beta=0.1, gamma=100.0, memoryorder='block',
+                  direct=direct, exact=exact)
 
 
 def TiledIdentityKeynet(inshape, net, tilesize, direct=None, exact=None):

@@ -14,6 +14,7 @@ Fixtures:
   F3 mini_tiled_*.npz    MiniNet (2,16,16) Tiled{Identity,Permutation,Orthogonal}Keynet: blocks/tiles dumps, CSR, I/O
   F4 tiled_cases.npz     TiledMatrix / Conv2dTiledMatrix / DiagonalTiledMatrix cases mirroring test/test_sparse.py:122-199
   F5 allconv_tiny_perm.npz  reduced-channel AllConvNet-shaped PermutationKeynet (stride 2, 1x1 conv, dropout bypass)
+  F6 keygen_cases.npz    (A, Ainv) of keynet.system.keygen for every key family on small shapes (host-keying parity)
 """
 import os
 import sys
@@ -379,14 +380,39 @@ def f5():
     return save('allconv_tiny_perm.npz', out, manifest)
 
 
+from keygen_case_table import KEYGEN_CASES  # noqa: E402  (pure data: names, shapes, keyword arguments)
+
+
+def f6():
+    """(A, Ainv) pairs of the reference's keygen (keynet/system.py:317-469) for every key family, np.random.seed(7) each."""
+    import warnings
+    out = {}
+    manifest = {'layers': {}, 'cases': [c[0] for c in KEYGEN_CASES], 'recipe': 'np.random.seed(7); keynet.system.keygen(shape, **kwargs)'}
+    for (name, shape, kw) in KEYGEN_CASES:
+        np.random.seed(7)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (A, Ainv) = keynet.system.keygen(shape, **kw)
+        for (tag, M) in (('A', A), ('Ainv', Ainv)):
+            M = M.tocsr()
+            out['K.%s.%s.indptr' % (name, tag)] = np.asarray(M.indptr, dtype=np.int32)
+            out['K.%s.%s.indices' % (name, tag)] = np.asarray(M.indices, dtype=np.int32)
+            out['K.%s.%s.data' % (name, tag)] = np.asarray(M.data)
+            out['K.%s.%s.shape' % (name, tag)] = np.array(M.shape, dtype=np.int64)
+        err = np.abs((A.dot(Ainv) - scipy.sparse.eye(A.shape[0])).todense()).max()
+        print('keygen %-18s nnz(A)=%6d  |A.Ainv - I|=%.2e  dtype=%s' % (name, A.nnz, err, A.dtype))
+        manifest['layers'][name] = {'nnz': int(A.nnz), 'dtype': str(A.dtype)}
+    return save('keygen_cases.npz', out, manifest)
+
+
 if __name__ == '__main__':
     os.chdir('/tmp')
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6']
     mf = os.path.join(HERE, 'MANIFEST.json')
     manifest = json.load(open(mf)) if os.path.exists(mf) else {}
     manifest['_versions'] = {'numpy': np.__version__, 'scipy': scipy.__version__, 'torch': torch.__version__, 'python': sys.version.split()[0]}
     for w in which:
-        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5}[w]()
+        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5, 'f6': f6}[w]()
         manifest[w] = r
     with open(mf, 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
