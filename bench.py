@@ -85,6 +85,9 @@ def layer_table(knet, batch):
         if isinstance(c.W, ksp.Conv2dTiledMatrix):
             kind = 'convtaps'
             wbytes = 4 * c.W.nnz()            # taps + entries + last column actually read
+        elif not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
+            kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
+            wbytes = 4 * r * cdim
         else:
             kind = 'csr'
             wbytes = 8 * nnz_exp               # (col,val) per non-zero

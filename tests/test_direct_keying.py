@@ -46,3 +46,29 @@ def test_direct_refuses_global_permutation(golden):
     A = scipy.sparse.csr_matrix((z['sensor.enc.data'], z['sensor.enc.indices'], z['sensor.enc.indptr']), shape=shape)
     with pytest.raises((ValueError, AssertionError)):
         direct.spatial_key(scipy.sparse.block_diag((A[:-1, :-1], A[:-1, :-1].T, [[1]])).tocsr(), 2, 784)   # channel 1 keyed differently
+
+
+def test_direct_equals_reference_route_float_keys(golden):
+    """Orthogonal key family (Givens rotations + affine photometric key + block memory order): the factored operator
+    (coefficients K_t = a_out S_t a_in^-1, last column M_out(Wc gamma + b) + beta_out) equals the reference route's
+    A.W.Ainv up to f32 rounding of the SpGEMM sums (the reference accumulates the same products in another order)."""
+    import warnings
+    import scipy.sparse
+    z = golden('mini_tiled_orthogonal.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4, direct=True)
+    for (name, child) in knet._keynet.named_children():
+        if not isinstance(child, KeyedLayer):
+            continue
+        p = 'L.%s.' % name
+        kind = str(z[p + 'kind'])
+        if kind == 'conv2dtiled':
+            assert child.W._taps is not None and child.W._taps['ent_coef'] is not None     # float coefficients
+        c = child.W.tocsr() if isinstance(child.W, ksp.TiledMatrix) else child.W._matrix.tocsr()
+        ref = scipy.sparse.csr_matrix((z[p + 'data'], z[p + 'indices'], z[p + 'indptr']), shape=c.shape)
+        (D, R) = (np.asarray(c.todense(), dtype=np.float64), np.asarray(ref.todense(), dtype=np.float64))
+        scale = np.abs(R).max()
+        assert np.abs(D - R).max() <= 2e-6 * scale, (name, np.abs(D - R).max(), scale)

@@ -149,6 +149,25 @@ def test_full_stack_tiled_permutation(golden):
     assert np.allclose(y, z['logits_plain'], atol=1e-4)
 
 
+@pytest.mark.parametrize('direct', [False, True])
+def test_full_stack_tiled_orthogonal(golden, direct):
+    """Float-key family through the whole stack (factory under the seed -> encrypt -> forward on MFMA), both keying routes;
+    criterion = the reference's own (keyed logits vs plain net, test/test_keynet.py:196-219 use 1e-5 on LeNet; the gamma=100
+    bias key costs ~1e-5 of f32 cancellation already in the reference: tests/golden/make_golden.py prints 1.06e-5)."""
+    import warnings
+    z = golden('mini_tiled_orthogonal.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4, direct=direct)
+    xc = sensor.fromtensor(torch.as_tensor(z['x_plain']).to(dev())).encrypt().astensor()
+    assert close(xc.cpu().numpy(), z['x_cipher'], tol=1e-6)
+    y = knet.forward(xc).reshape(4, 10).cpu().numpy()
+    assert np.allclose(y, z['logits_keyed'], atol=1e-4)
+    assert np.allclose(y, z['logits_plain'], atol=1e-4)
+
+
 def test_challenge_known_answer(golden):
     """demo/challenge.ipynb cell 5 (float64 operators in the pickle -> f32 on the device): all 4 printed decimals."""
     z = golden('challenge_kat.npz')
