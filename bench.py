@@ -188,6 +188,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=3)
+    ap.add_argument('--graph', action='store_true', help='replay the forward from a captured HIP graph (launch-bound small nets)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -223,8 +224,10 @@ def main():
     torch.cuda.synchronize()
     log('[bench rank %d] operators resident + first forward in %.1f s; logits %s' % (rank, time.time() - t0, tuple(y.shape)))
 
+    replay = knet.capture(x_cipher) if args.graph else None
+
     def step():
-        yl = knet.forward_linear(x_cipher)[:, :-1]
+        yl = (replay(x_cipher) if replay is not None else knet.forward_linear(x_cipher))[:, :-1]
         if world == 1:
             return yl
         if share:   # gloo has no device all_gather_into_tensor: bounce through the host (test-only path)

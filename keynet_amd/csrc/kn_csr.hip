@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict
 
 // Grouped rows: work item w = RB member rows [r0, r0+RB) of group g; all share the column sequence grp_cols[colptr[g]..].
 // grp_vals layout per group: [j][Rpad] (Rpad = members rounded up to RB), so the RB values of column j are contiguous.
-template <int VEC>
+template <int VEC, int RBK>
 __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                         const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
                                                         const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
@@ -156,24 +156,28 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
     const int64_t rb = item - ct * n_rb;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // the stored work list is in bundles of RB rows; a wavefront takes RBK <= RB of them (more wavefronts for operators
+    // with few rows, e.g. a 121-row Linear: the serial walk over its columns cannot be split without changing rounding)
+    constexpr int SUB = RB / RBK;
     const int64_t w = rb * WAVES + wave;
-    if (w >= n_work) return;
-    const int g = work_grp[w];
-    const int r0 = work_r0[w];
+    if (w >= n_work * SUB) return;
+    const int g = work_grp[w / SUB];
+    const int r0 = work_r0[w / SUB] + (int)(w % SUB) * RBK;
     const int cbeg = grp_colptr[g];
     const int ncol = grp_colptr[g + 1] - cbeg;
     const int rbeg = grp_rowptr[g];
     const int nmem = grp_rowptr[g + 1] - rbeg;
     const int rpad = (nmem + RB - 1) / RB * RB;
+    if (r0 >= nmem) return;
     const float* vals = grp_vals + grp_valptr[g] + r0;
     const int32_t* cols = grp_cols + cbeg;
     const int64_t c = ct * (64 * VEC) + (int64_t)lane * VEC;
     const bool active = c < n_vecs;
     const float* xc = X + (active ? c : 0);
 
-    float acc[RB][VEC];
+    float acc[RBK][VEC];
 #pragma unroll
-    for (int r = 0; r < RB; r++)
+    for (int r = 0; r < RBK; r++)
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
 
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
         for (int u = 0; u < U; u++) {
             const float* a = vals + (int64_t)(j + u) * rpad;   // wave-uniform: scalar loads
 #pragma unroll
-            for (int r = 0; r < RB; r++) {
+            for (int r = 0; r < RBK; r++) {
                 const float ar = a[r];
 #pragma unroll
                 for (int v = 0; v < VEC; v++) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
         load_vec<VEC>(xv, xc + (int64_t)cols[j] * ldx);
         const float* a = vals + (int64_t)j * rpad;
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBK; r++) {
             const float ar = a[r];
 #pragma unroll
             for (int v = 0; v < VEC; v++) {
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
     }
     if (active) {
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
+        for (int r = 0; r < RBK; r++) {
             if (r0 + r < nmem) {
                 const int row = grp_rows[rbeg + r0 + r];
                 if (relu) {
@@ -329,14 +333,14 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     return KN_OK;
 }
 
-template <int VEC>
+template <int VEC, int RBK>
 static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
     if (A.n_work > 0) {
-        const int64_t n_rb = (A.n_work + WAVES - 1) / WAVES;
+        const int64_t n_rb = (A.n_work * (RB / RBK) + WAVES - 1) / WAVES;
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
-        hipLaunchKernelGGL(csr_group_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+        hipLaunchKernelGGL((csr_group_kernel<VEC, RBK>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
                            A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
     }
     if (A.n_loose > 0) {
@@ -355,15 +359,28 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     auto aligned = [&](int v) {
         return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0);
     };
-    // Widest per-lane vector that still gives the chip enough wavefronts (>= 4096: 4 per SIMD); a dense Linear at
-    // n_vecs = 256 is ONE pattern group of ~500 row bundles, so it must be split over batch columns instead.
-    const int64_t bundles = (A.n_work + WAVES - 1) / WAVES * WAVES + (A.n_loose + WAVES - 1) / WAVES * WAVES;
-    auto waves = [&](int v) { return bundles * ((n_vecs + 64 * v - 1) / (64 * v)); };
-    if (aligned(4) && waves(4) >= 4096) return launch_csr<4>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (aligned(2) && waves(2) >= 4096) return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (n_vecs <= 64 || !aligned(2)) return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    if (waves(1) >= 2 * waves(2)) return launch_csr<1>(A, x, ldx, n_vecs, y, ldy, relu, s);
-    return launch_csr<2>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    // (rows per wavefront, batch columns per lane): the most accumulators per lane that still gives the chip >= 2048
+    // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner
+    // bundles / narrower vectors -- the walk over a row's columns is serial by contract, so parallelism can only come
+    // from rows and batch columns.
+    const int64_t loose = (A.n_loose + WAVES - 1) / WAVES * WAVES;
+    auto waves = [&](int v, int rbk) { return (A.n_work * (RB / rbk) + loose) * ((n_vecs + 64 * v - 1) / (64 * v)); };
+    constexpr int64_t ENOUGH = 2048;
+#define KN_TRY(V, R) \
+    if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    KN_TRY(4, 8)
+    KN_TRY(2, 8)
+    KN_TRY(4, 2)
+    KN_TRY(1, 8)
+    KN_TRY(2, 2)
+    KN_TRY(1, 2)
+#undef KN_TRY
+    if (A.n_work == 0) {   // loose rows only: the bundle height is irrelevant, take the widest aligned vector
+        if (aligned(4) && n_vecs >= 256) return launch_csr<4, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
+        if (aligned(2) && n_vecs >= 128) return launch_csr<2, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
+        return launch_csr<1, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    }
+    return launch_csr<1, 1>(A, x, ldx, n_vecs, y, ldy, relu, s);
 }
 
 }  // namespace kn

@@ -328,3 +328,38 @@ def test_allconvnet_permutation_keynet_reduced_width():
     assert np.array_equal(knet.forward_linear(xc).cpu().numpy()[:4], ref)      # batch 512 vs batch 4: identical columns
     back = sensor.fromtensor(x[:2]).encrypt().decrypt().astensor()
     assert np.array_equal(back.numpy(), x[:2].numpy())
+
+
+def test_hip_graph_capture_replay(golden):
+    """The whole keyed forward captured in a HIP graph: replays are bit-identical to the eager forward, for new inputs too."""
+    z = golden('lenet_perm.npz')
+    knet = kio.keynet_from_arrays(z)
+    rng = np.random.RandomState(0)
+    X = np.concatenate([z['x_cipher']] * 16, axis=0)
+    X[:, :-1] += rng.randn(*X[:, :-1].shape).astype(np.float32) * 0.05
+    xd = torch.as_tensor(X).to(dev())
+    eager = knet.forward_linear(xd).cpu().numpy()
+    replay = knet.capture(xd)
+    assert np.array_equal(replay(xd).cpu().numpy(), eager)
+    X2 = X[::-1].copy()
+    out2 = replay(torch.as_tensor(X2).to(dev())).cpu().numpy()
+    assert np.array_equal(out2, knet.forward_linear(torch.as_tensor(X2).to(dev())).cpu().numpy())
+    assert np.array_equal(out2[::-1], eager)
+
+
+def test_output_encryption_roundtrip(golden):
+    """do_output_encryption=True (keynet/system.py:48-50,135-137; the reference's decrypt call is broken, the intent is one more
+    torchdot with the embedding key): logits come back decrypted and equal the plain net."""
+    z = golden('lenet_perm.npz')
+    net = load_weights(LeNet_AvgPool(), z)
+    np.random.seed(0)
+    (sensor, knet) = ksys.PermutationKeynet((1, 28, 28), net, do_output_encryption=True)
+    assert knet.embeddingkey() is not None
+    x = torch.as_tensor(z['x_plain'])
+    xc = sensor.fromtensor(x.to(dev())).encrypt().astensor()
+    y_cipher = knet.forward_linear(xc)
+    y = knet.forward(xc).reshape(8, 10).cpu().numpy()
+    assert np.allclose(y, z['logits_plain'], atol=1e-5)
+    assert not np.allclose(y_cipher[:, :-1].cpu().numpy(), z['logits_plain'], atol=1e-3)    # still encrypted before the key
+    pub = knet.public()
+    assert pub.embeddingkey() is None and pub.imagekey() is None
