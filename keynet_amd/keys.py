@@ -11,7 +11,7 @@ import scipy.sparse
 from sklearn.preprocessing import normalize
 
 from .util import blockview, find_closest_positive_divisor
-from .sparse import sparse_permutation_matrix
+from .sparse import sparse_permutation_matrix, sparse_identity_matrix, sparse_affine_to_linear, DiagonalTiledMatrix, is_scipy_sparse
 
 
 def channelorder_to_pixelorder_matrix(shape, withinverse=False):
@@ -145,3 +145,215 @@ def hierarchical_block_permutation_matrix(imgshape, blockshape, permute_at_level
     cols = hierarchical_block_permute(np.arange(n).reshape(imgshape), blockshape, permute_at_level, min_blocksize, twist=twist, strict=strict).flatten()
     P = scipy.sparse.coo_matrix((np.ones(n, dtype=np.int64), (np.arange(n), cols)), shape=(n, n), dtype=np.float32)
     return P if not withinverse else (P, P.transpose())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# keygen: one layer's key pair, composed from five stages
+def diagonal_affine_to_linear(A, bias=None, withinverse=False, dtype=np.float32):
+    """[[A, b], [0, 1]] for a diagonal A; the inverse comes from the rank-one (Woodbury) update of the diagonal part
+    (keynet/sparse.py:99-119).  Arithmetic in float64, cast at the end, as the reference does."""
+    assert is_scipy_sparse(A) and A.shape[0] == A.shape[1]
+    n = A.shape[0] + 1
+    L = sparse_affine_to_linear(A, bias=bias, dtype=np.float64)
+    if not withinverse:
+        return L.astype(dtype)
+    if bias is None:
+        return (L.astype(dtype), scipy.sparse.spdiags(1.0 / L.diagonal(), 0, n, n).tocoo().astype(dtype))
+    d = L.diagonal()
+    d[-1] = 0.5
+    Dinv = scipy.sparse.spdiags(1.0 / d, 0, n, n)
+    u = scipy.sparse.csr_matrix(np.vstack((bias, np.array([0.5]))))
+    v = scipy.sparse.csr_matrix(np.hstack((np.zeros_like(bias).flatten(), np.array([1.0]))))
+    Linv = Dinv - ((Dinv.dot(u).dot(v.dot(Dinv))) / float(1 + (v.dot(Dinv).dot(u).todense())))
+    return (L.astype(dtype), Linv.astype(dtype))
+
+
+class _Ctx(object):
+    """What the stages of one keygen call share: the layer shape and the (possibly snapped) block geometry."""
+    def __init__(self, shape, blocksize, tileshape, strict, alpha, beta, gamma, memoryorder, seed):
+        (self.channels, self.height, self.width) = shape
+        self.shape = shape
+        self.N = int(np.prod(shape))
+        (self.alpha, self.beta, self.gamma, self.tileshape, self.memoryorder, self.seed) = (alpha, beta, gamma, tileshape, memoryorder, seed)
+        (self.blocksize, self.plane, self.blocknumel) = (blocksize, None, None)
+        if blocksize is not None:
+            if tileshape is not None:
+                assert blocksize == tileshape[0] == tileshape[1], 'blocksize and tileshape disagree'
+            if self.height == 1 and self.width == 1:                      # a vector (fc output): one global block
+                (self.blocksize, self.plane, self.blocknumel) = (self.N, self.N, self.N)
+            else:
+                if not strict and (self.height % blocksize or self.width % blocksize):
+                    assert self.height == self.width, 'ragged blocksize needs a square image'
+                    self.blocksize = find_closest_positive_divisor(self.height, blocksize)
+                (self.plane, self.blocknumel) = (self.height * self.width, self.blocksize * self.blocksize)
+
+    def eye(self):
+        return sparse_identity_matrix(self.N)
+
+    def need(self, **named):
+        for (k, v) in named.items():
+            assert v is not None, 'option "%s" is required for this key family' % k
+
+    def not_tiled(self, what):
+        assert self.tileshape is None, '%s is not tile compressible' % what
+
+    def spread(self, block):
+        """block [blocknumel^2] -> repeated over the plane, then over the channels (COO)."""
+        return DiagonalTiledMatrix(DiagonalTiledMatrix(block, shape=(self.plane, self.plane)).tocoo(), shape=(self.N, self.N)).tocoo()
+
+    def tiled_bias(self):
+        return np.tile(self.gamma * np.random.rand(self.blocknumel), int(np.ceil(self.N / self.blocknumel)))[0:self.N].reshape(self.N, 1)
+
+
+def _stage_memoryorder(c):
+    if c.memoryorder == 'channel':
+        return (c.eye(), c.eye())
+    if c.memoryorder == 'block':
+        c.need(blocksize=c.blocksize)
+        return channelorder_to_blockorder_matrix(c.shape, c.blocksize, withinverse=True)
+    raise ValueError("unknown memoryorder '%s' (channel | block)" % c.memoryorder)
+
+
+def _gg_permutation(c, order):
+    c.not_tiled('a global permutation')
+    return sparse_permutation_matrix(c.N, withinverse=True)
+
+
+def _gg_hierarchical(twist):
+    def build(c, order):
+        c.need(hierarchical_blockshape=c.hblockshape, hierarchical_permute_at_level=c.hlevels)
+        levels = list(c.hlevels) if isinstance(c.hlevels, (list, tuple)) else [c.hlevels]
+        if max(c.height, c.width) / np.power(2, max(levels)) < 8 or (c.height == 1 and c.width == 1):
+            levels = []
+        (to_px, from_px) = channelorder_to_pixelorder_matrix((c.channels, c.height, c.width), withinverse=True)
+        (Q, Qinv) = hierarchical_block_permutation_matrix((c.height, c.width, c.channels), c.hblockshape, levels, min_blocksize=8, seed=c.seed,
+                                                          twist=twist, withinverse=True, strict=False)
+        (Q, Qinv) = (from_px.dot(Q).dot(to_px), from_px.dot(Qinv).dot(to_px))
+        if c.memoryorder != 'channel':
+            (o, oinv) = order
+            (Q, Qinv) = (o.dot(Q).dot(oinv), o.dot(Qinv).dot(oinv))
+        return (Q, Qinv)
+    return build
+
+
+def _gg_givens(c, order):
+    c.need(alpha=c.alpha)
+    c.not_tiled('a global Givens rotation')
+    return givens_orthogonal(c.N, int(c.alpha), withinverse=True)
+
+
+def _lg_permutation(c):
+    assert c.blocksize is not None and c.height == c.width, 'local permutation needs a blocksize and a square image'
+    fwd = c.spread(sparse_permutation_matrix(c.blocknumel)).astype(np.float32)
+    return (fwd, fwd.transpose())
+
+
+def _lg_doubly_stochastic(c):
+    assert c.blocksize is not None and c.alpha is not None and c.height == c.width
+    assert c.blocksize < 8192, 'doubly_stochastic inverts a dense blocksize^2 matrix: blocksize %d is too large' % c.blocksize
+    (m, minv) = diagonally_dominant_doubly_stochastic(c.blocknumel, int(c.alpha), withinverse=True)
+    return (c.spread(m), c.spread(minv))
+
+
+def _lg_givens(c):
+    assert c.alpha is not None and c.blocksize is not None and c.height == c.width
+    (rot, rotinv) = givens_orthogonal(c.blocknumel, int(c.alpha), withinverse=True)
+    (shuf, shufinv) = sparse_permutation_matrix(c.blocknumel, withinverse=True)
+    return (c.spread(shuf.dot(rot)).astype(np.float32), c.spread(rotinv.dot(shufinv)).astype(np.float32))
+
+
+def _lin(pair):
+    return (sparse_affine_to_linear(pair[0]), sparse_affine_to_linear(pair[1]))
+
+
+def _gp_gain(c):
+    c.not_tiled('a global gain')
+    assert c.beta is not None and c.beta > 0
+    return _lin(uniform_random_diagonal(c.N, c.beta, bias=1, withinverse=True))
+
+
+def _gp_bias(c):
+    assert c.gamma is not None and c.gamma > 0
+    return diagonal_affine_to_linear(c.eye(), c.gamma * np.random.rand(c.N, 1), withinverse=True)
+
+
+def _gp_linear_bias(c):
+    assert c.gamma is not None and c.gamma > 0
+    return diagonal_affine_to_linear(c.eye(), (c.gamma / float(c.N)) * np.array(range(0, c.N)).reshape(c.N, 1), withinverse=True)
+
+
+def _gp_affine(c):
+    c.not_tiled('a global affine photometric key')
+    assert c.beta is not None and c.beta > 0 and c.gamma is not None and c.gamma > 0
+    gain = uniform_random_diagonal(c.N, c.beta, bias=1)
+    return diagonal_affine_to_linear(gain, c.gamma * np.random.rand(c.N, 1), withinverse=True)
+
+
+def _gp_blockwise_bias(c):
+    assert c.gamma is not None and c.gamma > 0 and c.blocksize is not None
+    b = c.gamma * np.random.rand(int(np.ceil(c.N // c.blocksize)), 1).dot(np.ones((1, c.blocknumel))).flatten()[0:c.N].reshape(c.N, 1)
+    return diagonal_affine_to_linear(c.eye(), b, withinverse=True)
+
+
+def _lp_gain(c):
+    assert c.blocksize is not None and c.beta is not None and c.beta > 0
+    (d, dinv) = uniform_random_diagonal(c.blocknumel, c.beta, bias=1, withinverse=True)
+    return _lin((block_diagonal(d, (c.N, c.N)), block_diagonal(dinv, (c.N, c.N))))
+
+
+def _lp_bias(c):
+    assert c.blocksize is not None and c.gamma is not None and c.gamma > 0
+    return diagonal_affine_to_linear(c.eye(), bias=c.tiled_bias(), withinverse=True)
+
+
+def _lp_affine(c):
+    assert c.blocksize is not None and c.beta is not None and c.beta > 0 and c.gamma is not None and c.gamma > 0
+    d = uniform_random_diagonal(c.blocknumel, c.beta, bias=1)
+    return diagonal_affine_to_linear(block_diagonal(d, (c.N, c.N)), bias=c.tiled_bias(), withinverse=True)
+
+
+_GLOBAL_GEOMETRIC = {'permutation': _gg_permutation, 'hierarchical_permutation': _gg_hierarchical(False), 'hierarchical_rotation': _gg_hierarchical(True),
+                     'givens_orthogonal': _gg_givens}
+_LOCAL_GEOMETRIC = {'permutation': _lg_permutation, 'doubly_stochastic': _lg_doubly_stochastic, 'givens_orthogonal': _lg_givens}
+_GLOBAL_PHOTOMETRIC = {'uniform_random_gain': _gp_gain, 'uniform_random_bias': _gp_bias, 'linear_bias': _gp_linear_bias, 'uniform_random_affine': _gp_affine,
+                       'blockwise_constant_bias': _gp_blockwise_bias}
+_LOCAL_PHOTOMETRIC = {'uniform_random_gain': _lp_gain, 'uniform_random_bias': _lp_bias, 'uniform_random_affine': _lp_affine}
+
+
+def keygen(shape, global_geometric, local_geometric, global_photometric, local_photometric, memoryorder='channel', alpha=None, beta=None,
+           gamma=None, seed=None, hierarchical_blockshape=None, hierarchical_permute_at_level=None, blocksize=None, tileshape=None, strict=False):
+    """Key pair (A, Ainv) of one layer output of `shape` = (C,H,W):   A = O^-1 . lp . lg . gp . gg . O
+
+        O   memory-order change ('channel' | 'block')            gg  global geometric key      gp  global photometric key
+        lg  local (block-repeated, channel-replicated) geometric key                              lp  local photometric key
+
+    Same option names and accepted values as the reference's keygen (keynet/system.py:317-469); the stages draw from
+    numpy's global RNG in the reference's order (gg, lg, gp, lp) and hand scipy the same formats, so a seeded call
+    returns the reference's matrices bit for bit (tests/test_keygen_families.py, 20 cases).  Unknown values raise
+    ValueError; a tile-incompatible choice with `tileshape` set raises AssertionError, as there."""
+    if seed is not None:
+        np.random.seed(seed)
+    c = _Ctx(tuple(shape), blocksize, tileshape, strict, alpha, beta, gamma, memoryorder, seed)
+    (c.hblockshape, c.hlevels) = (hierarchical_blockshape, hierarchical_permute_at_level)
+
+    order = _stage_memoryorder(c)
+    (O, Oinv) = _lin(order)
+
+    def stage(kind, name, table, linearise, *extra):
+        if name == 'identity':
+            return _lin((c.eye(), c.eye()))
+        if name not in table:
+            raise ValueError("unknown %s key '%s' (identity | %s)" % (kind, name, ' | '.join(sorted(table))))
+        pair = table[name](c, *extra)
+        return _lin(pair) if linearise else pair
+
+    (GG, GGinv) = stage('global geometric', global_geometric, _GLOBAL_GEOMETRIC, True, order)
+    (LG, LGinv) = stage('local geometric', local_geometric, _LOCAL_GEOMETRIC, True)
+    (GP, GPinv) = stage('global photometric', global_photometric, _GLOBAL_PHOTOMETRIC, False)
+    if local_photometric == 'blockwise_constant_bias':
+        raise ValueError("'blockwise_constant_bias' exists as a global photometric key only")
+    (LP, LPinv) = stage('local photometric', local_photometric, _LOCAL_PHOTOMETRIC, False)
+
+    A = Oinv.dot(LP.dot(LG.dot(GP.dot(GG.dot(O)))))
+    Ainv = Oinv.dot(GGinv.dot(GPinv.dot(LGinv.dot(LPinv.dot(O)))))
+    return (A, Ainv)

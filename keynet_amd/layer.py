@@ -16,77 +16,93 @@ from .sparse import SparseMatrix, sparse_toeplitz_conv2d, sparse_toeplitz_avgpoo
 from .torch import affine_to_linear_matrix
 
 
+def _square(v, what):
+    """kernel_size / stride given as int or (a, a) -> a."""
+    if isinstance(v, int):
+        return v
+    assert len(v) in (1, 2) and v[0] == v[-1], '%s must be square / isotropic, got %s' % (what, str(v))
+    return v[0]
+
+
+def _sandwich(A, W, Ainv):
+    """A . W . Ainv with the reference's association ((A.W).Ainv, keynet/layer.py:35): scipy's SpGEMM leaves each row in
+    an order that depends on it, and that stored order is part of the bit-exact contract.  A is None for the last
+    layer of a key-net without output encryption."""
+    return W.dot(Ainv) if A is None else A.dot(W).dot(Ainv)
+
+
+def _conv_operator(m, inshape, outshape, A, Ainv, tileshape, direct):
+    k = _square(m.kernel_size, 'kernel')
+    stride = _square(m.stride, 'stride')
+    assert len(inshape) == 3, 'inshape is the (C,H,W) of the tensor entering this layer'
+    assert m.padding[0] == k // 2 and m.padding[-1] == k // 2, "only 'same' padding ((k-1)/2) is keyable"
+    (w, b) = (m.weight.detach().numpy(), m.bias.detach().numpy())
+    if direct is None:
+        direct = tileshape is not None and kdirect.toeplitz_entries('conv', inshape, outshape, k) > KeyedLayer.DIRECT_THRESHOLD
+    if direct:
+        return ksp.Conv2dTiledMatrix.fromtaps(tileshape=tileshape, **kdirect.keyed_conv_taps(w, b, inshape, outshape, stride, A, Ainv))
+    W = _sandwich(A, sparse_toeplitz_conv2d(inshape, w, bias=b, stride=stride), Ainv)
+    if tileshape is None:
+        return W
+    return ksp.Conv2dTiledMatrix(W, inshape, outshape, tileshape, bias=True, sanitycheck=False)
+
+
+def _pool_operator(m, inshape, outshape, A, Ainv, tileshape, direct):
+    k = _square(m.kernel_size, 'kernel')
+    stride = _square(m.stride, 'stride')
+    assert len(inshape) == 3, 'inshape is the (C,H,W) of the tensor entering this layer'
+    C = inshape[0]
+    if direct is None:
+        direct = tileshape is not None and kdirect.toeplitz_entries('pool', inshape, (C,) + tuple(outshape[1:]), k) > KeyedLayer.DIRECT_THRESHOLD
+    if direct:
+        W = kdirect.keyed_avgpool_csr(C, (inshape[1], inshape[2]), k, stride, A, Ainv)
+    else:
+        W = _sandwich(A, sparse_toeplitz_avgpool2d(inshape, (C, C, k, k), stride), Ainv)
+    return W if tileshape is None else ksp.TiledMatrix(W, tileshape)
+
+
+def _linear_operator(m, A, Ainv):
+    dense = affine_to_linear_matrix(m.weight, m.bias).detach().numpy()      # (in+1, out+1), left-multiplying
+    return _sandwich(A, scipy.sparse.coo_matrix(dense).transpose(), Ainv)
+
+
 class KeyedLayer(nn.Module):
+    """One keyed layer of a key-net: holds W_hat = A . W . A_prev^-1 as an HBM-resident operator and applies it."""
+
     DIRECT_THRESHOLD = 20000000   # Toeplitz entries above which tiled conv/pool layers are keyed in factored form
 
     def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None, direct=None, exact=None):
-        """`direct`: None = automatic (factored, Toeplitz-free keying for tiled conv/avgpool layers whose Toeplitz matrix
+        """module: the source nn.Conv2d / nn.AvgPool2d / nn.Linear / nn.ReLU; A: this layer's output key (None = leave the
+        output unkeyed); Ainv: inverse of the key on its input; tileshape: store conv/pool operators tiled.
+        `direct`: None = automatic (factored, Toeplitz-free keying for tiled conv/avgpool layers whose Toeplitz matrix
         would exceed DIRECT_THRESHOLD entries -- the reference route cannot build those at all); True / False force it.
         `exact`: True = every product in the reference's accumulation order and rounding (bit-exact with scipy);
         False = float-key tolerance (1e-5): conv-taps and large dense operators run on the matrix cores.  None = exact
-        for untiled layers (the permutation key-nets), tolerance for tiled ones (BASELINE north_star)."""
+        for untiled layers (the permutation key-nets), tolerance for tiled ones (BASELINE north_star).
+        Raises ValueError for layer types that cannot be keyed (the reference's behaviour, keynet/layer.py:72-79)."""
         super(KeyedLayer, self).__init__()
-        self._exact = (tileshape is None) if exact is None else bool(exact)
         self._layertype = str(type(module))
-        self._tileshape = tileshape
-        self._inshape = inshape
-        self._outshape = outshape
-
+        (self._inshape, self._outshape, self._tileshape) = (inshape, outshape, tileshape)
+        self._exact = (tileshape is None) if exact is None else bool(exact)
         if isinstance(module, nn.Conv2d):
-            assert len(module.kernel_size) == 1 or (len(module.kernel_size) == 2 and module.kernel_size[0] == module.kernel_size[1]), 'Kernel must be square'
-            assert len(module.stride) == 1 or (len(module.stride) == 2 and module.stride[0] == module.stride[1]), 'Strides must be isotropic'
-            assert len(inshape) == 3, 'Inshape must be (C,H,W) for the shape of the tensor at the input to this layer'
-            assert module.padding[0] == module.kernel_size[0] // 2 and module.padding[1] == module.kernel_size[1] // 2, 'Padding is assumed to be equal to (kernelsize-1)/2'
-            stride = module.stride[0]
-            self._repr = 'Conv2d: in_channels=%d, out_channels=%d, kernel_size=%s, stride=%s' % (module.in_channels, module.out_channels, str(module.kernel_size), str(stride))
-            if direct is None:
-                direct = tileshape is not None and kdirect.toeplitz_entries('conv', inshape, outshape, module.kernel_size[0]) > self.DIRECT_THRESHOLD
-            if direct:
-                kw = kdirect.keyed_conv_taps(module.weight.detach().numpy(), module.bias.detach().numpy(), inshape, outshape, stride, A, Ainv)
-                W = ksp.Conv2dTiledMatrix.fromtaps(tileshape=tileshape, **kw)
-            else:
-                W = sparse_toeplitz_conv2d(inshape, module.weight.detach().numpy(), bias=module.bias.detach().numpy(), stride=stride)
-                W = A.dot(W).dot(Ainv)    # the key: same association as the reference so the stored order matches (keynet/layer.py:35)
-                if tileshape is not None:
-                    W = ksp.Conv2dTiledMatrix(W, self._inshape, self._outshape, self._tileshape, bias=True, sanitycheck=False)
-            self.W = W
-
-        elif isinstance(module, nn.ReLU):
-            self._repr = 'ReLU'
-            self.W = A.dot(Ainv)
-
+            self._repr = 'Conv2d %d->%d, k=%s, s=%s' % (module.in_channels, module.out_channels, str(module.kernel_size), str(module.stride))
+            W = _conv_operator(module, inshape, outshape, A, Ainv, tileshape, direct)
         elif isinstance(module, nn.AvgPool2d):
-            assert isinstance(module.kernel_size, int) or (len(module.kernel_size) == 2 and module.kernel_size[0] == module.kernel_size[1]), 'Kernel must be square'
-            assert isinstance(module.stride, int) or (len(module.stride) == 2 and module.stride[0] == module.stride[1]), 'Strides must be isotropic'
-            assert len(inshape) == 3, 'Inshape must be (C,H,W) for the shape of the tensor at the input to this layer'
-            stride = module.stride if isinstance(module.stride, int) else module.stride[0]
-            kernel_size = module.kernel_size if isinstance(module.kernel_size, int) else module.kernel_size[0]
-            self._repr = 'AvgPool2d: kernel_size=%s, stride=%s' % (str(kernel_size), str(stride))
-            if direct is None:
-                direct = tileshape is not None and kdirect.toeplitz_entries('pool', inshape, (inshape[0],) + tuple(outshape[1:]), kernel_size) > self.DIRECT_THRESHOLD
-            if direct:
-                W = kdirect.keyed_avgpool_csr(inshape[0], (inshape[1], inshape[2]), kernel_size, stride, A, Ainv)
-            else:
-                W = sparse_toeplitz_avgpool2d(inshape, (inshape[0], inshape[0], kernel_size, kernel_size), stride)
-                W = A.dot(W).dot(Ainv) if A is not None else W.dot(Ainv)
-            if tileshape is not None:
-                W = ksp.TiledMatrix(W, self._tileshape)
-            self.W = W
-
+            self._repr = 'AvgPool2d k=%s, s=%s' % (str(module.kernel_size), str(module.stride))
+            W = _pool_operator(module, inshape, outshape, A, Ainv, tileshape, direct)
         elif isinstance(module, nn.Linear):
-            self._repr = 'Linear: in_features=%d, out_features=%d' % (module.in_features, module.out_features)
-            W = scipy.sparse.coo_matrix(affine_to_linear_matrix(module.weight, module.bias).detach().numpy()).transpose()
-            self.W = W.dot(Ainv) if A is None else A.dot(W).dot(Ainv)
-
+            self._repr = 'Linear %d->%d' % (module.in_features, module.out_features)
+            W = _linear_operator(module, A, Ainv)
+        elif isinstance(module, nn.ReLU):
+            self._repr = 'ReLU'                       # a keyed ReLU: the key change alone, ReLU applied in forward
+            W = A.dot(Ainv)
         elif isinstance(module, nn.BatchNorm2d):
-            raise ValueError('batchnorm layer should be named "mylayer_bn" for batchnorm of "mylayer" and should come right before "mylayer" to merge keyed layers')
+            raise ValueError('a BatchNorm2d is folded into the layer before it: name it "<layer>_bn" and place it right after "<layer>"')
         elif isinstance(module, nn.Dropout):
-            raise ValueError('dropout layer should be skipped during keying and removed from final network')
+            raise ValueError('Dropout is the identity at inference: it is skipped during keying, never keyed')
         else:
             raise ValueError('unsupported layer type "%s"' % str(type(module)))
-
-        if not isinstance(self.W, SparseMatrix):
-            self.W = SparseMatrix(self.W)
+        self.W = W if isinstance(W, SparseMatrix) else SparseMatrix(W)
 
     @classmethod
     def fromoperator(cls, W, layertype, inshape=None, outshape=None, repr_=None, exact=None):
