@@ -85,7 +85,7 @@ def layer_table(knet, batch):
         if isinstance(c.W, ksp.Conv2dTiledMatrix):
             kind = 'convtaps'
             wbytes = 4 * c.W.nnz()            # taps + entries + last column actually read
-        elif not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
+        elif type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
             kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
             wbytes = 4 * r * cdim
         else:
@@ -98,20 +98,28 @@ def layer_table(knet, batch):
 
 
 def time_layers(knet, x_cipher, table, iters):
-    """Per-layer kernel time with events on the launch stream (torch's current stream is the one kn_spmm launches on)."""
+    """Per-layer kernel time with HIP events on the launch stream (torch's current stream is the one kn_spmm launches on).
+    Every iteration is timed on its own and the MEDIAN is kept: a multi-GB output allocation can occasionally fall out of
+    the caching allocator and cost tens of ms, which must not leak into a kernel's average."""
     y = x_cipher
     for row in table:
         c = row['layer']
         xin = y
-        y = c.forward(xin, fuse_relu=row['fuse'])       # warm
+        y = None
+        out = c.forward(xin, fuse_relu=row['fuse'])       # warm
         torch.cuda.synchronize()
-        (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        e0.record()
-        for _ in range(iters):
-            y = c.forward(xin, fuse_relu=row['fuse'])
-        e1.record()
-        torch.cuda.synchronize()
-        row['ms'] = e0.elapsed_time(e1) / iters
+        times = []
+        for _ in range(max(iters, 1)):
+            del out
+            (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            e0.record()
+            out = c.forward(xin, fuse_relu=row['fuse'])
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        row['ms'] = float(np.median(times))
+        row['ms_min'] = float(np.min(times))
+        y = out
     return table
 
 
@@ -127,10 +135,11 @@ def committed_traffic(workload):
     return (t.get('convtaps_hbm_bytes_per_forward'), os.path.relpath(files[-1], ROOT))
 
 
-def cpu_baseline(knet, batch_total_nnz, budget_cols=64):
+def cpu_baseline(knet, batch_total_nnz, budget_cols=256, conv_pixels=1024):
     """CPU oracle (oracle/kn_oracle.c: scipy csr_matvecs restated, 1 thread) on a bounded sample of the workload:
-    256 output pixels x all output channels of the largest conv layer (realistic gather pattern), the first pooling
-    layer and the last two FC layers, `budget_cols` images; extrapolated to the whole net by non-zeros."""
+    `conv_pixels` output pixels x all output channels of the largest conv layer (realistic gather pattern), the first
+    pooling layer and the last two FC layers, `budget_cols` images (about 10-20 s of single-thread CPU work on the VGG-16
+    workload); extrapolated to the whole net by non-zeros."""
     import oracle
     import scipy.sparse
     sample = []
@@ -141,7 +150,7 @@ def cpu_baseline(knet, batch_total_nnz, budget_cols=64):
         t = c.W._taps
         (Cout, Hout, Wout) = c.W._outshape
         (Cin, Hin, Win) = c.W._inshape
-        pix = np.sort(rng.choice(Hout * Wout, size=min(256, Hout * Wout), replace=False))
+        pix = np.sort(rng.choice(Hout * Wout, size=min(conv_pixels, Hout * Wout), replace=False))
         sel = np.isin(t['ent_out'], pix)
         remap = -np.ones(Hout * Wout, dtype=np.int64)
         remap[pix] = np.arange(len(pix))
@@ -150,7 +159,7 @@ def cpu_baseline(knet, batch_total_nnz, budget_cols=64):
         cols = (t['ent_in'][sel].astype(np.int64)[:, None, None] + (jc * Hin * Win)[None]).ravel()
         vals = t['taps'][t['ent_tap'][sel]].ravel()
         M = scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(Cout * len(pix), c.W.shape[1]))
-        sample.append((name + '[256 px]', M))
+        sample.append((name + '[%d px]' % len(pix), M))
     others = [(n, c) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer) and not isinstance(c.W, ksp.Conv2dTiledMatrix)]
     pools = [(n, c) for (n, c) in others if isinstance(c.W, ksp.TiledMatrix)]
     fcs = [(n, c) for (n, c) in others if not isinstance(c.W, ksp.TiledMatrix)]
@@ -187,7 +196,7 @@ def main():
     ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--layer-iters', type=int, default=3)
+    ap.add_argument('--layer-iters', type=int, default=5)
     ap.add_argument('--graph', action='store_true', help='replay the forward from a captured HIP graph (launch-bound small nets)')
     args = ap.parse_args()
 

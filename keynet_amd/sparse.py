@@ -108,6 +108,8 @@ class SparseMatrix(object):
 
     def _dense_device_op(self):
         """kn_dense_create handle for a (nearly) dense operator such as a keyed nn.Linear, or None when not eligible."""
+        if getattr(self, '_matrix', None) is None:
+            return None          # tiled containers have no single host matrix: never dense-eligible
         if getattr(self, '_op_dense', None) is None:
             M = self._matrix
             (r, c) = self.shape
