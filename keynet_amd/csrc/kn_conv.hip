@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < BL; i++) {
         const int f = tid + i * 256;
-        b_off[i] = (uint32_t)((int64_t)(f / (NB / 4)) * p.HiWi * p.ldx + (f % (NB / 4)) * 4);
+        // rows ci >= Cin exist only when Cin < KC (one zero-padded chunk per slot): their taps are zero, so they may read
+        // any valid activation row (row 0 of the slot) -- finite activations assumed, as for every padded GEMM
+        const int r = f / (NB / 4);
+        b_off[i] = (uint32_t)((int64_t)(r < p.Cin ? r : 0) * p.HiWi * p.ldx + (f % (NB / 4)) * 4);
     }
     // K order: input-channel chunk OUTER, slot INNER.  Workgroups of neighbouring output pixels (which share most of
     // their input pixels, at different slot positions) then touch the same activation tile within a few chunk-times,
@@ -305,7 +308,7 @@ template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(const ConvArgs& a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t grid = ((items + 7) / 8) * 8;
-    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
+    const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, a);

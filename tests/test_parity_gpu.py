@@ -363,3 +363,52 @@ def test_output_encryption_roundtrip(golden):
     assert not np.allclose(y_cipher[:, :-1].cpu().numpy(), z['logits_plain'], atol=1e-3)    # still encrypted before the key
     pub = knet.public()
     assert pub.embeddingkey() is None and pub.imagekey() is None
+
+
+@pytest.mark.parametrize('case', range(10))
+def test_convtaps_random_shapes(case):
+    """Randomised conv-taps operators (odd channel counts, stride 2, 1x1 / 3x3 / 5x5 windows, several float-coefficient
+    entries per (pixel, tap), missing bias column, ragged batches that exercise the generic loader):
+    MFMA path vs the order-preserving path (bit-exact vs the oracle) within the conditioned 1e-5 bound."""
+    from keynet_amd import direct as kdirect
+    rng = np.random.RandomState(100 + case)
+    Cin = int(rng.choice([1, 2, 3, 5, 16, 17, 32, 40]))
+    Cout = int(rng.choice([1, 3, 8, 33, 64, 65, 130]))
+    H = int(rng.choice([4, 6, 8]))
+    k = int(rng.choice([1, 3, 5]))
+    stride = int(rng.choice([1, 2]))
+    n_vecs = int(rng.choice([1, 3, 4, 64, 100, 128, 256, 260]))
+    unit = bool(rng.rand() < 0.5)
+    has_last = bool(rng.rand() < 0.7)
+    (Ho, HW, HoWo) = (H // stride, H * H, (H // stride) ** 2)
+    w = (rng.randn(Cout, Cin, k, k) / np.sqrt(k * k * Cin)).astype(np.float32)
+    (pi, po) = (rng.permutation(HW), rng.permutation(HoWo))
+    (eo, ei, et, ec) = ([], [], [], [])
+    for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((H, H), k, stride)):
+        S = S.tocoo()
+        eo.append(po[S.row]); ei.append(pi[S.col]); et.append(np.full(S.nnz, t)); ec.append(np.ones(S.nnz, np.float32))
+        if not unit:                                         # a second, weighted entry for some (pixel, tap) pairs
+            sel = rng.rand(S.nnz) < 0.5
+            eo.append(po[S.row][sel]); ei.append(pi[(S.col[sel] + 1) % HW]); et.append(np.full(int(sel.sum()), t))
+            ec.append(rng.randn(int(sel.sum())).astype(np.float32))
+    (eo, ei, et, ec) = (np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec))
+    if not unit:                                             # merge duplicate (out, in, tap) triples: the operator forbids them
+        key = (eo.astype(np.int64) * HW + ei) * (k * k) + et
+        (_, first) = np.unique(key, return_index=True)
+        (eo, ei, et, ec) = (eo[first], ei[first], et[first], ec[first])
+    taps = np.stack([w[:, :, i, j] for i in range(k) for j in range(k)])
+    lastcol = np.concatenate((rng.randn(Cout * HoWo), [1.0])).astype(np.float32) if has_last else None
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, Ho, Ho), taps, eo, ei, et, None if unit else ec, lastcol)
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    if has_last:
+        X[-1] = 1.0
+    xd = torch.as_tensor(X).to(dev())
+    M = W.tosparse('csr')
+    M.sort_indices()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    ye = W.torchdot(xd, exact=True).cpu().numpy()
+    assert np.array_equal(ye, ref), 'order-preserving path differs from the oracle'
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu).cpu().numpy()
+        r = np.maximum(ref, 0) if relu else ref
+        assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (case, Cin, Cout, H, k, stride, n_vecs, unit, np.abs(y - r).max())
