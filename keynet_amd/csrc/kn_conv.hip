@@ -250,10 +250,12 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; j++) bf[cur ^ 1][j] = b[(kk + 2 + arow) * NB + bcol + j * 32];
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
+            __builtin_amdgcn_s_setprio(1);       // matrix burst wins arbitration over the co-resident waves' VALU/LDS issue (+1 %, A-B-A-B)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
