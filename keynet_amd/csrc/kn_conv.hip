@@ -36,7 +36,7 @@ struct ConvArgs {
     int64_t ldx, ldy;
     int32_t cin_pad, cout_pad, Cin, Cout, HiWi, HoWo;
     int32_t n_vecs, relu, unit_coef, vec_ok;
-    int32_t n_mt, n_bt, n_pix, max_slots, ntaps;
+    int32_t n_mt, n_bt, n_pix, max_slots, ntaps, wide_store;
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
 };
 
@@ -263,6 +263,54 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
 
     // ---- epilogue: bias column (x homogeneous coordinate), ReLU, store --------------------------------------
     const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx) : nullptr;
+    if (p.wide_store && b0 + NB <= p.n_vecs) {
+        // Wide path: an accumulator register holds one output row per 32-lane half (4 bytes per lane), so storing it
+        // directly costs 64 scalar stores per lane.  Instead each wavefront transposes 8 rows x (TN*32) columns at a time
+        // through its own 2 KiB slice of the now idle tile buffers and writes 16 bytes per lane: whole 128*TN-byte row
+        // segments, 4x fewer store instructions (the stores, not the bandwidth, bound the short-K layers).
+        constexpr int COLS = TN * 32;                 // columns of this wave's sub-tile
+        constexpr int LPR = COLS / 4;                 // lanes per row (16 B each)
+        constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+        float* stage = lds + wave * (8 * COLS);       // [8 rows][COLS]  (all tile reads are behind the last barrier)
+        const int rl = lane / LPR, c4 = lane % LPR;
+        const int ncol = b0 + wn * COLS + c4 * 4;
+        f32x4 xl4 = {0.f, 0.f, 0.f, 0.f};
+        if (xlast) xl4 = *reinterpret_cast<const f32x4*>(xlast + ncol);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {             // rows 8g .. 8g+7 of the 32-row MFMA tile i
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < 8 / RPI; h++) {
+                    const int rloc = rl + h * RPI;
+                    const int m = m0 + wm * (TM * 32) + i * 32 + 8 * g + rloc;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
+                    if (m < p.Cout) {
+                        const int64_t row = (int64_t)m * p.HoWo + o;
+                        if (xlast) {
+                            const float lc = p.lastcol[row];
+                            const f32x4 bp = xl4 * lc;
+                            v = v + bp;
+                        }
+                        if (p.relu) {
+                            v.x = (v.x < 0.0f) ? 0.0f : v.x;
+                            v.y = (v.y < 0.0f) ? 0.0f : v.y;
+                            v.z = (v.z < 0.0f) ? 0.0f : v.z;
+                            v.w = (v.w < 0.0f) ? 0.0f : v.w;
+                        }
+                        *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + ncol) = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = b0 + wn * (TN * 32) + j * 32 + (lane & 31);
@@ -343,6 +391,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.unit_coef = A.unit_coef ? 1 : 0;
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
+    a.wide_store = (a.vec_ok && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0) ? 1 : 0;
     a.max_slots = A.max_slots;
     a.ntaps = (int32_t)A.ntaps;
     a.last_in_row = A.Cin * A.Hin * A.Win;
