@@ -51,3 +51,16 @@ def test_tiled_orthogonal_keynet_matches_reference(golden):
         (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4)
     _check_sensor(z, sensor)
     _check_layers(z, knet)
+
+
+def test_hierarchical_permutation_matrix_is_the_image_permutation():
+    """test/test_blockpermute.py:62-73: P.dot(img.flatten()).reshape(shape) == hierarchical_block_permute(img) for the same draws."""
+    from keynet_amd import keys as kkeys
+    img = np.random.RandomState(0).rand(32, 32, 3).astype(np.float32)
+    for (levels, twist) in (((0,), False), ((0, 1), False), ((0, 1, 2), False), ((0,), True)):
+        np.random.seed(5)
+        ref = kkeys.hierarchical_block_permute(img, (2, 2), list(levels), min_blocksize=8, twist=twist)
+        (P, Pinv) = kkeys.hierarchical_block_permutation_matrix(img.shape, (2, 2), list(levels), min_blocksize=8, seed=5, twist=twist, withinverse=True)
+        assert np.array_equal(P.dot(img.flatten()).reshape(img.shape), ref)
+        assert np.array_equal(Pinv.dot(P.dot(img.flatten())), img.flatten())
+        assert not np.array_equal(ref, img)

@@ -412,3 +412,75 @@ def test_convtaps_random_shapes(case):
         y = W.torchdot(xd, relu=relu).cpu().numpy()
         r = np.maximum(ref, 0) if relu else ref
         assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (case, Cin, Cout, H, k, stride, n_vecs, unit, np.abs(y - r).max())
+
+
+def _keyed_vs_plain(net, inshape, n, factory_kwargs, atol):
+    """The reference's own integration criterion (test/test_keynet.py): keyed logits == source-network logits."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.Keynet(inshape, net, **factory_kwargs)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, *inshape, generator=g)
+    y = knet.forward(sensor.fromtensor(x.to(dev())).encrypt().astensor()).reshape(n, -1).cpu().numpy()
+    with torch.no_grad():
+        yp = net(x).numpy()
+    assert np.allclose(y, yp, atol=atol), (factory_kwargs, np.abs(y - yp).max())
+    return knet
+
+
+@pytest.mark.parametrize('kw,atol', [
+    (dict(global_photometric='uniform_random_gain', beta=1.0), 1e-5),                  # test_keynet.py:70-71
+    (dict(global_photometric='uniform_random_bias', gamma=1.0), 1e-5),                 # :74-75
+    (dict(global_photometric='uniform_random_affine', beta=1.0, gamma=1.0), 1e-4),     # :78-79
+    (dict(global_geometric='permutation', memoryorder='block', blocksize=14), 1e-5),   # :59-61
+])
+def test_photometric_and_block_order_keynets(kw, atol):
+    torch.manual_seed(0)
+    np.random.seed(1)
+    _keyed_vs_plain(LeNet_AvgPool().eval(), (1, 28, 28), 3, kw, atol)
+
+
+def test_lenet_orthogonal_untiled():
+    """test/test_keynet.py:178-197: hierarchical rotation + global bias + local Givens + local affine, block order, untiled."""
+    torch.manual_seed(0)
+    np.random.seed(2)
+    _keyed_vs_plain(LeNet_AvgPool().eval(), (1, 28, 28), 2,
+                    dict(tileshape=None, global_geometric='hierarchical_rotation', hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0),
+                         global_photometric='uniform_random_bias', local_geometric='givens_orthogonal', alpha=2.0, blocksize=8,
+                         local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='block'), 2e-5)
+
+
+def test_lenet_orthogonal_tiled():
+    """test/test_keynet.py:200-219: the same family with tileshape (4,4) (conv layers on the MFMA path, effective tiles 4/2/7)."""
+    torch.manual_seed(0)
+    np.random.seed(3)
+    knet = _keyed_vs_plain(LeNet_AvgPool().eval(), (1, 28, 28), 2,
+                           dict(tileshape=(4, 4), global_geometric='hierarchical_permutation', hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1),
+                                global_photometric='identity', local_geometric='givens_orthogonal', alpha=2.0, blocksize=4,
+                                local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='block'), 2e-5)
+    assert isinstance(knet._keynet.conv1.W, ksp.Conv2dTiledMatrix) and isinstance(knet._keynet.pool1.W, ksp.TiledMatrix)
+
+
+@pytest.mark.parametrize('tiled', [False, True])
+def test_allconvnet_identity_with_batchnorm(tiled):
+    """test/test_keynet.py:241-261: AllConvNet(batchnorm=True) -- batch norms folded into conv3/conv6, the ReLUs that follow
+    them keyed on their own (KeyedLayer of an nn.ReLU: key change + ReLU in forward) -- identity keys, optionally tiled (8,8).
+    Reduced width (16/32 channels); running statistics randomised so the fold is not trivially the identity."""
+    from keynet_amd.models import AllConvNet
+    torch.manual_seed(0)
+    net = AllConvNet(batchnorm=True, width=16).eval()
+    with torch.no_grad():
+        for m in (net.conv3_bn, net.conv6_bn):
+            m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+            m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+            m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+            m.bias.copy_(torch.randn_like(m.bias) * 0.1)
+    np.random.seed(4)
+    knet = _keyed_vs_plain(net, (3, 32, 32), 2,
+                           dict(tileshape=None if not tiled else (8, 8), global_geometric='identity', hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1),
+                                global_photometric='identity', local_geometric='identity', alpha=2.0, blocksize=8, local_photometric='identity', beta=1.0, gamma=1.0,
+                                memoryorder='channel'), 2e-5)
+    names = [n for (n, _) in knet._keynet.named_children()]
+    assert 'conv3_bn' not in names and 'dropout3' not in names and 'relu3' in names
+    assert isinstance(knet._keynet.relu3, KeyedLayer) and knet._keynet.relu3.iskeyedrelu()      # keyed ReLU after the folded batch norm
