@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/<run>/ directory (bench.json/.log, stats/, pmc_fetch/, pmc_write/, pmc_mfma/, pmc_l2/ written by the
+rocprofv3 commands listed in profiles/README.md) into the committed profiles/rNN_* artefacts.
+
+    python3 tools/make_profiles.py gpurun_out/r1d r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def per_kernel(d, counter):
+    f = glob.glob(d + '/runc/*counter_collection.csv')[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+            agg[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return agg
+
+
+def main(R, tag, out='profiles', forwards=4):
+    os.makedirs(out, exist_ok=True)
+    for f in glob.glob(out + '/%s_*' % tag):
+        os.remove(f)
+    pre = '%s/%s_vgg16_b256_' % (out, tag)
+    rows = list(csv.DictReader(open(glob.glob(R + '/stats/runc/*kernel_stats.csv')[0])))
+    with open(pre + 'kernel_stats.csv', 'w') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for r in rows:
+            n = r['Name']
+            w.writerow([n if len(n) < 150 else n[:147] + '...', r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
+    shutil.copy(R + '/bench.json', pre + 'bench.json')
+    shutil.copy(R + '/stats_bench.json', pre + 'bench_under_rocprof.json')
+    open(pre + 'layers.log', 'w').write(''.join(l for l in open(R + '/bench.log') if 'bench' in l))
+    (fe, wr) = (per_kernel(R + '/pmc_fetch', 'FETCH_SIZE'), per_kernel(R + '/pmc_write', 'WRITE_SIZE'))
+    tr = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES '
+                     'SQ_LDS_BANK_CONFLICT / TCC_HIT_sum TCC_MISS_sum) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline',
+          'units': 'FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads: MI355X_MICROARCH.md HBM section; calibrated in the '
+                   'same kind of run on kn::transpose_kernel: 147.0 MiB read -> FETCH_SIZE 73.5 MiB, WRITE_SIZE 147.0 MiB exact)',
+          'forwards_in_run': forwards, 'kernels': {}}
+    (tot_f, tot_w) = (0.0, 0.0)
+    for k in fe:
+        if 'convtaps' not in k and 'csr_' not in k and 'dense_reduce' not in k:
+            continue
+        f_raw = sum(fe[k]) * 1024 / forwards
+        w_b = sum(wr.get(k, [0])) * 1024 / forwards
+        tr['kernels'][k[:80]] = {'launches_per_forward': len(fe[k]) // forwards, 'fetch_bytes_raw_per_forward': f_raw,
+                                 'fetch_bytes_corrected_per_forward': 2 * f_raw, 'write_bytes_per_forward': w_b}
+        if 'convtaps' in k:
+            tot_f += 2 * f_raw
+            tot_w += w_b
+    tr['convtaps_hbm_bytes_per_forward'] = tot_f + tot_w
+    tr['convtaps_fetch_corrected_per_forward'] = tot_f
+    tr['convtaps_write_per_forward'] = tot_w
+    pm = {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(glob.glob(R + '/pmc_mfma/runc/*counter_collection.csv')[0])):
+        if 'convtaps' in r['Kernel_Name']:
+            agg[r['Kernel_Name'][:70]][r['Counter_Name']] += float(r['Counter_Value'])
+    dur = collections.defaultdict(float)
+    for r in csv.DictReader(open(glob.glob(R + '/pmc_mfma/runc/*kernel_trace.csv')[0])):
+        if 'convtaps' in r['Kernel_Name']:
+            dur[r['Kernel_Name'][:70]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9
+    for (k, v) in agg.items():
+        pm[k] = {'effective_clock_ghz': v['GRBM_GUI_ACTIVE'] / 8 / dur[k] / 1e9, 'mfma_busy_fraction_of_simd_cycles': v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * v['GRBM_GUI_ACTIVE'] / 8),
+                 'lds_bank_conflict_cycles': v['SQ_LDS_BANK_CONFLICT'], 'duration_s_under_pmc': dur[k]}
+    agg2 = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(glob.glob(R + '/pmc_l2/runc/*counter_collection.csv')[0])):
+        if 'convtaps' in r['Kernel_Name']:
+            agg2[r['Kernel_Name'][:70]][r['Counter_Name']] += float(r['Counter_Value'])
+    for (k, v) in agg2.items():
+        pm.setdefault(k, {})['l2_hit_rate'] = v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum'])
+    tr['convtaps_pmc'] = pm
+    json.dump(tr, open(pre + 'traffic.json', 'w'), indent=1)
+    b = json.load(open(R + '/bench.json'))
+    print('value %.1f img/s, %.2f ms/step, roofline frac %.4f (%.1f TF), conv traffic %.1f GB (fetch %.1f + write %.1f), alg bytes %.1f GB' %
+          (b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline']['achieved'], (tot_f + tot_w) / 1e9, tot_f / 1e9, tot_w / 1e9, b['roofline']['algorithmic_bytes'] / 1e9))
+    print(json.dumps(pm, indent=1))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2])
