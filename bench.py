@@ -45,14 +45,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(name, rank, world):
+def build_workload(name, rank, world, exact=None):
     """(sensor, knet, inshape, per_gpu_batch, description).  Deterministic under the seeds, identical on every rank."""
     t0 = time.time()
     if name == 'vgg16':
         torch.manual_seed(0)
         net = VGG16(num_classes=2622).eval()
         np.random.seed(0)
-        (sensor, knet) = ksys.TiledPermutationKeynet((3, 224, 224), net, 64)
+        (sensor, knet) = ksys.TiledPermutationKeynet((3, 224, 224), net, 64, exact=exact)
         (inshape, batch, desc) = ((3, 224, 224), 256, 'TiledPermutationKeynet VGG16(2622) 3x224x224 tile=64 (effective 56/28/14/7)')
     elif name == 'lenet':
         torch.manual_seed(0)
@@ -197,6 +197,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=5)
+    ap.add_argument('--exact', action='store_true', help='bit-exact mode for the tiled key-nets (order-preserving kernels everywhere; not the headline)')
     ap.add_argument('--graph', action='store_true', help='replay the forward from a captured HIP graph (launch-bound small nets)')
     args = ap.parse_args()
 
@@ -220,7 +221,9 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
     assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world)
 
-    (sensor, knet, inshape, batch, desc) = build_workload(args.workload, rank, world)
+    (sensor, knet, inshape, batch, desc) = build_workload(args.workload, rank, world, exact=True if args.exact else None)
+    if args.exact:
+        desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
     batch = args.batch if args.batch is not None else batch
 
     # synthetic encrypted batch, resident in HBM before the timed region

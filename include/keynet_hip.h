@@ -42,7 +42,8 @@ enum kn_status {
                               (unkeyed nn.ReLU after a keyed layer: keynet/system.py:92; keyed ReLU: keynet/layer.py:93) */
 #define KN_FLAG_EXACT  2u  /* demand the reference's accumulation order and mul-then-add rounding (bit-exact with
                               scipy csr_matvecs).  CSR operators always honour it; conv-tap operators switch from the
-                              MFMA path to the order-preserving path */
+                              MFMA kernel to an order-preserving VALU kernel that walks the factored operator in the
+                              expansion's column order (no CSR is materialised: works at VGG-16 scale) */
 
 typedef struct kn_operator* kn_handle_t;   /* opaque keyed operator resident in HBM */
 

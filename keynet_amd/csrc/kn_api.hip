@@ -303,24 +303,6 @@ static void last_pairs(const kn_operator* h, std::vector<int64_t>& rows, std::ve
     }
 }
 
-static int get_exact_twin(kn_operator* h, kn_operator** twin) {
-    std::lock_guard<std::mutex> g(h->lazy_mu);
-    if (!h->exact) {
-        std::vector<int32_t> ip, ix;
-        std::vector<float> dt;
-        std::vector<int64_t> lr;
-        std::vector<float> lv;
-        last_pairs(h, lr, lv);
-        convtaps_expand(h, lr, lv, ip, ix, dt);
-        kn_operator* t = nullptr;
-        int rc = csr_create_impl(h->rows, h->cols, (int64_t)ix.size(), ip.data(), ix.data(), dt.data(), &t);
-        if (rc) return rc;
-        h->exact = t;
-    }
-    *twin = h->exact;
-    return KN_OK;
-}
-
 }  // namespace kn
 
 using namespace kn;
@@ -626,12 +608,7 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
         if (rc) return rc;
         return dense_reduce(h->dense_ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
     }
-    if (flags & KN_FLAG_EXACT) {
-        kn_operator* t = nullptr;
-        int rc = get_exact_twin(h, &t);
-        if (rc) return rc;
-        return csr_spmm(t->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
-    }
+    // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
     return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
 }
 

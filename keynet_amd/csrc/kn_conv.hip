@@ -336,6 +336,115 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     }
 }
 
+
+// ---- order-preserving path on the factored operator (KN_FLAG_EXACT) ------------------------------------------------
+// The reference applies a Conv2dTiledMatrix as the canonical CSR of its expansion (scipy csr_matrix((v,(r,c))) sorts each
+// row by column), so output row (co, o) accumulates, in f32 with separate multiply and add, over
+//     ci = 0..Cin-1 (ascending), and inside one ci over the pixel's slots by ascending input pixel,   then the bias column.
+// The slot lists are already sorted by input pixel and tapsT[tap][ci][co] keeps the 8 values of a column for 8
+// consecutive output channels contiguous, i.e. the factored operator IS a pattern-grouped CSR (kn_csr.hip) whose values
+// and column indices can be generated on the fly.  One wavefront = one output pixel x 8 output channels x 64*VEC batch
+// columns; values arrive as wave-uniform scalar loads.  No expansion is materialised, so a bit-exact forward of the
+// tiled key-nets is possible at any size (VGG-16: 15 G non-zeros would be 120 GB as CSR).
+#pragma clang fp contract(off)
+template <int VEC>
+__global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
+    constexpr int RBX = 8;
+    const int64_t n_ct = (p.n_vecs + 64 * VEC - 1) / (64 * VEC);
+    const int64_t n_items = n_ct * n_rb;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t item = xl * chunk + (blockIdx.x >> 3);
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = rb * 4 + wave;                       // (pixel index in processing order, channel bundle)
+    if (w >= (int64_t)p.n_pix * n_cob) return;
+    const int o = p.pix_order[w / n_cob];
+    const int co0 = (int)(w % n_cob) * RBX;
+    const int s_beg = p.pix_ptr[o];
+    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    const int64_t c = ct * (64 * VEC) + (int64_t)lane * VEC;
+    const bool active = c < p.n_vecs;
+    const float* xc = p.X + (active ? c : 0);
+
+    float acc[RBX][VEC];
+#pragma unroll
+    for (int r = 0; r < RBX; r++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
+
+    for (int ci = 0; ci < p.Cin; ci++) {
+        const float* xrow = xc + (int64_t)ci * p.HiWi * p.ldx;
+        int s = 0;
+        while (s < n_slots) {
+            const int in = p.slot_in[s_beg + s];
+            // value of the expansion's entry (row, col): entries of several taps that hit the same (output, input) pixel pair
+            // are ONE stored non-zero, their f32 sum in entry order (scipy sums duplicates; kn_export_csr does the same)
+            float ar[RBX];
+            {
+                const float* a = p.tapsT + ((int64_t)p.slot_tap[s_beg + s] * p.cin_pad + ci) * p.cout_pad + co0;
+                const float coef = p.unit_coef ? 1.0f : p.slot_coef[s_beg + s];
+#pragma unroll
+                for (int r = 0; r < RBX; r++) ar[r] = p.unit_coef ? a[r] : (coef == 1.0f ? a[r] : coef * a[r]);
+            }
+            s++;
+            while (s < n_slots && p.slot_in[s_beg + s] == in) {
+                const float* a = p.tapsT + ((int64_t)p.slot_tap[s_beg + s] * p.cin_pad + ci) * p.cout_pad + co0;
+                const float coef = p.unit_coef ? 1.0f : p.slot_coef[s_beg + s];
+#pragma unroll
+                for (int r = 0; r < RBX; r++) {
+                    const float t = p.unit_coef ? a[r] : (coef == 1.0f ? a[r] : coef * a[r]);
+                    ar[r] = ar[r] + t;
+                }
+                s++;
+            }
+            float xv[VEC];
+            if constexpr (VEC == 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(xrow + (int64_t)in * p.ldx);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) xv[v] = xrow[(int64_t)in * p.ldx + v];
+            }
+#pragma unroll
+            for (int r = 0; r < RBX; r++) {
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const float pr = ar[r] * xv[v];
+                    acc[r][v] = acc[r][v] + pr;
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
+#pragma unroll
+    for (int r = 0; r < RBX; r++) {
+        const int m = co0 + r;
+        if (m >= p.Cout) continue;
+        const int64_t row = (int64_t)m * p.HoWo + o;
+        if (xlast) {
+            const float lc = p.lastcol[row];
+            if (lc != 0.0f) {                              // the bias entry exists in the reference's row only when it is stored
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const float bp = lc * xlast[v];
+                    acc[r][v] = acc[r][v] + bp;
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            float t = acc[r][v];
+            if (p.relu) t = (t < 0.0f) ? 0.0f : t;
+            p.Y[row * p.ldy + c + v] = t;
+        }
+    }
+}
+
 // homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
 __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
                                                            float* __restrict__ ylast, int64_t n_vecs, int relu) {
@@ -391,6 +500,23 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.unit_coef = A.unit_coef ? 1 : 0;
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
+    a.last_in_row = A.Cin * A.Hin * A.Win;
+    if (flags & KN_FLAG_EXACT) {
+        const int n_cob = (int)((A.Cout + 7) / 8);
+        const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
+        const bool v4 = a.vec_ok && n_vecs >= 256;
+        const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
+        const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
+        if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (A.has_last) {
+            const int64_t out_last = A.Cout * A.Hout * A.Wout;
+            hipLaunchKernelGGL(conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
+                               x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+        }
+        KN_HIP(hipGetLastError());
+        return KN_OK;
+    }
     a.wide_store = (a.vec_ok && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0) ? 1 : 0;
     a.max_slots = A.max_slots;
     a.ntaps = (int32_t)A.ntaps;
