@@ -23,6 +23,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static constexpr int MAX_FAST_SLOTS = 64;   // slots per output pixel the FAST path keeps in LDS (3x3 .. 7x7 windows)
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: arrays of HIP's float4 struct are not promoted to registers
 
+// Ordering point for LDS traffic that stays inside one wavefront (no s_barrier, no vmcnt wait on in-flight global stores).
+__device__ __forceinline__ void kn_wave_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 struct ConvArgs {
     const float* tapsT;
     const int32_t* pix_ptr;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; j++)
 #pragma unroll
                     for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
-                __syncthreads();
+                kn_wave_sync();   // the slice is private to this wavefront and a wavefront's LDS operations execute in order
 #pragma unroll
                 for (int h = 0; h < 8 / RPI; h++) {
                     const int rloc = rl + h * RPI;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
                         *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + ncol) = v;
                     }
                 }
-                __syncthreads();
+                kn_wave_sync();
             }
         }
         return;
@@ -336,6 +343,141 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     }
 }
 
+
+// ---- one-shot small-K path -----------------------------------------------------------------------------------------------
+// First layer of an image network (VGG conv1_1: Cin = 3, 9 taps): the whole contraction of one output pixel is
+// K = slots*Cin + 1 (bias via the homogeneous row) <= 28 rows, while the output tile is 64 x 256 floats -- the layer is
+// bound by its 3.3 GB of output writes, not by MFMA.  So no chunk loop: gather all K activation rows and tap rows into
+// LDS once, one barrier, K/2 MFMA steps per wavefront, wide store.  Four workgroups per CU overlap each other's phases.
+constexpr int SMALLK_MAX = 28;
+
+__global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
+    constexpr int MT = 64, NB = 256, TM = 2, TN = 2, KM = SMALLK_MAX;
+    __shared__ __attribute__((aligned(16))) float lds[KM * MT + KM * NB];
+    float* As = lds;              // [KM][64]
+    float* Bs = lds + KM * MT;    // [KM][256]
+
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t item = xl * chunk + (blockIdx.x >> 3);
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    const int mt = (int)(item % p.n_mt);
+    const int64_t t1 = item / p.n_mt;
+    const int pi = (int)(t1 % p.n_pix);
+    const int bt = (int)(t1 / p.n_pix);
+    const int o = p.pix_order[pi];
+    const int m0 = mt * MT;
+    const int b0 = bt * NB;
+    const int s_beg = p.pix_ptr[o];
+    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    const int k_conv = n_slots * p.Cin;                 // rows of the contraction proper
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // activation rows: wavefront w gathers rows w, w+4, ... (one 1 KiB row per instruction)
+    f32x4 bv[KM / 4];
+#pragma unroll
+    for (int r = 0; r < KM / 4; r++) {
+        const int k = wave + 4 * r;
+        bv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < k_conv) {
+            const int sl = k / p.Cin, ci = k - sl * p.Cin;
+            const int64_t xrow = (int64_t)ci * p.HiWi + p.slot_in[s_beg + sl];
+            bv[r] = *reinterpret_cast<const f32x4*>(p.X + xrow * p.ldx + b0 + lane * 4);
+        } else if (k == k_conv && p.lastcol) {
+            bv[r] = *reinterpret_cast<const f32x4*>(p.X + p.last_in_row * p.ldx + b0 + lane * 4);
+        }
+    }
+    // tap rows (scaled by the slot coefficient) and the bias row
+    constexpr int AV = (KM * MT / 4 + 255) / 256;
+    f32x4 av[AV];
+#pragma unroll
+    for (int r = 0; r < AV; r++) {
+        const int idx = tid + 256 * r;
+        const int k = idx >> 4, m4 = (idx & 15) * 4;
+        av[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < k_conv) {
+            const int sl = k / p.Cin, ci = k - sl * p.Cin;
+            const float cf = p.slot_coef[s_beg + sl];
+            av[r] = *reinterpret_cast<const f32x4*>(p.tapsT + ((int64_t)p.slot_tap[s_beg + sl] * p.cin_pad + ci) * p.cout_pad + m0 + m4);
+            av[r] = av[r] * cf;
+        } else if (k == k_conv && p.lastcol) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int m = m0 + m4 + e;
+                av[r][e] = (m < p.Cout) ? p.lastcol[(int64_t)m * p.HoWo + o] : 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < KM / 4; r++) *reinterpret_cast<f32x4*>(Bs + (wave + 4 * r) * NB + lane * 4) = bv[r];
+#pragma unroll
+    for (int r = 0; r < AV; r++) {
+        const int idx = tid + 256 * r;
+        if (idx < KM * MT / 4) *reinterpret_cast<f32x4*>(As + idx * 4) = av[r];
+    }
+    __syncthreads();
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    const int arow = lane >> 5;
+    const int acol = lane & 31;
+    const int bcol = wave * (TN * 32) + (lane & 31);
+    const int k_steps = (k_conv + (p.lastcol ? 1 : 0) + 1) >> 1;
+    for (int st = 0; st < k_steps; st++) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[i] = As[(2 * st + arow) * MT + acol + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[j] = Bs[(2 * st + arow) * NB + bcol + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // tiles are dead: reuse them as per-wavefront transposition slices
+
+    constexpr int COLS = TN * 32;
+    constexpr int LPR = COLS / 4;
+    constexpr int RPI = 64 / LPR;
+    float* stage = lds + wave * (8 * COLS);
+    const int rl = lane / LPR, c4 = lane % LPR;
+    const int ncol = b0 + wave * COLS + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
+            kn_wave_sync();
+#pragma unroll
+            for (int h = 0; h < 8 / RPI; h++) {
+                const int rloc = rl + h * RPI;
+                const int m = m0 + i * 32 + 8 * g + rloc;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
+                if (m < p.Cout) {
+                    if (p.relu) {
+                        v.x = (v.x < 0.0f) ? 0.0f : v.x;
+                        v.y = (v.y < 0.0f) ? 0.0f : v.y;
+                        v.z = (v.z < 0.0f) ? 0.0f : v.z;
+                        v.w = (v.w < 0.0f) ? 0.0f : v.w;
+                    }
+                    *reinterpret_cast<f32x4*>(p.Y + ((int64_t)m * p.HoWo + o) * p.ldy + ncol) = v;
+                }
+            }
+            kn_wave_sync();
+        }
+    }
+}
 
 // ---- order-preserving path on the factored operator (KN_FLAG_EXACT) ------------------------------------------------
 // The reference applies a Conv2dTiledMatrix as the canonical CSR of its expansion (scipy csr_matrix((v,(r,c))) sorts each
@@ -523,7 +665,13 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.last_in_row = A.Cin * A.Hin * A.Win;
     const bool big_m = A.cout_pad % 128 == 0 && A.Cout > 64;
     const bool k16 = A.cin_pad % 16 == 0;
-    if (big_m) {
+    static const bool no_smallk = getenv("KN_NO_SMALLK") != nullptr;
+    if (!no_smallk && (int64_t)A.max_slots * A.Cin + (A.has_last ? 1 : 0) <= SMALLK_MAX && a.wide_store && n_vecs % 256 == 0 && A.cout_pad % 64 == 0) {
+        a.n_mt = (int32_t)(A.cout_pad / 64);
+        a.n_bt = (int32_t)(n_vecs / 256);
+        const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
+        hipLaunchKernelGGL(convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
+    } else if (big_m) {
         a.n_mt = (int32_t)(A.cout_pad / 128);
         a.n_bt = (int32_t)((n_vecs + 127) / 128);
         if (k16) launch_conv<128, 128, 16, 2, 2>(a, s);

@@ -365,21 +365,10 @@ def test_output_encryption_roundtrip(golden):
     assert pub.embeddingkey() is None and pub.imagekey() is None
 
 
-@pytest.mark.parametrize('case', range(10))
-def test_convtaps_random_shapes(case):
-    """Randomised conv-taps operators (odd channel counts, stride 2, 1x1 / 3x3 / 5x5 windows, several float-coefficient
-    entries per (pixel, tap), missing bias column, ragged batches that exercise the generic loader):
-    MFMA path vs the order-preserving path (bit-exact vs the oracle) within the conditioned 1e-5 bound."""
+def _random_convtaps(rng, Cin, Cout, H, k, stride, unit, has_last):
+    """A conv-taps operator with permuted input / output pixels; `unit=False` adds a second, float-weighted entry to about
+    half of the (pixel, tap) pairs (the shape of a non-permutation spatial key)."""
     from keynet_amd import direct as kdirect
-    rng = np.random.RandomState(100 + case)
-    Cin = int(rng.choice([1, 2, 3, 5, 16, 17, 32, 40]))
-    Cout = int(rng.choice([1, 3, 8, 33, 64, 65, 130]))
-    H = int(rng.choice([4, 6, 8]))
-    k = int(rng.choice([1, 3, 5]))
-    stride = int(rng.choice([1, 2]))
-    n_vecs = int(rng.choice([1, 3, 4, 64, 100, 128, 256, 260]))
-    unit = bool(rng.rand() < 0.5)
-    has_last = bool(rng.rand() < 0.7)
     (Ho, HW, HoWo) = (H // stride, H * H, (H // stride) ** 2)
     w = (rng.randn(Cout, Cin, k, k) / np.sqrt(k * k * Cin)).astype(np.float32)
     (pi, po) = (rng.permutation(HW), rng.permutation(HoWo))
@@ -387,7 +376,7 @@ def test_convtaps_random_shapes(case):
     for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((H, H), k, stride)):
         S = S.tocoo()
         eo.append(po[S.row]); ei.append(pi[S.col]); et.append(np.full(S.nnz, t)); ec.append(np.ones(S.nnz, np.float32))
-        if not unit:                                         # a second, weighted entry for some (pixel, tap) pairs
+        if not unit:
             sel = rng.rand(S.nnz) < 0.5
             eo.append(po[S.row][sel]); ei.append(pi[(S.col[sel] + 1) % HW]); et.append(np.full(int(sel.sum()), t))
             ec.append(rng.randn(int(sel.sum())).astype(np.float32))
@@ -398,7 +387,10 @@ def test_convtaps_random_shapes(case):
         (eo, ei, et, ec) = (eo[first], ei[first], et[first], ec[first])
     taps = np.stack([w[:, :, i, j] for i in range(k) for j in range(k)])
     lastcol = np.concatenate((rng.randn(Cout * HoWo), [1.0])).astype(np.float32) if has_last else None
-    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, Ho, Ho), taps, eo, ei, et, None if unit else ec, lastcol)
+    return ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, Ho, Ho), taps, eo, ei, et, None if unit else ec, lastcol)
+
+
+def _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, tag):
     X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
     if has_last:
         X[-1] = 1.0
@@ -411,7 +403,42 @@ def test_convtaps_random_shapes(case):
     for relu in (False, True):
         y = W.torchdot(xd, relu=relu).cpu().numpy()
         r = np.maximum(ref, 0) if relu else ref
-        assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (case, Cin, Cout, H, k, stride, n_vecs, unit, np.abs(y - r).max())
+        assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (tag, np.abs(y - r).max())
+
+
+@pytest.mark.parametrize('case', range(10))
+def test_convtaps_random_shapes(case):
+    """Randomised conv-taps operators (odd channel counts, stride 2, 1x1 / 3x3 / 5x5 windows, several float-coefficient
+    entries per (pixel, tap), missing bias column, ragged batches that exercise the generic loader):
+    MFMA path vs the order-preserving path (bit-exact vs the oracle) within the conditioned 1e-5 bound."""
+    rng = np.random.RandomState(100 + case)
+    Cin = int(rng.choice([1, 2, 3, 5, 16, 17, 32, 40]))
+    Cout = int(rng.choice([1, 3, 8, 33, 64, 65, 130]))
+    H = int(rng.choice([4, 6, 8]))
+    k = int(rng.choice([1, 3, 5]))
+    stride = int(rng.choice([1, 2]))
+    n_vecs = int(rng.choice([1, 3, 4, 64, 100, 128, 256, 260]))
+    unit = bool(rng.rand() < 0.5)
+    has_last = bool(rng.rand() < 0.7)
+    W = _random_convtaps(rng, Cin, Cout, H, k, stride, unit, has_last)
+    _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, (case, Cin, Cout, H, k, stride, n_vecs, unit))
+
+
+@pytest.mark.parametrize('Cin,Cout,k,stride,n_vecs,unit,has_last', [
+    (3, 64, 3, 1, 256, True, True),      # VGG conv1_1 shape: K = 27 + bias row = 28, the limit of the one-shot kernel
+    (1, 64, 3, 1, 512, False, True),     # float coefficients (<= 18 slots per pixel): folded into the tap rows
+    (3, 70, 3, 1, 256, True, False),     # no bias column, odd K (zero row pads the last MFMA step), Cout ragged over 2 tiles
+    (1, 6, 5, 1, 256, True, True),       # LeNet conv1 shape: K = 25 + 1
+    (2, 33, 3, 2, 256, True, True),      # stride 2
+    (3, 64, 3, 1, 256, False, True),     # up to 18 slots * 3 channels: too deep for the one-shot kernel, chunked kernel
+    (3, 64, 3, 1, 260, True, True),      # ragged batch: not eligible, generic loader
+])
+def test_convtaps_small_k_path(Cin, Cout, k, stride, n_vecs, unit, has_last):
+    """First-layer operators (slots * Cin + bias <= 28) take the one-shot small-K kernel when the batch is a multiple of 256
+    (kn_conv.hip convtaps_smallk_kernel); same bar as every other MFMA launch."""
+    rng = np.random.RandomState(7 * Cin + k + n_vecs)
+    W = _random_convtaps(rng, Cin, Cout, 8, k, stride, unit, has_last)
+    _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, (Cin, Cout, k, stride, n_vecs, unit, has_last))
 
 
 def _keyed_vs_plain(net, inshape, n, factory_kwargs, atol):
