@@ -72,6 +72,15 @@ def build_workload(name, rank, world, exact=None):
     return (sensor, knet, inshape, batch, desc)
 
 
+def _takes_small_k_kernel(W, batch):
+    """Mirror of the dispatch in kn_conv.hip (convtaps_spmm): one output pixel's whole contraction fits 28 rows (VGG conv1_1),
+    which runs in the write-bound convtaps_smallk_kernel and is therefore not part of the MFMA roofline aggregate."""
+    t = getattr(W, '_taps', None)
+    if t is None or batch % 256:
+        return False
+    return int(np.bincount(t['ent_out']).max()) * W._inshape[0] + (1 if t['lastcol'] is not None else 0) <= 28
+
+
 def layer_table(knet, batch):
     """Per keyed layer: algorithmic MACs (= nnz of the expanded operator the reference applies) and bytes."""
     rows = []
@@ -83,7 +92,7 @@ def layer_table(knet, batch):
         (r, cdim) = op.shape()
         nnz_exp = op.nnz_expanded()
         if isinstance(c.W, ksp.Conv2dTiledMatrix):
-            kind = 'convtaps'
+            kind = 'smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps'
             wbytes = 4 * c.W.nnz()            # taps + entries + last column actually read
         elif type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
             kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)

@@ -187,6 +187,7 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
         slot_tap[k] = b.ent_tap[e];
         slot_coef[k] = b.ent_coef[e];
         if (b.ent_coef[e] != 1.0f) c.unit_coef = false;
+        if (k > 0 && b.ent_out[order[k - 1]] == b.ent_out[e] && b.ent_in[order[k - 1]] == b.ent_in[e]) c.has_dups = true;
     }
     int mx = 0;
     for (int64_t o = 0; o < HoWo; o++) {

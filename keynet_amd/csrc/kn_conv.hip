@@ -30,6 +30,9 @@ __device__ __forceinline__ void kn_wave_sync() {
     asm volatile("" ::: "memory");
 }
 
+// Ordering point for the machine scheduler (holds inside one basic block).
+__device__ __forceinline__ void kn_order() { __builtin_amdgcn_sched_barrier(0); }
+
 struct ConvArgs {
     const float* tapsT;
     const int32_t* pix_ptr;
@@ -587,6 +590,118 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
     }
 }
 
+// Software-pipelined instantiation of the order-preserving path for the common operator shape: unit coefficients
+// (identity / permutation keys) and no (output, input) pixel pair hit twice, so the contraction is a plain double loop
+// "ci ascending, slot ascending" with ONE stored value per step.  The slot table lives in two VGPRs (lane s = slot s,
+// read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
+// before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
+// vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
+template <int RBX>
+__global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
+    const int64_t n_ct = (p.n_vecs + 255) / 256;
+    const int64_t n_items = n_ct * n_rb;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t item = xl * chunk + (blockIdx.x >> 3);
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t w = rb * 4 + wave;
+    if (w >= (int64_t)p.n_pix * n_cob) return;
+    const int o = p.pix_order[w / n_cob];
+    const int co0 = (int)(w % n_cob) * RBX;
+    const int s_beg = p.pix_ptr[o];
+    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    const int64_t c = ct * 256 + (int64_t)lane * 4;
+    const bool active = c < p.n_vecs;
+    const uint32_t lane_off = (uint32_t)(active ? c : 0);
+
+    f32x4 acc[RBX];
+#pragma unroll
+    for (int r = 0; r < RBX; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (n_slots > 0) {
+        // lane s: element offsets of slot s (32-bit: the launcher checks the ranges)
+        int my_xoff = 0, my_aoff = 0;
+        if (lane < n_slots) {
+            my_xoff = p.slot_in[s_beg + lane] * (int)p.ldx;
+            my_aoff = p.slot_tap[s_beg + lane] * (p.cin_pad * p.cout_pad);
+        }
+        const int ch_x = p.HiWi * (int)p.ldx;                   // one input channel of X
+        const float* a_base = p.tapsT + co0;
+        const int n_q = n_slots * p.Cin;
+        int s = 0, ci_x = 0, ci_a = 0;                           // wave-uniform walk: slot inner, channel outer
+        int q_next = 0;                                          // step whose operands are fetched next
+        auto fetch = [&](f32x4& xr, float (&ar)[RBX]) {
+            const int xo = __builtin_amdgcn_readlane(my_xoff, s) + ci_x;
+            const int ao = __builtin_amdgcn_readlane(my_aoff, s) + ci_a;
+            xr = *reinterpret_cast<const f32x4*>((p.X + xo) + lane_off);
+            const float* a = a_base + ao;
+#pragma unroll
+            for (int r = 0; r < RBX; r++) ar[r] = a[r];
+            // Branch-free advance (selects on wave-uniform values: one basic block, so the ordering points below hold).  Past the
+            // end the last step's operands are fetched again: exactly one row stays in flight and the wait is a counted one.
+            q_next++;
+            const bool more = q_next < n_q;
+            const bool wrap = (s + 1 == n_slots);
+            s = __builtin_amdgcn_readfirstlane(more ? (wrap ? 0 : s + 1) : s);
+            ci_x = __builtin_amdgcn_readfirstlane(ci_x + ((more && wrap) ? ch_x : 0));
+            ci_a = __builtin_amdgcn_readfirstlane(ci_a + ((more && wrap) ? p.cout_pad : 0));
+        };
+        auto mac = [&](const f32x4& xv, const float (&av)[RBX]) {
+#pragma unroll
+            for (int r = 0; r < RBX; r++) {
+                const f32x4 pr = xv * av[r];
+                acc[r] = acc[r] + pr;
+            }
+        };
+        f32x4 x0, x1;
+        float a0[RBX], a1[RBX];
+        fetch(x0, a0);
+        int q = 0;
+        // kn_order(): step q+1's loads are issued before step q's arithmetic and never hoisted over step q-1's (that would cost a
+        // register copy and a vmcnt(0) at the loop end)
+        for (; q + 1 < n_q; q += 2) {
+            fetch(x1, a1);
+            kn_order();
+            mac(x0, a0);
+            kn_order();
+            fetch(x0, a0);
+            kn_order();
+            mac(x1, a1);
+            kn_order();
+        }
+        if (q < n_q) mac(x0, a0);
+    }
+    if (!active) return;
+    const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
+    f32x4 xl4 = {0.f, 0.f, 0.f, 0.f};
+    if (xlast) xl4 = *reinterpret_cast<const f32x4*>(xlast);
+#pragma unroll
+    for (int r = 0; r < RBX; r++) {
+        const int m = co0 + r;
+        if (m >= p.Cout) continue;
+        const int64_t row = (int64_t)m * p.HoWo + o;
+        f32x4 t = acc[r];
+        if (xlast) {
+            const float lc = p.lastcol[row];
+            if (lc != 0.0f) {
+                const f32x4 bp = xl4 * lc;
+                t = t + bp;
+            }
+        }
+        if (p.relu) {
+            t.x = (t.x < 0.0f) ? 0.0f : t.x;
+            t.y = (t.y < 0.0f) ? 0.0f : t.y;
+            t.z = (t.z < 0.0f) ? 0.0f : t.z;
+            t.w = (t.w < 0.0f) ? 0.0f : t.w;
+        }
+        *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + c) = t;
+    }
+}
+
 // homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
 __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
                                                            float* __restrict__ ylast, int64_t n_vecs, int relu) {
@@ -644,12 +759,19 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.n_pix = a.HoWo;
     a.last_in_row = A.Cin * A.Hin * A.Win;
     if (flags & KN_FLAG_EXACT) {
-        const int n_cob = (int)((A.Cout + 7) / 8);
-        const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const bool v4 = a.vec_ok && n_vecs >= 256;
         const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
+        static const int pipe_mode = getenv("KN_EXACT_PIPE") ? atoi(getenv("KN_EXACT_PIPE")) : 16;
+        const bool pipe = pipe_mode > 0 && v4 && A.unit_coef && !A.has_dups && A.max_slots <= 64 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0 &&
+                          (a.last_in_row + 1) * ldx < ((int64_t)1 << 31) && (int64_t)A.ntaps * A.cin_pad * A.cout_pad < ((int64_t)1 << 31);
+        // 16 output channels per wavefront when that still leaves every SIMD several wavefronts, else 8
+        const int rbx = (pipe && pipe_mode >= 16 && A.Cout % 16 == 0 && (int64_t)a.n_pix * (A.Cout / 16) * n_ct >= 4096) ? 16 : 8;
+        const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
+        const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16) hipLaunchKernelGGL(convtaps_exact_pipe_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe) hipLaunchKernelGGL(convtaps_exact_pipe_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;

@@ -65,6 +65,7 @@ struct ConvTapsDev {
     float* lastcol = nullptr;           // [Cout*HoWo+1] or null
     bool has_last = false;
     bool unit_coef = true;
+    bool has_dups = false;              // some (output pixel, input pixel) pair is hit by more than one slot
     int max_slots = 0;
 };
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=7)
     ap.add_argument('--perm', action='store_true', help='block-permutation spatial key (tile = hw or 56)')
+    ap.add_argument('--exact', action='store_true', help='time the order-preserving path (KN_FLAG_EXACT) instead of the MFMA path')
     args = ap.parse_args()
     rng = np.random.RandomState(0)
     (Cin, Cout, H) = (args.cin, args.cout, args.hw)
@@ -47,17 +48,17 @@ def main():
     dev = torch.device('cuda:0')
     x = torch.randn((Cin * HW + 1, args.batch), device=dev)
     x[-1] = 1.0
-    y = W.torchdot(x, relu=True)
+    y = W.torchdot(x, relu=True, exact=args.exact)
     torch.cuda.synchronize()
     nnz = W._device_op().nnz_expanded()
     for _ in range(3):
-        y = W.torchdot(x, relu=True)
+        y = W.torchdot(x, relu=True, exact=args.exact)
     torch.cuda.synchronize()
     times = []
     for _ in range(args.iters):
         (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         e0.record()
-        y = W.torchdot(x, relu=True)
+        y = W.torchdot(x, relu=True, exact=args.exact)
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1))
@@ -74,9 +75,10 @@ def main():
     ref = np.maximum(ref + b[:, None].astype(np.float64), 0)
     got = y.cpu().numpy()[np.arange(Cout) * HW + o]
     err = float(np.abs(got - ref).max())
+    if args.exact:
+        print('EXACT path: %.2f T MAC/s (median), %.2f (min time)' % (nnz * args.batch / ms / 1e9, nnz * args.batch / ms_min / 1e9))
     print('cin=%d cout=%d hw=%d batch=%d perm=%d: median %.3f ms %.2f TFLOP/s | min %.3f ms %.2f TFLOP/s | max|err| vs f64 = %.2e' %
           (Cin, Cout, H, args.batch, int(args.perm), ms, 2.0 * nnz * args.batch / ms / 1e9, ms_min, 2.0 * nnz * args.batch / ms_min / 1e9, err))
-    pass
 
 
 if __name__ == '__main__':

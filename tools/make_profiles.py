@@ -51,7 +51,7 @@ def main(R, tag, out='profiles', forwards=4):
         w_b = sum(wr.get(k, [0])) * 1024 / forwards
         tr['kernels'][k[:80]] = {'launches_per_forward': len(fe[k]) // forwards, 'fetch_bytes_raw_per_forward': f_raw,
                                  'fetch_bytes_corrected_per_forward': 2 * f_raw, 'write_bytes_per_forward': w_b}
-        if 'convtaps' in k:
+        if 'convtaps_mfma' in k:
             tot_f += 2 * f_raw
             tot_w += w_b
     tr['convtaps_hbm_bytes_per_forward'] = tot_f + tot_w
