@@ -92,7 +92,7 @@ def layer_table(knet, batch):
         (r, cdim) = op.shape()
         nnz_exp = op.nnz_expanded()
         if isinstance(c.W, ksp.Conv2dTiledMatrix):
-            kind = 'smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps'
+            kind = 'smallk' if (_takes_small_k_kernel(c.W, batch) and not getattr(c, '_exact', False)) else 'convtaps'
             wbytes = 4 * c.W.nnz()            # taps + entries + last column actually read
         elif type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
             kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)

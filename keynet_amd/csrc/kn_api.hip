@@ -196,69 +196,15 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     }
     c.max_slots = mx;
     c.nslots = (int64_t)order.size();
-    // Processing order of the output pixels.  Two pixels are neighbours when they share an input pixel.  The order is a
-    // sequence of breadth-first BALLS of PATCH pixels (for a keyed 3x3 conv: roughly 8x8 patches of the un-keyed image),
-    // seeded along a global breadth-first sweep so consecutive patches are adjacent.  One patch = the workgroups resident
+    // Processing order of the output pixels (kn::locality_order): two pixels are neighbours when they share an input pixel;
+    // balls of 64 are, for a keyed 3x3 conv, roughly 8x8 patches of the un-keyed image.  One patch = the workgroups resident
     // on one XCD at a time (32 CUs x 4 workgroups / 2 Cout tiles), so the gathered activation rows of a patch (a ~10x10
     // halo instead of 64 x 9 scattered pixels) are fetched into that XCD's L2 about once.  This recovers the locality a
     // permutation key destroys, without knowing the key: only the operator's own sparsity structure is used.
     {
-        constexpr int PATCH = 64;
-        std::vector<int32_t> in_ptr((size_t)HiWi + 1, 0), in_outs(order.size());
-        for (size_t k = 0; k < order.size(); k++) in_ptr[(size_t)slot_in[k] + 1]++;
-        for (int64_t i = 0; i < HiWi; i++) in_ptr[(size_t)i + 1] += in_ptr[(size_t)i];
-        std::vector<int32_t> fill(in_ptr.begin(), in_ptr.end() - 1);
-        for (int64_t o = 0; o < HoWo; o++)
-            for (int32_t k = pix_ptr[(size_t)o]; k < pix_ptr[(size_t)o + 1]; k++) in_outs[(size_t)fill[(size_t)slot_in[(size_t)k]]++] = (int32_t)o;
-        auto for_neighbours = [&](int32_t o, auto&& fn) {
-            for (int32_t k = pix_ptr[(size_t)o]; k < pix_ptr[(size_t)o + 1]; k++) {
-                const int32_t i = slot_in[(size_t)k];
-                for (int32_t q = in_ptr[(size_t)i]; q < in_ptr[(size_t)i + 1]; q++) fn(in_outs[(size_t)q]);
-            }
-        };
-        // global sweep (seeds are visited in this order)
-        std::vector<int32_t> sweep((size_t)HoWo);
-        {
-            std::vector<char> seen((size_t)HoWo, 0);
-            size_t head = 0, tail = 0;
-            for (int64_t seed = 0; seed < HoWo; seed++) {
-                if (seen[(size_t)seed]) continue;
-                seen[(size_t)seed] = 1;
-                sweep[tail++] = (int32_t)seed;
-                while (head < tail) {
-                    const int32_t o = sweep[head++];
-                    for_neighbours(o, [&](int32_t o2) {
-                        if (!seen[(size_t)o2]) {
-                            seen[(size_t)o2] = 1;
-                            sweep[tail++] = o2;
-                        }
-                    });
-                }
-            }
-        }
-        // balls
-        std::vector<char> taken((size_t)HoWo, 0);
-        size_t out_n = 0;
-        std::vector<int32_t> ball;
-        ball.reserve(PATCH * 2);
-        for (int64_t si = 0; si < HoWo; si++) {
-            const int32_t seed = sweep[(size_t)si];
-            if (taken[(size_t)seed]) continue;
-            ball.clear();
-            ball.push_back(seed);
-            taken[(size_t)seed] = 1;
-            size_t head = 0;
-            while (head < ball.size() && (int)ball.size() < PATCH) {
-                const int32_t o = ball[head++];
-                for_neighbours(o, [&](int32_t o2) {
-                    if (!taken[(size_t)o2] && (int)ball.size() < PATCH) {
-                        taken[(size_t)o2] = 1;
-                        ball.push_back(o2);
-                    }
-                });
-            }
-            for (int32_t o : ball) pix_order[out_n++] = o;
-        }
+        std::vector<int32_t> ids((size_t)HoWo);
+        for (int64_t o = 0; o < HoWo; o++) ids[(size_t)o] = (int32_t)o;
+        pix_order = locality_order(ids, pix_ptr.data(), slot_in.data(), HiWi, 64, 1 << 30);
     }
     std::vector<float> lastcol;
     if (b.has_last) {

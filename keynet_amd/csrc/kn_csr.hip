@@ -316,6 +316,12 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     }
     for (int64_t r = 0; r < rows; r++)
         if (!in_group[(size_t)r]) loose.push_back((int32_t)r);   // includes empty rows (they must still be zeroed)
+    // loose rows of a big operator (keyed pooling: ~9 non-zeros per row, windows overlap): order them for L2 reuse of the gathers
+    if (loose.size() >= 4096 && !getenv("KN_NO_ROW_ORDER")) {
+        int64_t lnnz = 0;
+        for (int32_t r : loose) lnnz += indptr[r + 1] - indptr[r];
+        if (lnnz <= 64 * (int64_t)loose.size()) loose = locality_order(loose, indptr, indices, h->cols, 64, 64);
+    }
     A.n_groups = (int64_t)colptr.size() - 1;
     A.n_work = (int64_t)wgrp.size();
     A.n_loose = (int64_t)loose.size();
@@ -331,6 +337,77 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     if ((rc = upload(&A.work_r0, wr0.data(), wr0.size()))) return rc;
     if ((rc = upload(&A.loose_rows, loose.data(), loose.size()))) return rc;
     return KN_OK;
+}
+
+// ---- locality order (host) --------------------------------------------------------------------------------------------------
+// A permutation key scatters rows that touch neighbouring inputs all over the row index space.  Rows that are resident on
+// one XCD at the same time should share gathered X rows in that XCD's L2, so the processing order is rebuilt from the
+// operator's own sparsity structure: balls of `patch` rows grown breadth-first over the "shares a column" relation,
+// seeded along a global breadth-first sweep so consecutive balls are adjacent.  The key is never needed.
+std::vector<int32_t> locality_order(const std::vector<int32_t>& row_ids, const int32_t* indptr, const int32_t* indices, int64_t n_cols, int patch,
+                                    int max_degree) {
+    const size_t n = row_ids.size();
+    // column -> local rows (CSC of the selected rows)
+    std::vector<int32_t> cptr((size_t)n_cols + 1, 0);
+    for (size_t i = 0; i < n; i++)
+        for (int32_t k = indptr[row_ids[i]]; k < indptr[row_ids[i] + 1]; k++) cptr[(size_t)indices[k] + 1]++;
+    for (int64_t c = 0; c < n_cols; c++) cptr[(size_t)c + 1] += cptr[(size_t)c];
+    std::vector<int32_t> crow((size_t)cptr[(size_t)n_cols]);
+    {
+        std::vector<int32_t> fill(cptr.begin(), cptr.end() - 1);
+        for (size_t i = 0; i < n; i++)
+            for (int32_t k = indptr[row_ids[i]]; k < indptr[row_ids[i] + 1]; k++) crow[(size_t)fill[(size_t)indices[k]]++] = (int32_t)i;
+    }
+    auto for_neighbours = [&](int32_t i, auto&& fn) {
+        for (int32_t k = indptr[row_ids[(size_t)i]]; k < indptr[row_ids[(size_t)i] + 1]; k++) {
+            const int32_t c = indices[k];
+            if (cptr[(size_t)c + 1] - cptr[(size_t)c] > max_degree) continue;
+            for (int32_t q = cptr[(size_t)c]; q < cptr[(size_t)c + 1]; q++) fn(crow[(size_t)q]);
+        }
+    };
+    std::vector<int32_t> sweep(n);
+    {
+        std::vector<char> seen(n, 0);
+        size_t head = 0, tail = 0;
+        for (size_t seed = 0; seed < n; seed++) {
+            if (seen[seed]) continue;
+            seen[seed] = 1;
+            sweep[tail++] = (int32_t)seed;
+            while (head < tail) {
+                const int32_t i = sweep[head++];
+                for_neighbours(i, [&](int32_t j) {
+                    if (!seen[(size_t)j]) {
+                        seen[(size_t)j] = 1;
+                        sweep[tail++] = j;
+                    }
+                });
+            }
+        }
+    }
+    std::vector<char> taken(n, 0);
+    std::vector<int32_t> out;
+    out.reserve(n);
+    std::vector<int32_t> ball;
+    ball.reserve((size_t)patch * 2);
+    for (size_t si = 0; si < n; si++) {
+        const int32_t seed = sweep[si];
+        if (taken[(size_t)seed]) continue;
+        ball.clear();
+        ball.push_back(seed);
+        taken[(size_t)seed] = 1;
+        size_t head = 0;
+        while (head < ball.size() && (int)ball.size() < patch) {
+            const int32_t i = ball[head++];
+            for_neighbours(i, [&](int32_t j) {
+                if (!taken[(size_t)j] && (int)ball.size() < patch) {
+                    taken[(size_t)j] = 1;
+                    ball.push_back(j);
+                }
+            });
+        }
+        for (int32_t i : ball) out.push_back(row_ids[(size_t)i]);
+    }
+    return out;
 }
 
 template <int VEC, int RBK>

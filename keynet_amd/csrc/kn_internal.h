@@ -103,6 +103,10 @@ int dense_reduce(const float* z, int64_t ldz, int64_t outs, int64_t splits, cons
                  int relu, hipStream_t s);
 int affine_to_linear(const float* x, int64_t n, int64_t d, float* out, int64_t ldo, hipStream_t s);
 int linear_to_affine(const float* y, int64_t ldy, int64_t n, int64_t d, float* out, float* maxdev, hipStream_t s);
+// Processing order for rows of a sparse pattern (host): breadth-first balls of `patch` rows over "shares a column", seeded along
+// a global breadth-first sweep.  Columns referenced by more than `max_degree` of the rows (a bias column) do not link rows.
+std::vector<int32_t> locality_order(const std::vector<int32_t>& row_ids, const int32_t* indptr, const int32_t* indices, int64_t n_cols, int patch,
+                                    int max_degree);
 void csr_free(CsrDev& c);
 void convtaps_free(ConvTapsDev& c);
 
