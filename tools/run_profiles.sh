@@ -1,0 +1,23 @@
+#!/bin/bash
+# Produces the raw material of profiles/rNN_* on a GPU box (run through gpurun), then tools/make_profiles.py condenses it:
+#   gpurun --timeout 2400 -- 'bash tools/run_profiles.sh gpurun_out/r1e'
+#   python3 tools/make_profiles.py gpurun_out/r1e r01
+# Counter passes are separate runs with --kernel-trace only (never combined with sys/runtime traces).
+set -u
+R=${1:-gpurun_out/prof}
+REPO=$(pwd)
+mkdir -p "$REPO/$R"
+R="$REPO/$R"
+export TMPDIR=/tmp
+python3 bench.py --steps 5 --warmup 2 > "$R/bench.json" 2> "$R/bench.log"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$R/stats_bench.json" 2> "$R/stats_bench.log"
+PMC_BENCH="--steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/pmc_fetch" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_fetch.json" 2> "$R/pmc_fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/pmc_write" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_write.json" 2> "$R/pmc_write.log"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d "$R/pmc_mfma" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_mfma.json" 2> "$R/pmc_mfma.log"
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$R/pmc_l2" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_l2.json" 2> "$R/pmc_l2.log"
+cd "$REPO"
+# keep the merge-back small: the per-dispatch traces are large, the condensed CSVs are what make_profiles reads
+find "$R" -name '*.csv' -size +40M -delete
+ls -la "$R" "$R"/*/* | head -60
