@@ -13,7 +13,9 @@ forward) and the step ends with ONE RCCL all-gather of the logits.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (convtaps_mfma_kernel, f32 MFMA bound: SURVEY 8d);
 `cpu_baseline` is the CPU oracle (oracle/: C restatement of scipy's csr_matvecs, 1 thread as the reference runs it) timed
-on a bounded sample of the same workload and extrapolated by non-zeros (labelled).
+on a bounded sample of the same workload and extrapolated by non-zeros (labelled).  `parity` is this run's own gate: the
+logits of the timed batch's first images against the source network in plain torch f32 (the reference's criterion, atol 1e-3);
+a run that fails it raises instead of printing a number.
 """
 import argparse
 import json
@@ -46,7 +48,7 @@ def log(*a):
 
 
 def build_workload(name, rank, world, exact=None):
-    """(sensor, knet, inshape, per_gpu_batch, description).  Deterministic under the seeds, identical on every rank."""
+    """(sensor, knet, inshape, per_gpu_batch, description, source network).  Deterministic under the seeds, identical on every rank."""
     t0 = time.time()
     if name == 'vgg16':
         torch.manual_seed(0)
@@ -69,7 +71,7 @@ def build_workload(name, rank, world, exact=None):
     else:
         raise ValueError('unknown workload "%s"' % name)
     log('[bench rank %d] keyed %s on the host in %.1f s' % (rank, name, time.time() - t0))
-    return (sensor, knet, inshape, batch, desc)
+    return (sensor, knet, inshape, batch, desc, net)
 
 
 def _takes_small_k_kernel(W, batch):
@@ -266,7 +268,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
     assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world)
 
-    (sensor, knet, inshape, batch, desc) = build_workload(args.workload, rank, world, exact=True if args.exact else None)
+    (sensor, knet, inshape, batch, desc, net) = build_workload(args.workload, rank, world, exact=True if args.exact else None)
     if args.exact:
         desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
     batch = args.batch if args.batch is not None else batch
@@ -275,6 +277,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn((batch,) + tuple(inshape), generator=g, device=dev)
     x_cipher = sensor.fromtensor(x).encrypt().astensor()        # [B, D0+1] view of a feature-major block
+    # parity gate of this run: the reference's own integration criterion (test/test_keynet.py:94,112) -- keyed logits
+    # equal the source network's on the same plain images -- evaluated on the first images of the timed batch, plain torch f32 on the host
+    n_gate = min(4, batch)
+    with torch.no_grad():
+        y_plain = net(x[:n_gate].cpu()).reshape(n_gate, -1) if rank == 0 else None
     del x
     t0 = time.time()
     y = knet.forward_linear(x_cipher)                            # first call uploads the operators
@@ -308,6 +315,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape[0] == batch * world and bool(torch.isfinite(out).all())
+    parity = None
+    if rank == 0:
+        err = float((out[:n_gate].cpu() - y_plain).abs().max())
+        parity = {'check': 'keyed logits of the timed batch vs the source network (torch f32, host) on %d images' % n_gate, 'max_abs_err': err,
+                  'max_abs_logit': float(y_plain.abs().max()), 'err_over_max_logit': err / max(float(y_plain.abs().max()), 1e-30), 'atol': 1e-3,
+                  'ok': bool(err <= 1e-3)}
+        if not parity['ok']:
+            raise AssertionError('parity gate failed: %s' % json.dumps(parity))
 
     if rank == 0:
         table = layer_table(knet, batch)
@@ -338,7 +353,7 @@ def main():
             'config': {'workload': desc, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
                        'parallelism': 'batch shards x%d, all_gather(logits)' % world if world > 1 else 'single GPU'},
             'achieved_hbm_gbs_algorithmic': total_bytes / (ms_per_step * 1e6), 'achieved_tflops_algorithmic': 2.0 * nnz_img * batch / (ms_per_step * 1e9),
-            'roofline': roof,
+            'roofline': roof, 'parity': parity,
         }
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(knet, nnz_img)
