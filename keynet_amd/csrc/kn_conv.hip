@@ -48,12 +48,13 @@ struct ConvArgs {
     int32_t n_vecs, relu, unit_coef, vec_ok;
     int32_t n_mt, n_bt, n_pix, max_slots, ntaps, wide_store;
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
+    int32_t tail_main;     // work items per XCD chunk computed as full tiles; the rest of the chunk runs as 4 quarter tiles each
 };
 
 // FAST = (batch 16-byte aligned and a multiple of the batch tile NB) && (all coefficients 1: identity / permutation keys) && (Cin % KC == 0):
 // the loaders are straight-line code, so the next chunk's global loads stay in flight in registers during the MFMAs.
 template <int MT, int NB, int KC, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
+__device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int o, const int m0, const int b0, float* lds) {
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     constexpr int TM = MT / WM / 32;
     constexpr int TN = NB / WN / 32;
@@ -63,25 +64,11 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     constexpr int BL = (B4 + 255) / 256;
     constexpr int LS_AT = (KC >= 8) ? KC / 2 - 2 : 0;   // k-step at which chunk q+1 is written to LDS ...
     constexpr int GL_AT = KC / 2;                        // ... and the one at which chunk q+2's global loads are issued
-    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 2 * MAX_FAST_SLOTS];
     float* As = lds;                  // [2][KC][MT]
     float* Bs = lds + 2 * KC * MT;    // [2][KC][NB]
     int32_t* s_aoff = reinterpret_cast<int32_t*>(lds + 2 * KC * MT + 2 * KC * NB);   // FAST: per-slot tap offset (elements)
     int32_t* s_boff = s_aoff + MAX_FAST_SLOTS;                                       //       per-slot input-pixel row offset
 
-    // ---- work item ------------------------------------------------------------------------------------------
-    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
-    const int64_t chunk = (n_items + 7) >> 3;
-    const int64_t xl = blockIdx.x & 7;
-    const int64_t item = xl * chunk + (blockIdx.x >> 3);
-    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
-    const int mt = (int)(item % p.n_mt);
-    const int64_t t1 = item / p.n_mt;
-    const int pi = (int)(t1 % p.n_pix);
-    const int bt = (int)(t1 / p.n_pix);
-    const int o = p.pix_order[pi];
-    const int m0 = mt * MT;
-    const int b0 = bt * NB;
     const int s_beg = p.pix_ptr[o];
     const int n_slots = p.pix_ptr[o + 1] - s_beg;
     const int cpk = p.cin_pad / KC;
@@ -346,6 +333,40 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     }
 }
 
+
+// Work items (output pixel, batch tile, Cout tile) are dealt to the 8 XCDs in contiguous chunks (blockIdx & 7 labels the XCD), Cout tile
+// fastest.  TAIL: the items of a chunk beyond `tail_main` -- the last, partial round of resident workgroups -- are computed as four
+// quarter tiles (MT/2 x NB/2) by four workgroups instead of one: a lone 128x128 workgroup on an otherwise idle CU runs at ~60 % of
+// the matrix pipe for a full tile time while most CUs wait, the quarter tiles finish in about a third of that.  Same K order and MFMA
+// shape per output element, so the result is bit-identical to the unsplit launch.
+template <int MT, int NB, int KC, int WM, int WN, bool FAST, bool TAIL>
+__global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 2 * MAX_FAST_SLOTS];
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    int64_t item = xl * chunk + q;
+    int quad = -1;
+    if (TAIL && q >= p.tail_main) {
+        const int64_t t = q - p.tail_main;
+        item = xl * chunk + p.tail_main + (t >> 2);
+        quad = (int)(t & 3);
+    }
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    const int mt = (int)(item % p.n_mt);
+    const int64_t t1 = item / p.n_mt;
+    const int pi = (int)(t1 % p.n_pix);
+    const int bt = (int)(t1 / p.n_pix);
+    const int o = p.pix_order[pi];
+    if constexpr (TAIL) {
+        if (quad >= 0) {
+            convtaps_mfma_tile<MT / 2, NB / 2, KC, WM, WN, FAST>(p, o, mt * MT + (quad & 1) * (MT / 2), bt * NB + (quad >> 1) * (NB / 2), lds);
+            return;
+        }
+    }
+    convtaps_mfma_tile<MT, NB, KC, WM, WN, FAST>(p, o, mt * MT, bt * NB, lds);
+}
 
 // ---- one-shot small-K path -----------------------------------------------------------------------------------------------
 // First layer of an image network (VGG conv1_1: Cin = 3, 9 taps): the whole contraction of one output pixel is
@@ -720,14 +741,40 @@ void convtaps_free(ConvTapsDev& c) {
     c = ConvTapsDev();
 }
 
+// resident workgroups per XCD for a kernel (occupancy x CUs of one XCD), cached per instantiation
+template <typename K>
+static int64_t xcd_slots(K kernel) {
+    int occ = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess || occ <= 0)
+        return 0;
+    return (int64_t)occ * (prop.multiProcessorCount / 8);
+}
+
 template <int MT, int NB, int KC, int WM, int WN>
-static void launch_conv(const ConvArgs& a, hipStream_t s) {
+static void launch_conv(ConvArgs a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
-    const int64_t grid = ((items + 7) / 8) * 8;
+    const int64_t chunk = (items + 7) / 8;
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
-    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    a.tail_main = (int32_t)chunk;
+    if constexpr (MT == 128 && NB == 128 && KC == 16) {
+        static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
+        if (fast && a.wide_store && !no_tail) {
+            static const int64_t slots = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>);
+            const int64_t rem = slots > 0 ? chunk % slots : 0;
+            if (rem > 0) {   // the last, partial round of resident workgroups (measured: pays even when it fills half the machine)
+                a.tail_main = (int32_t)(chunk - rem);
+                const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
+                hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                return;
+            }
+        }
+    }
+    const int64_t grid = 8 * chunk;
+    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
