@@ -90,18 +90,21 @@ def layer_table(knet, batch):
     for (i, (name, c)) in enumerate(children):
         if not isinstance(c, KeyedLayer):
             continue
-        op = c.W._device_op()
-        (r, cdim) = op.shape()
-        nnz_exp = op.nnz_expanded()
-        if isinstance(c.W, ksp.Conv2dTiledMatrix):
-            kind = 'smallk' if (_takes_small_k_kernel(c.W, batch) and not getattr(c, '_exact', False)) else 'convtaps'
-            wbytes = 4 * c.W.nnz()            # taps + entries + last column actually read
-        elif type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
-            kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
+        if type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
+            kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode); its CSR twin is never built
+            (r, cdim) = c.W.shape
+            nnz_exp = int(c.W.nnz())
             wbytes = 4 * r * cdim
         else:
-            kind = 'csr'
-            wbytes = 8 * nnz_exp               # (col,val) per non-zero
+            op = c.W._device_op()
+            (r, cdim) = op.shape()
+            nnz_exp = op.nnz_expanded()
+            if isinstance(c.W, ksp.Conv2dTiledMatrix):
+                kind = 'smallk' if (_takes_small_k_kernel(c.W, batch) and not getattr(c, '_exact', False)) else 'convtaps'
+                wbytes = 4 * c.W.nnz()        # taps + entries + last column actually read
+            else:
+                kind = 'csr'
+                wbytes = 8 * nnz_exp           # (col,val) per non-zero
         rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch,
                          bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c,
                          fuse=(i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)))
@@ -317,7 +320,7 @@ def main():
     assert out.shape[0] == batch * world and bool(torch.isfinite(out).all())
     parity = None
     if rank == 0:
-        err = float((out[:n_gate].cpu() - y_plain).abs().max())
+        err = float((out[:n_gate].contiguous().cpu() - y_plain).abs().max())   # contiguous first: a strided D2H copy is ~1500 tiny copies
         parity = {'check': 'keyed logits of the timed batch vs the source network (torch f32, host) on %d images' % n_gate, 'max_abs_err': err,
                   'max_abs_logit': float(y_plain.abs().max()), 'err_over_max_logit': err / max(float(y_plain.abs().max()), 1e-30), 'atol': 1e-3,
                   'ok': bool(err <= 1e-3)}
