@@ -182,29 +182,36 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
         for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
 
     // U columns per step; the next step's U gathers are issued before this step's arithmetic (a dense Linear is ONE
-    // group of ~500 bundles, i.e. 1-2 wavefronts per SIMD: latency must be hidden inside the wavefront).
-    constexpr int U = (VEC == 4) ? 4 : 8;
+    // group of ~500 bundles, i.e. 1-2 wavefronts per SIMD: latency must be hidden inside the wavefront).  Thin bundles
+    // (RBK <= 2: a 121-row Linear walking 785 columns) have registers to spare: 16/VEC gathers in flight.
+    constexpr int U = (RBK <= 2) ? 16 / VEC : ((VEC == 4) ? 4 : 8);
     int j = 0;
     float xcur[U][VEC], xnxt[U][VEC];
     if (ncol >= U) {
 #pragma unroll
         for (int u = 0; u < U; u++) load_vec<VEC>(xcur[u], xc + (int64_t)cols[u] * ldx);
     }
-#pragma unroll 2
     for (; j + U <= ncol; j += U) {
         if (j + 2 * U <= ncol) {
 #pragma unroll
             for (int u = 0; u < U; u++) load_vec<VEC>(xnxt[u], xc + (int64_t)cols[j + U + u] * ldx);
         }
+        // the step's U x RBK values first (wave-uniform scalar loads, ONE wait for all of them), then the ordered arithmetic
+        float av[U][RBK];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const float* a = vals + (int64_t)(j + u) * rpad;   // wave-uniform: scalar loads
+            const float* a = vals + (int64_t)(j + u) * rpad;
+#pragma unroll
+            for (int r = 0; r < RBK; r++) av[u][r] = a[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
 #pragma unroll
             for (int r = 0; r < RBK; r++) {
-                const float ar = a[r];
 #pragma unroll
                 for (int v = 0; v < VEC; v++) {
-                    const float p = ar * xcur[u][v];
+                    const float p = av[u][r] * xcur[u][v];
                     acc[r][v] = acc[r][v] + p;
                 }
             }
