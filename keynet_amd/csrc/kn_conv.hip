@@ -66,8 +66,8 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     constexpr int GL_AT = KC / 2;                        // ... and the one at which chunk q+2's global loads are issued
     float* As = lds;                  // [2][KC][MT]
     float* Bs = lds + 2 * KC * MT;    // [2][KC][NB]
-    int32_t* s_aoff = reinterpret_cast<int32_t*>(lds + 2 * KC * MT + 2 * KC * NB);   // FAST: per-slot tap offset (elements)
-    int32_t* s_boff = s_aoff + MAX_FAST_SLOTS;                                       //       per-slot input-pixel row offset
+    int64_t* s_da = reinterpret_cast<int64_t*>(lds + 2 * KC * MT + 2 * KC * NB);     // FAST: per-slot byte delta to the next chunk's tap tile
+    int64_t* s_db = s_da + MAX_FAST_SLOTS;                                           //       ... and to its activation tile
 
     const int s_beg = p.pix_ptr[o];
     const int n_slots = p.pix_ptr[o + 1] - s_beg;
@@ -166,30 +166,48 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     // so the second use hits the XCD's L2 instead of going back to the fabric.
     const int64_t a_step = (int64_t)KC * p.cout_pad;
     const int64_t b_step = (int64_t)KC * p.HiWi * p.ldx;
-    const float* a_base = p.tapsT + m0;
-    const float* b_base = p.X + b0;
     int f_slot = 0;
+    // FAST: every thread walks its own tile pointers.  The LDS table holds, per slot, the BYTE DELTA from this slot's tiles to
+    // the next chunk's (next slot of the pixel, or slot 0 of the next channel chunk after the last one), so advancing is one
+    // 64-bit add per load and the chunk loop carries no slot-offset / base-pointer arithmetic at all.
+    const char* pa[AL];
+    const char* pb[BL];
+    int64_t da = 0, db = 0;
     if constexpr (FAST) {
         if (tid < n_slots) {
-            s_aoff[tid] = p.slot_tap[s_beg + tid] * p.cin_pad * p.cout_pad;
-            s_boff[tid] = p.slot_in[s_beg + tid] * (int32_t)p.ldx;
+            const int nxt = (tid + 1 < n_slots) ? tid + 1 : 0;
+            const int64_t wrap_a = (tid + 1 < n_slots) ? 0 : a_step, wrap_b = (tid + 1 < n_slots) ? 0 : b_step;
+            s_da[tid] = 4 * ((int64_t)(p.slot_tap[s_beg + nxt] - p.slot_tap[s_beg + tid]) * p.cin_pad * p.cout_pad + wrap_a);
+            s_db[tid] = 4 * ((int64_t)(p.slot_in[s_beg + nxt] - p.slot_in[s_beg + tid]) * p.ldx + wrap_b);
+        }
+        if (n_slots > 0) {
+            const char* a0 = reinterpret_cast<const char*>(p.tapsT + m0 + (int64_t)p.slot_tap[s_beg] * p.cin_pad * p.cout_pad);
+            const char* b0p = reinterpret_cast<const char*>(p.X + b0 + (int64_t)p.slot_in[s_beg] * p.ldx);
+#pragma unroll
+            for (int i = 0; i < AL; i++) pa[i] = a0 + 4 * (int64_t)a_off[i];
+#pragma unroll
+            for (int i = 0; i < BL; i++) pb[i] = b0p + 4 * (int64_t)b_off[i];
         }
         __syncthreads();
+        if (n_slots > 0) {
+            da = s_da[0];
+            db = s_db[0];
+        }
     }
     auto gload_fast = [&]() {
-        const float* a_ptr = a_base + s_aoff[f_slot];
-        const float* b_ptr = b_base + s_boff[f_slot];
 #pragma unroll
         for (int i = 0; i < AL; i++)
-            if (A4 % 256 == 0 || tid + i * 256 < A4) ra[i] = *reinterpret_cast<const f32x4*>(a_ptr + a_off[i]);
+            if (A4 % 256 == 0 || tid + i * 256 < A4) ra[i] = *reinterpret_cast<const f32x4*>(pa[i]);
 #pragma unroll
         for (int i = 0; i < BL; i++)
-            if (B4 % 256 == 0 || tid + i * 256 < B4) rb[i] = *reinterpret_cast<const f32x4*>(b_ptr + b_off[i]);
-        if (++f_slot == n_slots) {
-            f_slot = 0;
-            a_base += a_step;
-            b_base += b_step;
-        }
+            if (B4 % 256 == 0 || tid + i * 256 < B4) rb[i] = *reinterpret_cast<const f32x4*>(pb[i]);
+#pragma unroll
+        for (int i = 0; i < AL; i++) pa[i] += da;
+#pragma unroll
+        for (int i = 0; i < BL; i++) pb[i] += db;
+        f_slot = (f_slot + 1 == n_slots) ? 0 : f_slot + 1;
+        da = s_da[f_slot];      // for the NEXT call: the LDS read has a whole chunk to complete
+        db = s_db[f_slot];
     };
     auto LOAD = [&](int q) {
         if constexpr (FAST) gload_fast();     // chunks are requested strictly in order 0,1,2,...
@@ -360,7 +378,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 // shape per output element, so the result is bit-identical to the unsplit launch.
 template <int MT, int NB, int KC, int WM, int WN, bool FAST, bool TAIL>
 __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 2 * MAX_FAST_SLOTS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS];
     const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
     const int64_t chunk = (n_items + 7) >> 3;
     const int64_t xl = blockIdx.x & 7;
