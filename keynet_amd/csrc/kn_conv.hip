@@ -16,6 +16,7 @@
 // Work items (pixel, batch tile, Cout tile) are dealt to the 8 XCDs in contiguous chunks with the Cout tile fastest,
 // so the workgroups that share one gathered X tile run on one XCD and hit its L2.
 #include "kn_internal.h"
+#include <type_traits>
 
 namespace kn {
 
@@ -262,8 +263,10 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     const int acol = wm * 32 + (lane & 31);       // permuted tile columns (see lstore)
     const int bcol = wn * 32 + (lane & 31);
     constexpr int AS = WM * 32, BS = WN * 32;     // distance of a wavefront's sub-tile fragments
-    for (int q = 0; q < n_chunks; q++) {
-        const int buf = q & 1;
+    // One chunk; the LDS buffer index is a compile-time constant (the loop below is unrolled by two), so tile addresses are
+    // one per-thread base register plus immediates for both buffers.
+    auto chunk = [&](const int q, auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
         const float* a = As + buf * KC * MT;
         const float* b = Bs + buf * KC * NB;
         // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk execute (register double buffer)
@@ -293,6 +296,14 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+    {
+        int q = 0;
+        for (; q + 1 < n_chunks; q += 2) {
+            chunk(q, std::integral_constant<int, 0>{});
+            chunk(q + 1, std::integral_constant<int, 1>{});
+        }
+        if (q < n_chunks) chunk(q, std::integral_constant<int, 0>{});
     }
 
     // ---- epilogue: bias column (x homogeneous coordinate), ReLU, store --------------------------------------
