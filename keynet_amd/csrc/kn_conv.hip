@@ -206,7 +206,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         for (int i = 0; i < AL; i++) pa[i] += da;
 #pragma unroll
         for (int i = 0; i < BL; i++) pb[i] += db;
-        f_slot = (f_slot + 1 == n_slots) ? 0 : f_slot + 1;
+        f_slot = __builtin_amdgcn_readfirstlane((f_slot + 1 == n_slots) ? 0 : f_slot + 1);   // scalar ALU, not 4 VALU ops
         da = s_da[f_slot];      // for the NEXT call: the LDS read has a whole chunk to complete
         db = s_db[f_slot];
     };
