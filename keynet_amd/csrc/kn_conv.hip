@@ -348,7 +348,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
                             v.z = (v.z < 0.0f) ? 0.0f : v.z;
                             v.w = (v.w < 0.0f) ? 0.0f : v.w;
                         }
-                        *reinterpret_cast<f32x4*>(p.Y + row * p.ldy + ncol) = v;
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.Y + row * p.ldy + ncol));   // streamed past L2: not re-read by this launch; multi-GB layers (measured: small-K kernel 1.15 -> 0.88 ms; the L2-resident nets on the CSR kernels lose with it)
                     }
                 }
                 kn_wave_sync();
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
                         v.z = (v.z < 0.0f) ? 0.0f : v.z;
                         v.w = (v.w < 0.0f) ? 0.0f : v.w;
                     }
-                    *reinterpret_cast<f32x4*>(p.Y + ((int64_t)m * p.HoWo + o) * p.ldy + ncol) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.Y + ((int64_t)m * p.HoWo + o) * p.ldy + ncol));
                 }
             }
             kn_wave_sync();
