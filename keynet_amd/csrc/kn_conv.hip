@@ -34,6 +34,48 @@ __device__ __forceinline__ void kn_wave_sync() {
 // Ordering point for the machine scheduler (holds inside one basic block).
 __device__ __forceinline__ void kn_order() { __builtin_amdgcn_sched_barrier(0); }
 
+// Wide store of a wavefront's (TM*32) x (TN*32) accumulator sub-tile.  An accumulator register holds one output row per 32-lane
+// half (4 bytes per lane), so storing it directly would cost 64 scalar stores per lane.  Instead the wavefront transposes 8 rows
+// at a time through its own LDS slice `stage` ([8][TN*32] floats; private, and a wavefront's LDS operations execute in order) and
+// streams 16 bytes per lane: whole row segments, nontemporal (the output is not re-read by this launch).  `yp` is this lane's
+// pointer into the first row it stores (sub-tile row `lane / (TN*8)`); the rows a lane visits are a constant RPI apart, so the
+// address is ONE running pointer plus a wave-uniform byte step -- no per-store 64-bit multiplies.  `rows_ok` (wave-uniform) says
+// that every row of the sub-tile exists (< Cout): the per-row test disappears for channel counts that fill the tile.
+template <int TM, int TN>
+__device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float* stage, const int lane, float* yp, const int64_t row_step_bytes,
+                                              const int m_first, const int Cout, const bool rows_ok, const int relu) {
+    constexpr int COLS = TN * 32;                 // columns of this wave's sub-tile
+    constexpr int LPR = COLS / 4;                 // lanes per row (16 B each)
+    constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+    const int rl = lane / LPR, c4 = lane % LPR;
+    char* ypb = reinterpret_cast<char*>(yp);
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {             // rows 8g .. 8g+7 of the 32-row MFMA tile i
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
+            kn_wave_sync();
+#pragma unroll
+            for (int h = 0; h < 8 / RPI; h++) {
+                const int rloc = rl + h * RPI;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
+                if (relu) {
+                    v.x = (v.x < 0.0f) ? 0.0f : v.x;
+                    v.y = (v.y < 0.0f) ? 0.0f : v.y;
+                    v.z = (v.z < 0.0f) ? 0.0f : v.z;
+                    v.w = (v.w < 0.0f) ? 0.0f : v.w;
+                }
+                if (rows_ok || m_first + i * 32 + 8 * g + rloc < Cout) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ypb));
+                ypb += row_step_bytes;            // next visited row: RPI rows further (also across g and i: 8 and 32 are multiples of RPI steps)
+            }
+            kn_wave_sync();
+        }
+    }
+}
+
 struct ConvArgs {
     const float* tapsT;
     const int32_t* pix_ptr;
@@ -258,6 +300,27 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         lstore(0);
     }
     if (n_chunks > 1) LOAD(1);
+    // Bias column x homogeneous coordinate = one more rank-1 term of the product: staged as a 2-row chunk (row 1 zero) in its
+    // own LDS area and accumulated by ONE MFMA k-step after the chunk loop -- instead of a scalar load, 8 multiplies and 8 adds
+    // per stored row segment in the epilogue.
+    float* bias_a = reinterpret_cast<float*>(s_db + MAX_FAST_SLOTS);   // [2][MT], columns permuted like the tiles
+    float* bias_b = bias_a + 2 * MT;                                   // [2][NB]
+    if (p.lastcol) {
+        const float* xlast = p.X + p.last_in_row * p.ldx;
+        for (int t = tid; t < MT + NB; t += 256) {
+            if (t < MT) {
+                const int c = t, m = m0 + c;
+                const int pc = ((c / 32) % TM) * (WM * 32) + (c / (TM * 32)) * 32 + (c % 32);
+                bias_a[pc] = (m < p.Cout) ? p.lastcol[(int64_t)m * p.HoWo + o] : 0.0f;
+                bias_a[MT + pc] = 0.0f;
+            } else {
+                const int c = t - MT, n = b0 + c;
+                const int pc = ((c / 32) % TN) * (WN * 32) + (c / (TN * 32)) * 32 + (c % 32);
+                bias_b[pc] = (n < p.n_vecs) ? xlast[n] : 0.0f;
+                bias_b[NB + pc] = 0.0f;
+            }
+        }
+    }
     __syncthreads();
     const int arow = lane >> 5;
     const int acol = wm * 32 + (lane & 31);       // permuted tile columns (see lstore)
@@ -306,75 +369,42 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         if (q < n_chunks) chunk(q, std::integral_constant<int, 0>{});
     }
 
-    // ---- epilogue: bias column (x homogeneous coordinate), ReLU, store --------------------------------------
-    const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx) : nullptr;
+    // bias term LAST, like the reference's row order (its rows stayed in their own LDS area since the prologue)
+    if (p.lastcol) {
+        float ab[TM], bb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) ab[i] = bias_a[arow * MT + acol + i * AS];
+#pragma unroll
+        for (int j = 0; j < TN; j++) bb[j] = bias_b[arow * NB + bcol + j * BS];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    // ---- epilogue: ReLU, store (the bias term is already in the accumulators) ------------------------------------
+    const int m_first = m0 + wm * (TM * 32);
     if (p.wide_store && b0 + NB <= p.n_vecs) {
-        // Wide path: an accumulator register holds one output row per 32-lane half (4 bytes per lane), so storing it
-        // directly costs 64 scalar stores per lane.  Instead each wavefront transposes 8 rows x (TN*32) columns at a time
-        // through its own 2 KiB slice of the now idle tile buffers and writes 16 bytes per lane: whole 128*TN-byte row
-        // segments, 4x fewer store instructions (the stores, not the bandwidth, bound the short-K layers).
-        constexpr int COLS = TN * 32;                 // columns of this wave's sub-tile
-        constexpr int LPR = COLS / 4;                 // lanes per row (16 B each)
-        constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
+        constexpr int COLS = TN * 32;
+        constexpr int LPR = COLS / 4;
         float* stage = lds + wave * (8 * COLS);       // [8 rows][COLS]  (all tile reads are behind the last barrier)
-        const int rl = lane / LPR, c4 = lane % LPR;
-        const int ncol = b0 + wn * COLS + c4 * 4;
-        f32x4 xl4 = {0.f, 0.f, 0.f, 0.f};
-        if (xlast) xl4 = *reinterpret_cast<const f32x4*>(xlast + ncol);
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-#pragma unroll
-            for (int g = 0; g < 4; g++) {             // rows 8g .. 8g+7 of the 32-row MFMA tile i
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-#pragma unroll
-                    for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
-                kn_wave_sync();   // the slice is private to this wavefront and a wavefront's LDS operations execute in order
-#pragma unroll
-                for (int h = 0; h < 8 / RPI; h++) {
-                    const int rloc = rl + h * RPI;
-                    const int m = m0 + wm * (TM * 32) + i * 32 + 8 * g + rloc;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
-                    if (m < p.Cout) {
-                        const int64_t row = (int64_t)m * p.HoWo + o;
-                        if (xlast) {
-                            const float lc = p.lastcol[row];
-                            const f32x4 bp = xl4 * lc;
-                            v = v + bp;
-                        }
-                        if (p.relu) {
-                            v.x = (v.x < 0.0f) ? 0.0f : v.x;
-                            v.y = (v.y < 0.0f) ? 0.0f : v.y;
-                            v.z = (v.z < 0.0f) ? 0.0f : v.z;
-                            v.w = (v.w < 0.0f) ? 0.0f : v.w;
-                        }
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.Y + row * p.ldy + ncol));   // streamed past L2: not re-read by this launch; multi-GB layers (measured: small-K kernel 1.15 -> 0.88 ms; the L2-resident nets on the CSR kernels lose with it)
-                    }
-                }
-                kn_wave_sync();
-            }
-        }
+        float* yp = p.Y + ((int64_t)(m_first + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wn * COLS + (lane % LPR) * 4);
+        const int64_t row_step_bytes = (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4;
+        kn_store_tile<TM, TN>(acc, stage, lane, yp, row_step_bytes, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu);
         return;
     }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = b0 + wn * (TN * 32) + j * 32 + (lane & 31);
         if (n >= p.n_vecs) continue;
-        const float xl1 = xlast ? xlast[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m_first + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (m < p.Cout) {
-                    const int64_t row = (int64_t)m * p.HoWo + o;
                     float v = acc[i][j][r];
-                    if (xlast) {
-                        const float bp = p.lastcol[row] * xl1;
-                        v = v + bp;
-                    }
                     if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-                    p.Y[row * p.ldy + n] = v;
+                    p.Y[((int64_t)m * p.HoWo + o) * p.ldy + n] = v;
                 }
             }
         }
@@ -389,7 +419,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 // shape per output element, so the result is bit-identical to the unsplit launch.
 template <int MT, int NB, int KC, int WM, int WN, bool FAST, bool TAIL>
 __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS];
+    __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS + 2 * (MT + NB)];
     const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
     const int64_t chunk = (n_items + 7) >> 3;
     const int64_t xl = blockIdx.x & 7;
@@ -518,37 +548,9 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
 
     constexpr int COLS = TN * 32;
     constexpr int LPR = COLS / 4;
-    constexpr int RPI = 64 / LPR;
     float* stage = lds + wave * (8 * COLS);
-    const int rl = lane / LPR, c4 = lane % LPR;
-    const int ncol = b0 + wave * COLS + c4 * 4;
-#pragma unroll
-    for (int i = 0; i < TM; i++) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) stage[(rr + 4 * (lane >> 5)) * COLS + j * 32 + (lane & 31)] = acc[i][j][4 * g + rr];
-            kn_wave_sync();
-#pragma unroll
-            for (int h = 0; h < 8 / RPI; h++) {
-                const int rloc = rl + h * RPI;
-                const int m = m0 + i * 32 + 8 * g + rloc;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
-                if (m < p.Cout) {
-                    if (p.relu) {
-                        v.x = (v.x < 0.0f) ? 0.0f : v.x;
-                        v.y = (v.y < 0.0f) ? 0.0f : v.y;
-                        v.z = (v.z < 0.0f) ? 0.0f : v.z;
-                        v.w = (v.w < 0.0f) ? 0.0f : v.w;
-                    }
-                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p.Y + ((int64_t)m * p.HoWo + o) * p.ldy + ncol));
-                }
-            }
-            kn_wave_sync();
-        }
-    }
+    float* yp = p.Y + ((int64_t)(m0 + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wave * COLS + (lane % LPR) * 4);
+    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m0, p.Cout, m0 + TM * 32 <= p.Cout, p.relu);
 }
 
 // ---- order-preserving path on the factored operator (KN_FLAG_EXACT) ------------------------------------------------
