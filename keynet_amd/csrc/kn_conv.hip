@@ -721,11 +721,22 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             ci_x = __builtin_amdgcn_readfirstlane(ci_x + ((more && wrap) ? ch_x : 0));
             ci_a = __builtin_amdgcn_readfirstlane(ci_a + ((more && wrap) ? p.cout_pad : 0));
         };
+        // acc[r] += x * av[r] (separate IEEE multiply and add).  The tap values sit in SGPR pairs; the packed multiply reads the
+        // pair directly and broadcasts its low or high half with op_sel -- the compiler would copy every odd value into a fresh
+        // aligned pair first (s_mov + hazard s_nop per value).
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
         auto mac = [&](const f32x4& xv, const float (&av)[RBX]) {
+            const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
 #pragma unroll
-            for (int r = 0; r < RBX; r++) {
-                const f32x4 pr = xv * av[r];
-                acc[r] = acc[r] + pr;
+            for (int r = 0; r < RBX; r += 2) {
+                const f32x2 a2 = {av[r], av[r + 1]};
+                f32x2 p0l, p0h, p1l, p1h;
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p0l) : "v"(xlo), "s"(a2));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p0h) : "v"(xhi), "s"(a2));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p1l) : "v"(xlo), "s"(a2));
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p1h) : "v"(xhi), "s"(a2));
+                acc[r] = acc[r] + f32x4{p0l.x, p0l.y, p0h.x, p0h.y};
+                acc[r + 1] = acc[r + 1] + f32x4{p1l.x, p1l.y, p1h.x, p1h.y};
             }
         };
         f32x4 x0, x1;
