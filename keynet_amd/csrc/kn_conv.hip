@@ -10,11 +10,16 @@
 // Per workgroup (4 wavefronts): the tap tile [KC][MT] and the gathered X tile [KC][NB] are staged in LDS (double
 // buffered, one barrier per chunk; 3-stage software pipeline: chunk q in LDS, chunk q+1 in registers and written to the
 // other LDS buffer mid-chunk, chunk q+2's global loads issued right after); each wavefront owns a
-// (TM*32)x(TN*32) sub-tile as TMxTN accumulators of v_mfma_f32_32x32x2_f32; A/B fragments are conflict-free
-// ds_read_b32 (lane&31 -> consecutive dwords, lane>>5 -> k).  Epilogue fuses the bias column (homogeneous coordinate),
-// ReLU and the store (each accumulator register = two coalesced 128-byte row segments).
+// (TM*32)x(TN*32) sub-tile as TMxTN accumulators of v_mfma_f32_32x32x2_f32; A/B fragments are conflict-free LDS reads
+// (lane&31 -> consecutive dwords, lane>>5 -> k) at base-register + immediate addresses (permuted tile columns, chunk loop
+// unrolled by two).  The chunk loop is kept almost free of VALU work (5 instructions per 32 MFMAs): VALU issue competes with
+// MFMA issue on a SIMD.  The bias column (homogeneous coordinate) is one extra MFMA k-step; the epilogue applies ReLU and
+// streams the tile out 16 bytes per lane through a per-wavefront LDS transposition (kn_store_tile).
 // Work items (pixel, batch tile, Cout tile) are dealt to the 8 XCDs in contiguous chunks with the Cout tile fastest,
-// so the workgroups that share one gathered X tile run on one XCD and hit its L2.
+// so the workgroups that share one gathered X tile run on one XCD and hit its L2; the last partial round of workgroups is
+// split into quarter tiles (TAIL).  Other kernels in this file: convtaps_smallk_kernel (first layer of an image net: whole
+// contraction <= 28 rows, write-bound), convtaps_exact_pipe_kernel / convtaps_exact_kernel (KN_FLAG_EXACT: the reference's
+// accumulation order and rounding on the VALU, bit-exact), conv_lastrow_kernel (homogeneous output row).
 #include "kn_internal.h"
 #include <type_traits>
 
