@@ -333,16 +333,20 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     constexpr int AS = WM * 32, BS = WN * 32;     // distance of a wavefront's sub-tile fragments
     // One chunk; the LDS buffer index is a compile-time constant (the loop below is unrolled by two), so tile addresses are
     // one per-thread base register plus immediates for both buffers.
+    // per-thread fragment base of each buffer in its own register: every read of a chunk is then base + a small immediate and
+    // pairs of sub-tile fragments merge into ds_read2st64_b32
+    const float* afrag[2] = {As + arow * MT + acol, As + KC * MT + arow * MT + acol};
+    const float* bfrag[2] = {Bs + arow * NB + bcol, Bs + KC * NB + arow * NB + bcol};
     auto chunk = [&](const int q, auto buf_c) {
         constexpr int buf = decltype(buf_c)::value;
-        const float* a = As + buf * KC * MT;
-        const float* b = Bs + buf * KC * NB;
+        const float* a = afrag[buf];
+        const float* b = bfrag[buf];
         // fragments of k-step kk+2 are read from LDS while the MFMAs of k-step kk execute (register double buffer)
         float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) af[0][i] = a[arow * MT + acol + i * AS];
+        for (int i = 0; i < TM; i++) af[0][i] = a[i * AS];
 #pragma unroll
-        for (int j = 0; j < TN; j++) bf[0][j] = b[arow * NB + bcol + j * BS];
+        for (int j = 0; j < TN; j++) bf[0][j] = b[j * BS];
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
             const int cur = (kk >> 1) & 1;
@@ -350,9 +354,9 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             if (kk == GL_AT && q + 2 < n_chunks) LOAD(q + 2);
             if (kk + 2 < KC) {
 #pragma unroll
-                for (int i = 0; i < TM; i++) af[cur ^ 1][i] = a[(kk + 2 + arow) * MT + acol + i * AS];
+                for (int i = 0; i < TM; i++) af[cur ^ 1][i] = a[(kk + 2) * MT + i * AS];
 #pragma unroll
-                for (int j = 0; j < TN; j++) bf[cur ^ 1][j] = b[(kk + 2 + arow) * NB + bcol + j * BS];
+                for (int j = 0; j < TN; j++) bf[cur ^ 1][j] = b[(kk + 2) * NB + j * BS];
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's MFMAs
             __builtin_amdgcn_s_setprio(1);       // matrix burst wins arbitration over the co-resident waves' VALU/LDS issue (+1 %, A-B-A-B)
