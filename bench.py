@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- keyed forward throughput on MI355X (BASELINE.json metric: encrypted images/sec + roofline, keyed VGG-16 224x224).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: starts N ranks itself, one per GPU, over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path (KeyedModel.forward_linear: all keyed layers, ReLU fused) over one batch of
@@ -11,15 +11,26 @@ Random-init weights (torch.manual_seed(0)), keys from np.random.seed(0), images 
 checkpoints or datasets).  With N GPUs every rank runs its own 256-image shard (weak scaling, no collective inside the
 forward) and the step ends with ONE RCCL all-gather of the logits.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (convtaps_mfma_kernel, f32 MFMA bound: SURVEY 8d);
-`cpu_baseline` is the CPU oracle (oracle/: C restatement of scipy's csr_matvecs, 1 thread as the reference runs it) timed
-on a bounded sample of the same workload and extrapolated by non-zeros (labelled).  `parity` is this run's own gate: the
-logits of the timed batch's first images against the source network in plain torch f32 (the reference's criterion, atol 1e-3);
-a run that fails it raises instead of printing a number.
+Rank 0 prints ONE JSON line.
+  roofline      the dominant kernel of the mode that ran: convtaps_mfma_kernel against the f32-MFMA peak (tolerance mode of the
+                tiled key-nets), the order-preserving kernels against the no-FMA VALU peak (--exact, AllConvNet), the CSR kernels
+                against HBM (LeNet).  `traffic` (HBM bytes per forward of that kernel from a separate rocprofv3 --pmc pass) is
+                quoted only when the committed pass was taken on THESE kernel sources (sha256 of keynet_amd/csrc recorded with it).
+  exact         (default vgg16 run, N=1) the SAME key-net switched to the bit-exact contract (KeyedModel.exact_mode(True): every
+                layer in the reference's accumulation order, no MFMA): images/s, ms/step, its own roofline (VALU without FMA,
+                39.3 T MAC/s) and a parity record -- bit-equality with the CPU oracle on sampled rows of real conv layers.
+  cpu_baseline  the reference's own arithmetic -- scipy.sparse.csr_matrix.dot (keynet/sparse.py:488-492) -- timed on this node's
+                host cores BEFORE the GPU is touched (the worker pool is forked from a GPU-free process): conv1_1, conv5_1, every
+                pool, fc6-8 measured directly on 1 thread and on all physical cores; the other layers extrapolated at the measured
+                ns/(nz*column) and labelled so; plus the reference-faithful tocsr()+dot of one tiled layer (keynet/sparse.py:603-612).
+  parity        this run's own gate: logits of the timed batch's first images against the source network in plain torch f32
+                (the reference's criterion, atol 1e-3); a run that fails it raises instead of printing a number.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,13 +44,12 @@ if ROOT not in sys.path:
 
 from keynet_amd import system as ksys          # noqa: E402
 from keynet_amd import sparse as ksp           # noqa: E402
-from keynet_amd import io as kio               # noqa: E402
 from keynet_amd import dist as kdist           # noqa: E402
 from keynet_amd.layer import KeyedLayer        # noqa: E402
 from keynet_amd.models import VGG16, LeNet_AvgPool, AllConvNet   # noqa: E402
-from keynet_amd.torch import affine_to_linear  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32-input MFMA = f32 vector peak)
+PEAK_VALU_NOFMA_TMACS = 39.3     # the same vector peak with separate multiply and add (bit-exact contract): 157.3 / 4 T MAC/s
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured copy)
 
 
@@ -47,7 +57,9 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(name, rank, world, exact=None):
+# ----------------------------------------------------------------------------------------------------------------------------
+# workload (host only: no GPU call in this section)
+def build_workload(name, rank, exact=None):
     """(sensor, knet, inshape, per_gpu_batch, description, source network).  Deterministic under the seeds, identical on every rank."""
     t0 = time.time()
     if name == 'vgg16':
@@ -74,6 +86,160 @@ def build_workload(name, rank, world, exact=None):
     return (sensor, knet, inshape, batch, desc, net)
 
 
+def keyed_layers(knet):
+    return [(n, c) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)]
+
+
+def host_nnz(c):
+    """nnz of the operator the reference would apply (= algorithmic MACs per image), from the host description alone."""
+    W = c.W
+    if isinstance(W, ksp.Conv2dTiledMatrix) and W._taps is not None:
+        t = W._taps
+        return int(len(t['ent_out'])) * W._outshape[0] * W._inshape[0] + (int(np.count_nonzero(t['lastcol'])) if t['lastcol'] is not None else 0)
+    if isinstance(W, ksp.TiledMatrix):
+        return int(W.tocsr().nnz)
+    return int(W.nnz())
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: scipy on the host cores, measured before any GPU call (fork-safe)
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them) from sched_getaffinity + lscpu."""
+    aff = sorted(os.sched_getaffinity(0))
+    phys = None
+    try:
+        out = subprocess.run(['lscpu', '-p=CPU,CORE,SOCKET'], capture_output=True, text=True, timeout=10).stdout
+        seen = set()
+        for line in out.splitlines():
+            if line.startswith('#') or not line.strip():
+                continue
+            (cpu, core, sock) = [int(v) for v in line.split(',')[:3]]
+            if cpu in aff:
+                seen.add((sock, core))
+        phys = len(seen) or None
+    except Exception:
+        phys = None
+    return (len(aff), phys if phys else len(aff))
+
+
+_CPU_JOBS = None    # [(name, scipy csr, X)] inherited by the forked workers (copy-on-write)
+
+
+def _cpu_worker(arg):
+    (k, P, warm) = arg
+    for (name, M, X) in _CPU_JOBS:
+        cols = np.array_split(np.arange(X.shape[1]), P)[k]
+        if len(cols) == 0:
+            continue
+        Xs = np.ascontiguousarray(X[:, cols[:1] if warm else cols])
+        M.dot(Xs)
+    return 0
+
+
+def cpu_baseline(knet, workload, budget_s=24.0):
+    """scipy.sparse.csr_matrix.dot (the call the reference makes: keynet/sparse.py:492; single-threaded _sparsetools.csr_matvecs)
+    on this node's host cores.  VGG-16: conv1_1 (0.7 GB CSR), conv5_1 (3.4 GB), all pools and fc6-8 are expanded to the CSR the
+    reference would hold and MEASURED; the remaining conv layers (up to 14.7 GB each) are extrapolated at the measured conv
+    ns/(nz*column).  The number of batch columns per layer is sized to the time budget (csr_matvecs is linear in them)."""
+    import multiprocessing as mp
+    import scipy
+    global _CPU_JOBS
+    layers = keyed_layers(knet)
+    nnz = {n: host_nnz(c) for (n, c) in layers}
+    total_nnz = float(sum(nnz.values()))
+    (logical, physical) = host_cores()
+    rng = np.random.RandomState(0)
+    measured = []
+    sampled = {}
+    for (n, c) in layers:
+        W = c.W
+        if isinstance(W, ksp.Conv2dTiledMatrix) and W._taps is not None:
+            if workload == 'vgg16' and n not in ('conv1_1', 'conv5_1'):
+                continue
+            t0 = time.time()
+            # rows (co, o) in the reference's order; conv5_1 is bounded to its first 128 of 512 output channels (0.84 of 3.4 GB:
+            # every row walks the same columns, so ns/(nz*column) is that of the whole operator and first-touch of the CSR stays cheap)
+            ch = 128 if (n == 'conv5_1' and W._outshape[0] > 128) else None
+            M = W.rows_csr(None, channels=ch)
+            sampled[n] = 'first %d of %d output channels, every pixel' % (ch, W._outshape[0]) if ch else 'whole operator'
+            log('[bench cpu] expanded %s (%s) to CSR: %d nnz in %.1f s' % (n, sampled[n], M.nnz, time.time() - t0))
+        elif isinstance(W, ksp.TiledMatrix):
+            M = W.tocsr()
+        else:
+            M = W._matrix.tocsr()
+        measured.append((n, M))
+    est_ns = 0.45                                            # sizing guess only; the reported figure is what gets measured
+    share = budget_s / 2.0 / max(len(measured), 1)
+    jobs = []
+    for (n, M) in measured:
+        cols = int(min(256, max(32, share / (est_ns * 1e-9 * max(M.nnz, 1)))))
+        cols = max(32, (cols // 8) * 8)                      # >= 32 columns: below that the (col,val) stream, not the arithmetic, is what is timed
+        jobs.append((n, M, rng.randn(M.shape[1], cols).astype(np.float32)))
+    # (i) one thread: the reference's real behaviour
+    rows = []
+    for (n, M, X) in jobs:
+        M.dot(X[:, :1])                                      # page in
+        t0 = time.perf_counter()
+        Y = M.dot(X)
+        dt = time.perf_counter() - t0
+        assert Y.dtype == np.float32
+        rows.append(dict(layer=n, nnz=int(M.nnz), columns=int(X.shape[1]), seconds=dt, ns_per_nz_col=1e9 * dt / (M.nnz * X.shape[1])))
+        log('[bench cpu] %-10s nnz=%10d x %3d columns  %.3f s  %.3f ns/(nz*col)  [scipy, 1 thread]' % (n, M.nnz, X.shape[1], dt, rows[-1]['ns_per_nz_col']))
+    by = {r['layer']: r for r in rows}
+    conv_rate = [r['ns_per_nz_col'] for r in rows if r['layer'].startswith('conv')]
+    conv_big = by['conv5_1']['ns_per_nz_col'] if 'conv5_1' in by else (float(np.mean(conv_rate)) if conv_rate else float(np.mean([r['ns_per_nz_col'] for r in rows])))
+    sec_per_image = 0.0
+    extrapolated = []
+    for (n, _) in layers:
+        if n in by:
+            sec_per_image += by[n]['ns_per_nz_col'] * 1e-9 * nnz[n]
+        else:
+            sec_per_image += conv_big * 1e-9 * nnz[n]
+            extrapolated.append(n)
+    res = dict(value=1.0 / sec_per_image, unit='images/s', cores=1, kind='port', engine='scipy.sparse.csr_matrix.dot (scipy %s), float32' % scipy.__version__,
+               host={'logical_cpus': logical, 'physical_cores': physical},
+               sample='measured directly on 1 thread: {%s}; extrapolated at the measured conv5_1 rate (%.3f ns per nz*column): {%s}; %.4g nnz per image'
+                      % (', '.join('%s x%d cols%s' % (r['layer'], r['columns'], (' [%s]' % sampled[r['layer']]) if sampled.get(r['layer'], 'whole operator') != 'whole operator' else '')
+                                   for r in rows), conv_big, ', '.join(extrapolated) or 'none', total_nnz),
+               layers=rows)
+    # (ii) every physical core: one process per core, batch columns sharded, operators shared copy-on-write
+    try:
+        P = max(1, min(physical, min(X.shape[1] for (_, _, X) in jobs)))
+        _CPU_JOBS = jobs
+        ctx = mp.get_context('fork')                         # safe: nothing in this process has touched the GPU yet
+        with ctx.Pool(P) as pool:
+            pool.map(_cpu_worker, [(k, P, 1) for k in range(P)])
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, [(k, P, 0) for k in range(P)])
+            par = time.perf_counter() - t0
+        macs = float(sum(M.nnz * X.shape[1] for (_, M, X) in jobs))
+        ns_par = 1e9 * par / macs
+        serial = float(sum(r['seconds'] for r in rows))
+        res['all_cores'] = dict(value=res['value'] * serial / par, unit='images/s', cores=P,
+                                sample='the same measured layers, batch columns sharded over %d processes (one per physical core): %.2f s wall vs %.2f s on one thread '
+                                       '(%.3f ns per nz*column aggregate); whole-net figure scaled by that ratio' % (P, par, serial, ns_par))
+    except Exception as e:       # a reported-only baseline must never break the bench line
+        res['all_cores'] = dict(value=None, error=str(e))
+    finally:
+        _CPU_JOBS = None
+    # (iii) the reference's TiledMatrix.torchdot rebuilds the CSR on EVERY call (keynet/sparse.py:610): tocsr() + dot of one tiled layer
+    tiled = [(n, c) for (n, c) in layers if type(c.W) is ksp.TiledMatrix]
+    if tiled:
+        (n, c) = tiled[len(tiled) // 2]
+        X = rng.randn(c.W.shape[1], 32).astype(np.float32)
+        t0 = time.perf_counter()
+        M = c.W.tocsr()
+        t1 = time.perf_counter()
+        M.dot(X)
+        t2 = time.perf_counter()
+        res['tocsr_per_call'] = dict(layer=n, nnz=int(M.nnz), tocsr_seconds=t1 - t0, dot_seconds=t2 - t1, columns=32,
+                                     note='tile expansion here is this build\'s vectorised host restatement; the reference walks the blocks in Python (slower)')
+    del jobs, measured
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# GPU side
 def _takes_small_k_kernel(W, batch):
     """Mirror of the dispatch in kn_conv.hip (convtaps_spmm): one output pixel's whole contraction fits 28 rows (VGG conv1_1),
     which runs in the write-bound convtaps_smallk_kernel and is therefore not part of the MFMA roofline aggregate."""
@@ -84,34 +250,38 @@ def _takes_small_k_kernel(W, batch):
 
 
 def layer_table(knet, batch):
-    """Per keyed layer: algorithmic MACs (= nnz of the expanded operator the reference applies) and bytes."""
+    """Per keyed layer: the kernel family that runs it in the key-net's CURRENT mode, algorithmic MACs (= nnz of the expanded
+    operator the reference applies) and bytes."""
     rows = []
     children = list(knet._keynet.named_children())
     for (i, (name, c)) in enumerate(children):
         if not isinstance(c, KeyedLayer):
             continue
-        if type(c.W) is ksp.SparseMatrix and not getattr(c, '_exact', True) and c.W._dense_device_op() is not None:
-            kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode); its CSR twin is never built
+        exact = bool(getattr(c, '_exact', True))
+        if type(c.W) is ksp.SparseMatrix and not exact and c.W._dense_device_op() is not None:
+            kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
             (r, cdim) = c.W.shape
             nnz_exp = int(c.W.nnz())
             wbytes = 4 * r * cdim
+        elif isinstance(c.W, ksp.Conv2dTiledMatrix):
+            op = c.W._device_op()
+            (r, cdim) = op.shape()
+            nnz_exp = op.nnz_expanded()
+            kind = 'convexact' if exact else ('smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps')
+            wbytes = 4 * c.W.nnz()             # taps + entries + last column actually read
         else:
             op = c.W._device_op()
             (r, cdim) = op.shape()
             nnz_exp = op.nnz_expanded()
-            if isinstance(c.W, ksp.Conv2dTiledMatrix):
-                kind = 'smallk' if (_takes_small_k_kernel(c.W, batch) and not getattr(c, '_exact', False)) else 'convtaps'
-                wbytes = 4 * c.W.nnz()        # taps + entries + last column actually read
-            else:
-                kind = 'csr'
-                wbytes = 8 * nnz_exp           # (col,val) per non-zero
+            kind = 'csr'
+            wbytes = 8 * nnz_exp               # (col,val) per non-zero
         rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch,
                          bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c,
                          fuse=(i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)))
     return rows
 
 
-def time_layers(knet, x_cipher, table, iters):
+def time_layers(x_cipher, table, iters):
     """Per-layer kernel time with HIP events on the launch stream (torch's current stream is the one kn_spmm launches on).
     Every iteration is timed on its own and the MEDIAN is kept: a multi-GB output allocation can occasionally fall out of
     the caching allocator and cost tens of ms, which must not leak into a kernel's average."""
@@ -137,105 +307,105 @@ def time_layers(knet, x_cipher, table, iters):
     return table
 
 
-def committed_traffic(workload):
-    """HBM bytes per forward of the dominant kernel from the committed PMC passes (profiles/rNN_<workload>_*_traffic.json:
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'keynet_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()
+
+
+def committed_traffic(workload, mode):
+    """HBM bytes per forward of the dominant kernel from the committed PMC passes (profiles/rNN_<workload>_*traffic.json:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, FETCH doubled per the guide's gfx950
-    note).  bench.py cannot collect PMC counters on itself; None when no such file is committed."""
+    note).  bench.py cannot collect PMC counters on itself, so the figure is quoted only when that pass was taken in the same
+    mode on byte-identical kernel sources (`csrc_sha256` recorded by tools/make_profiles.py); otherwise (None, reason)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_*traffic.json' % workload)))
     if not files:
-        return (None, None)
+        return (None, 'no committed PMC pass')
     t = json.load(open(files[-1]))
-    return (t.get('convtaps_hbm_bytes_per_forward'), os.path.relpath(files[-1], ROOT))
+    rel = os.path.relpath(files[-1], ROOT)
+    if t.get('mode', 'tolerance') != mode:
+        return (None, '%s is a %s-mode pass' % (rel, t.get('mode', 'tolerance')))
+    if t.get('csrc_sha256') != kernel_sources_sha():
+        return (None, '%s was taken on other kernel sources' % rel)
+    return (t.get('convtaps_hbm_bytes_per_forward'), rel)
 
 
-def cpu_baseline(knet, batch_total_nnz, budget_cols=256, conv_pixels=1024):
-    """CPU oracle (oracle/kn_oracle.c: scipy csr_matvecs restated, 1 thread) on a bounded sample of the workload:
-    `conv_pixels` output pixels x all output channels of the largest conv layer (realistic gather pattern), the first
-    pooling layer and the last two FC layers, `budget_cols` images (about 10-20 s of single-thread CPU work on the VGG-16
-    workload); extrapolated to the whole net by non-zeros."""
+def roofline_of(table, workload, batch, mode):
+    """Roofline record of the dominant kernel family of `table` (the layers as they ran in this mode)."""
+    kinds = {}
+    for r in table:
+        kinds.setdefault(r['kind'], []).append(r)
+    by_ms = sorted(kinds.items(), key=lambda kv: -sum(r['ms'] for r in kv[1]))
+    (kind, dom) = by_ms[0]
+    dom_ms = sum(r['ms'] for r in dom)
+    if kind in ('convtaps', 'dense'):
+        dom = kinds.get('convtaps', []) or dom
+        dom_ms = sum(r['ms'] for r in dom)
+        ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
+        (traffic, tsrc) = committed_traffic(workload, mode) if batch == 256 else (None, 'PMC pass is for 256 images')
+        return dict(bound='mfma', kernel='convtaps_mfma_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc,
+                    algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
+    macs = sum(r['nnz'] for r in dom) * float(batch)
+    intensity = 2.0 * macs / sum(r['bytes'] for r in dom)
+    names = {'convexact': 'convtaps_exact_pipe_kernel / convtaps_exact_kernel', 'csr': 'csr_group_kernel / csr_rows_kernel', 'smallk': 'convtaps_smallk_kernel'}[kind]
+    if kind == 'smallk' or intensity < 2.0 * PEAK_VALU_NOFMA_TMACS * 1e3 / PEAK_HBM_GBS:      # below the balance point of the no-FMA VALU roof: HBM-bound
+        ach = sum(r['bytes'] for r in dom) / dom_ms / 1e6
+        return dict(bound='hbm', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
+                    traffic=None, algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms)
+    ach = macs / dom_ms / 1e9
+    return dict(bound='valu-nofma', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_VALU_NOFMA_TMACS, unit='T MAC/s',
+                frac=ach / PEAK_VALU_NOFMA_TMACS, traffic=None, algorithmic_macs=macs, algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
+                note='bit-exact contract: separate f32 multiply and add in the reference\'s order, so neither FMA nor MFMA may be used; roof = 157.3 TFLOP/s / 4')
+
+
+def exact_parity(knet, x_cipher, n_img=8, n_pix=4):
+    """Checker for the exact leg: the order-preserving kernels on the REAL conv1_2 and conv4_2 operators against the CPU oracle
+    (oracle/: scipy csr_matvecs restated) on sampled output rows, bit for bit, with the key-net's own activations as input."""
     import oracle
-    import scipy.sparse
-    sample = []
-    convs = [(n, c) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer) and isinstance(c.W, ksp.Conv2dTiledMatrix) and c.W._taps is not None]
-    rng = np.random.RandomState(0)
-    if convs:
-        (name, c) = max(convs, key=lambda nc: nc[1].W.shape[0])
-        t = c.W._taps
-        (Cout, Hout, Wout) = c.W._outshape
-        (Cin, Hin, Win) = c.W._inshape
-        pix = np.sort(rng.choice(Hout * Wout, size=min(conv_pixels, Hout * Wout), replace=False))
-        sel = np.isin(t['ent_out'], pix)
-        remap = -np.ones(Hout * Wout, dtype=np.int64)
-        remap[pix] = np.arange(len(pix))
-        (ic, jc) = np.meshgrid(np.arange(Cout), np.arange(Cin), indexing='ij')
-        rows = (remap[t['ent_out'][sel]][:, None, None] + (ic * len(pix))[None]).ravel()
-        cols = (t['ent_in'][sel].astype(np.int64)[:, None, None] + (jc * Hin * Win)[None]).ravel()
-        vals = t['taps'][t['ent_tap'][sel]].ravel()
-        M = scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(Cout * len(pix), c.W.shape[1]))
-        sample.append((name + '[%d px]' % len(pix), M))
-    others = [(n, c) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer) and not isinstance(c.W, ksp.Conv2dTiledMatrix)]
-    pools = [(n, c) for (n, c) in others if isinstance(c.W, ksp.TiledMatrix)]
-    fcs = [(n, c) for (n, c) in others if not isinstance(c.W, ksp.TiledMatrix)]
-    for (n, c) in pools[:1]:
-        sample.append((n, c.W.tocsr()))
-    for (n, c) in fcs[-2:]:
-        sample.append((n, c.W._matrix.tocsr()))
-    if not convs:       # small nets: every layer
-        sample = [(n, (c.W.tocsr() if isinstance(c.W, ksp.TiledMatrix) else c.W._matrix.tocsr())) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)]
-    (macs, secs) = (0.0, 0.0)
-    prepared = []
-    for (n, M) in sample:
-        X = rng.randn(M.shape[1], budget_cols).astype(np.float32)
-        (ip, ix, dt) = (M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float32))
-        oracle.csr_matvecs(M.shape, ip, ix, dt, X[:, :1])        # page in
-        t0 = time.perf_counter()
-        oracle.csr_matvecs(M.shape, ip, ix, dt, X)
-        dt_s = time.perf_counter() - t0
-        macs += float(M.nnz) * budget_cols
-        secs += dt_s
-        prepared.append((M.shape, ip, ix, dt, X))
-        log('[bench cpu] %-22s nnz=%10d  %.3f s  %.3f ns/(nz*col)' % (n, M.nnz, dt_s, 1e9 * dt_s / (M.nnz * budget_cols)))
-    ns_per_mac = 1e9 * secs / macs
-    img_s = 1.0 / (ns_per_mac * 1e-9 * batch_total_nnz)
-    names = ', '.join(n for (n, _) in sample)
-    res = dict(value=img_s, unit='images/s', cores=1, kind='port',
-               sample='oracle csr_matvecs (1 thread) on {%s} x %d images = %.3g MAC in %.1f s; %.3f ns/(nz*image) extrapolated to %.4g nnz/image'
-                      % (names, budget_cols, macs, secs, ns_per_mac, batch_total_nnz))
-    # second figure (SURVEY 8d ii): the same sample with the batch columns sharded over all host cores (one process per
-    # core, operators shared copy-on-write) -- what a "whole host" deployment of the reference's algorithm could do
-    try:
-        import multiprocessing as mp
-        P = max(1, min(os.cpu_count() or 1, budget_cols // 8, 32))     # >= 8 batch columns per process, else the operator stream dominates
-        if P > 1:
-            global _CPU_SHARDS
-            _CPU_SHARDS = prepared
-            ctx = mp.get_context('fork')          # children only run the C oracle on CPU arrays; they never touch the GPU
-            with ctx.Pool(P) as pool:
-                pool.map(_cpu_shard, [(k, P, 1) for k in range(P)])            # warm
-                t0 = time.perf_counter()
-                pool.map(_cpu_shard, [(k, P, 0) for k in range(P)])
-                par = time.perf_counter() - t0
-            res['all_cores'] = dict(value=1.0 / (par / macs * batch_total_nnz), unit='images/s', cores=P,
-                                    sample='same sample, %d processes x %d columns each, %.2f s wall' % (P, (budget_cols + P - 1) // P, par))
-    except Exception as e:       # never let the reported-only baseline break the bench line
-        res['all_cores'] = dict(value=None, error=str(e))
-    return res
-
-
-_CPU_SHARDS = None
-
-
-def _cpu_shard(arg):
-    import oracle
-    (k, P, warm) = arg
-    for (shape, ip, ix, dt, X) in _CPU_SHARDS:
-        cols = np.array_split(np.arange(X.shape[1]), P)[k]
-        if len(cols) == 0:
+    rng = np.random.RandomState(1)
+    y = x_cipher[:n_img]
+    checked = []
+    children = list(knet._keynet.named_children())
+    for (i, (name, c)) in enumerate(children):
+        if not isinstance(c, KeyedLayer):
             continue
-        Xs = np.ascontiguousarray(X[:, cols[:1] if warm else cols])
-        oracle.csr_matvecs(shape, ip, ix, dt, Xs)
-    return 0
+        fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+        out = c.forward(y, fuse_relu=fuse)
+        if name in ('conv1_2', 'conv4_2') and isinstance(c.W, ksp.Conv2dTiledMatrix) and c.W._taps is not None:
+            (Cout, Hout, Wout) = c.W._outshape
+            pix = np.sort(rng.choice(Hout * Wout, size=n_pix, replace=False))
+            M = c.W.rows_csr(pix)
+            ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), y.t().contiguous().cpu().numpy())
+            if fuse:
+                ref = np.maximum(ref, 0)
+            rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
+            got = out.t()[torch.as_tensor(rows, device=out.device)].cpu().numpy()
+            checked.append({'layer': name, 'rows': int(len(rows)), 'images': n_img, 'bit_equal': bool(np.array_equal(got, ref))})
+        y = out
+        if name == 'conv4_2':
+            break
+    return {'check': 'exact-mode kernels vs the CPU oracle (scipy csr_matvecs restated) on sampled output rows of real layers', 'layers': checked,
+            'ok': bool(checked) and all(r['bit_equal'] for r in checked)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from THIS
+    process, which has not touched the GPU (no torch.cuda call above this point), and exit with their code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    log('[bench] starting %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -247,16 +417,34 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=5)
-    ap.add_argument('--exact', action='store_true', help='bit-exact mode for the tiled key-nets (order-preserving kernels everywhere; not the headline)')
+    ap.add_argument('--exact', action='store_true', help='bit-exact mode for the tiled key-nets as the MAIN measurement (order-preserving kernels everywhere)')
+    ap.add_argument('--no-exact-leg', action='store_true', help='skip the additional bit-exact-mode measurement of the default vgg16 run')
     ap.add_argument('--graph', action='store_true', help='replay the forward from a captured HIP graph (launch-bound small nets)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))                       # before ANY GPU call in this process
+    assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d' % (args.gpus, world)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    # ---- host phase: keying and the CPU baseline, nothing below touches the GPU until "device phase" ----------------------
+    (sensor, knet, inshape, batch, desc, net) = build_workload(args.workload, rank, exact=True if args.exact else None)
+    mode = 'exact' if (args.exact or args.workload != 'vgg16') else 'tolerance'
+    if args.exact:
+        desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
+    batch = args.batch if args.batch is not None else batch
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        t0 = time.time()
+        cpu = cpu_baseline(knet, args.workload)
+        log('[bench cpu] baseline section took %.1f s' % (time.time() - t0))
+
+    # ---- device phase --------------------------------------------------------------------------------------------------------
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     # Test-only override (single-GPU boxes): KN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so the N>1
-    # control flow (sharding, barriers, gather, max-over-ranks timing) can be smoke-tested without 8 GPUs.  Never set by
+    # control flow (sharding, barriers, gather, max-over-ranks timing) can be exercised without 8 GPUs.  Never set by
     # the driver; the real path is one rank per GPU over RCCL.
     share = os.environ.get('KN_BENCH_SHARE_GPU') == '1'
     if share:
@@ -269,12 +457,6 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
-    assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world)
-
-    (sensor, knet, inshape, batch, desc, net) = build_workload(args.workload, rank, world, exact=True if args.exact else None)
-    if args.exact:
-        desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
-    batch = args.batch if args.batch is not None else batch
 
     # synthetic encrypted batch, resident in HBM before the timed region
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -297,26 +479,28 @@ def main():
         yl = (replay(x_cipher) if replay is not None else knet.forward_linear(x_cipher))[:, :-1]
         if world == 1:
             return yl
-        if share:   # gloo has no device all_gather_into_tensor: bounce through the host (test-only path)
-            return kdist.gather_logits(yl.cpu(), total=batch * world).to(dev)
-        return kdist.gather_logits(yl, total=batch * world)
+        return kdist.gather_logits(yl, total=batch * world)     # RCCL all-gather over xGMI (gloo rigs bounce through the host)
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cpu') if share else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_warm, n_steps):
+        for _ in range(n_warm):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cpu') if share else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return (elapsed, out)
+
+    (elapsed, out) = timed(args.warmup, args.steps)
     assert out.shape[0] == batch * world and bool(torch.isfinite(out).all())
     parity = None
     if rank == 0:
@@ -326,42 +510,49 @@ def main():
                   'ok': bool(err <= 1e-3)}
         if not parity['ok']:
             raise AssertionError('parity gate failed: %s' % json.dumps(parity))
+    del out
 
     if rank == 0:
-        table = layer_table(knet, batch)
-        table = time_layers(knet, x_cipher, table, args.layer_iters)
+        table = time_layers(x_cipher, layer_table(knet, batch), args.layer_iters)
         nnz_img = float(sum(r['nnz'] for r in table))
         for r in table:
-            log('[bench layer] %-8s %-8s rows=%8d nnz=%12d  %8.3f ms  %7.2f TFLOP/s  %8.1f GB/s(alg)' %
+            log('[bench layer] %-8s %-9s rows=%8d nnz=%12d  %8.3f ms  %7.2f TFLOP/s  %8.1f GB/s(alg)' %
                 (r['name'], r['kind'], r['rows'], r['nnz'], r['ms'], r['flops'] / r['ms'] / 1e9, r['bytes'] / r['ms'] / 1e6))
-        dom = [r for r in table if r['kind'] == 'convtaps'] or table
-        dom_kind = 'mfma' if dom[0]['kind'] == 'convtaps' else 'hbm'
-        dom_ms = sum(r['ms'] for r in dom)
-        if dom_kind == 'mfma':
-            ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
-            (traffic, tsrc) = committed_traffic(args.workload) if batch == 256 else (None, None)
-            roof = dict(bound='mfma', kernel='convtaps_mfma_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                        frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc,
-                        algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
-        else:
-            ach = sum(r['bytes'] for r in dom) / dom_ms / 1e6
-            roof = dict(bound='hbm', kernel='csr_group_kernel/csr_rows_kernel', achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
-                        traffic=None, ms_per_forward=dom_ms)
+        roof = roofline_of(table, args.workload, batch, mode)
         total_bytes = sum(r['bytes'] for r in table)
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
             'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
             'value': batch * world * args.steps / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': desc, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
+            'config': {'workload': desc, 'mode': mode, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
                        'parallelism': 'batch shards x%d, all_gather(logits)' % world if world > 1 else 'single GPU'},
             'achieved_hbm_gbs_algorithmic': total_bytes / (ms_per_step * 1e6), 'achieved_tflops_algorithmic': 2.0 * nnz_img * batch / (ms_per_step * 1e9),
-            'roofline': roof, 'parity': parity,
+            'roofline': roof, 'parity': parity, 'cpu_baseline': cpu,
+            'layers_ms': {r['name']: round(r['ms'], 4) for r in table},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(knet, nnz_img)
-        else:
-            res['cpu_baseline'] = None
+        # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key")
+        if args.workload == 'vgg16' and world == 1 and not args.exact and not args.no_exact_leg and replay is None:
+            knet.exact_mode(True)
+            t0 = time.time()
+            knet.forward_linear(x_cipher)                    # uploads the CSR twins of fc6-8
+            torch.cuda.synchronize()
+            log('[bench exact] exact-mode operators resident + first forward in %.1f s' % (time.time() - t0))
+            (el_x, out_x) = timed(1, args.steps)
+            err_x = float((out_x[:n_gate].contiguous().cpu() - y_plain).abs().max())
+            del out_x
+            table_x = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
+            for r in table_x:
+                log('[bench exact] %-8s %-9s %8.3f ms  %7.2f T MAC/s' % (r['name'], r['kind'], r['ms'], r['nnz'] * batch / r['ms'] / 1e9))
+            par_x = exact_parity(knet, x_cipher)
+            par_x['vs_source_network_max_abs_err'] = err_x
+            if not par_x['ok'] or err_x > 1e-3:
+                raise AssertionError('exact-mode parity failed: %s' % json.dumps(par_x))
+            res['exact'] = {'images_per_s': batch * args.steps / el_x, 'ms_per_step': 1e3 * el_x / args.steps, 'steps': args.steps,
+                            'mode': 'KeyedModel.exact_mode(True): every layer in the reference\'s accumulation order and rounding (no FMA, no MFMA)',
+                            'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
+                            'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
+            knet.exact_mode(None)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -474,7 +474,9 @@ int kn_destroy(kn_handle_t h) {
     if (h->exact) kn_destroy(h->exact);
     if (h->dense_sub) kn_destroy(h->dense_sub);
     if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
-    if (h->dense_ws) (void)hipFree(h->dense_ws);
+    for (auto& kv : h->dense_ws)
+        if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (float* q : h->dense_ws_retired) (void)hipFree(q);
     csr_free(h->csr);
     convtaps_free(h->ct);
     delete h;
@@ -537,23 +539,34 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
     KN_REQUIRE(n_vecs < INT32_MAX, KN_ERR_UNSUPPORTED, "n_vecs too large");
     KN_REQUIRE(x_dev != y_dev, KN_ERR_INVALID, "x and y alias");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    {
+        // the operator lives in ONE device's HBM: running it from another device would dereference foreign memory
+        int cur = -1;
+        KN_HIP(hipGetDevice(&cur));
+        KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one (create it under the device of x)");
+    }
     if (h->kind == KIND_CSR) return csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
     if (h->kind == KIND_DENSE) {
         KN_REQUIRE(!(flags & KN_FLAG_EXACT), KN_ERR_UNSUPPORTED, "KN_FLAG_EXACT on a dense (MFMA) operator: create it with kn_csr_create instead");
         const int64_t outs = h->rows - 1, S = h->dense_splits;
+        float* ws = nullptr;
         {
-            // partial-sum workspace, grown on demand (not capturable the first time a larger batch is seen)
+            // partial-sum workspace of THIS stream, grown on demand (the growing call is not capturable in a HIP graph: run one
+            // eager forward per stream and batch size first, as KeyedModel.capture does)
             std::lock_guard<std::mutex> g(h->lazy_mu);
-            if (h->dense_ws_vecs < n_vecs) {
-                if (h->dense_ws) KN_HIP(hipFree(h->dense_ws));
-                h->dense_ws = nullptr;
-                KN_HIP(hipMalloc((void**)&h->dense_ws, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs));
-                h->dense_ws_vecs = n_vecs;
+            kn_operator::DenseWs& w = h->dense_ws[s];
+            if (w.vecs < n_vecs) {
+                if (w.ptr) h->dense_ws_retired.push_back(w.ptr);   // launches already queued on `s` may still use it
+                w.ptr = nullptr;
+                w.vecs = 0;
+                KN_HIP(hipMalloc((void**)&w.ptr, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs));
+                w.vecs = n_vecs;
             }
+            ws = w.ptr;
         }
-        int rc = convtaps_spmm(h->dense_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, h->dense_ws, n_vecs, 0, s);
+        int rc = convtaps_spmm(h->dense_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, ws, n_vecs, 0, s);
         if (rc) return rc;
-        return dense_reduce(h->dense_ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
+        return dense_reduce(ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
     }
     // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
     return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);

@@ -196,6 +196,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     // slot's (tap, input pixel) are re-read only when the slot changes, so the steady state has no scalar loads,
     // divisions or 64-bit multiplies.  Per-thread element offsets are computed once.
     uint32_t a_off[AL], b_off[BL];      // element offsets inside one chunk (< 2^31: checked by the launcher)
+    bool b_pad[BL];                     // this thread's activation row is a zero-padding row (only possible when KC < 16)
 #pragma unroll
     for (int i = 0; i < AL; i++) {
         const int f = tid + i * 256;
@@ -204,10 +205,12 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 #pragma unroll
     for (int i = 0; i < BL; i++) {
         const int f = tid + i * 256;
-        // rows ci >= Cin exist only when Cin < KC (one zero-padded chunk per slot): their taps are zero, so they may read
-        // any valid activation row (row 0 of the slot) -- finite activations assumed, as for every padded GEMM
+        // rows ci >= Cin exist only when Cin < KC (one zero-padded chunk per slot).  Their loads are pointed at a valid row (row 0
+        // of the slot) so the address stays in range, but what they return is DISCARDED: lstore writes zeros for them, so a
+        // NaN / Inf in that live activation row cannot leak into the product (0 x NaN) -- the reference has no such entries.
         const int r = f / (NB / 4);
         b_off[i] = (uint32_t)((int64_t)(r < p.Cin ? r : 0) * p.HiWi * p.ldx + (f % (NB / 4)) * 4);
+        b_pad[i] = (KC < 16) && (r >= p.Cin);
     }
     // K order: input-channel chunk OUTER, slot INNER.  Workgroups of neighbouring output pixels (which share most of
     // their input pixels, at different slot positions) then touch the same activation tile within a few chunk-times,
@@ -290,7 +293,12 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 #pragma unroll
         for (int i = 0; i < BL; i++) {
             const int f = tid + i * 256;
-            if (B4 % 256 == 0 || f < B4) *reinterpret_cast<f32x4*>(b + b_lds[i]) = rb[i];
+            if (B4 % 256 == 0 || f < B4) {
+                if constexpr (FAST && KC < 16) {
+                    if (b_pad[i]) rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                *reinterpret_cast<f32x4*>(b + b_lds[i]) = rb[i];
+            }
         }
     };
 

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <map>
 #include "../../include/keynet_hip.h"
 
 namespace kn {
@@ -88,8 +89,15 @@ struct kn_operator {
     kn_operator* dense_sub = nullptr;
     int64_t dense_splits = 0;
     float* dense_lastcol = nullptr;   // [rows] bias column incl. the homogeneous 1
-    float* dense_ws = nullptr;        // [ (rows-1) * splits, ws_vecs ] partial sums
-    int64_t dense_ws_vecs = 0;
+    // split-K partial sums [(rows-1) * splits, vecs]: ONE workspace PER STREAM (launches on one stream are ordered, launches on
+    // different streams get different buffers, so concurrent kn_spmm calls on one handle never share partial sums).  A buffer
+    // that is outgrown is retired, not freed: an earlier launch may still be reading it; kn_destroy frees everything.
+    struct DenseWs {
+        float* ptr = nullptr;
+        int64_t vecs = 0;
+    };
+    std::map<hipStream_t, DenseWs> dense_ws;
+    std::vector<float*> dense_ws_retired;
 };
 
 namespace kn {
@@ -113,11 +121,15 @@ void convtaps_free(ConvTapsDev& c);
 template <typename T>
 inline int upload(T** dptr, const T* h, size_t n) {
     *dptr = nullptr;
-    if (n == 0) n = 1;  // keep pointers non-null
+    const size_t n_copy = n;   // an empty host array has nothing to read, even when its pointer is non-null
+    if (n == 0) n = 1;         // keep device pointers non-null
     hipError_t e = hipMalloc((void**)dptr, n * sizeof(T));
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? KN_ERR_NOMEM : KN_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
-    if (h) {
-        e = hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice);
+    if (n_copy == 0) {
+        e = hipMemset(*dptr, 0, n * sizeof(T));
+        if (e != hipSuccess) return fail(KN_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    } else if (h) {
+        e = hipMemcpy(*dptr, h, n_copy * sizeof(T), hipMemcpyHostToDevice);
         if (e != hipSuccess) return fail(KN_ERR_HIP, std::string("hipMemcpy H2D: ") + hipGetErrorString(e));
     }
     return KN_OK;

@@ -35,6 +35,9 @@ def gather_logits(local_logits, total=None):
     (rank, ws) = world()
     if ws == 1:
         return local_logits
+    if local_logits.is_cuda and dist.get_backend() == 'gloo':
+        # gloo has no device collectives: bounce through the host (single-GPU test rigs; the production backend is RCCL)
+        return gather_logits(local_logits.cpu(), total=total).to(local_logits.device)
     n_local = local_logits.shape[0]
     if total is None:
         t = torch.tensor([n_local], dtype=torch.int64, device=local_logits.device)

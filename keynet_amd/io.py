@@ -8,8 +8,15 @@ Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_gold
     csr:          shape, indptr, indices, data           (STORED order)
     tiled:        shape, tileshape, blocks, tile_shapes, tile_ptr, tile_row, tile_col, tile_val
     conv2dtiled:  shape, inshape, outshape, tileshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias
-    convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol
+    convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol [, tileshape]
+    L.<name>.exact                   (save_keynet only) the layer's arithmetic contract: True = the reference's accumulation order and
+                                     rounding, False = float-key tolerance on the matrix cores; absent (golden files) = the default
     outshape                         (C,1,1) of the logits
+    sensor.*                         (optional) the image key pair as stored-order CSR + 'sensor.inshape'
+
+tests/golden/import_pickle.py converts a reference pickle (a keyed model saved with vipy.util.save / pickle, e.g.
+demo/keynet_challenge_lenet_10AUG20.pkl) into this container; it needs the reference importable and therefore runs in the build
+container only.
 """
 from collections import OrderedDict
 import numpy as np
@@ -25,8 +32,9 @@ def operator_from_arrays(z, p):
     kind = str(z[p + 'kind'])
     if kind == 'convtaps':
         g = (lambda k: z[p + k] if (p + k) in z.files and z[p + k].size > 0 else None)
+        ts = tuple(int(v) for v in z[p + 'tileshape']) if (p + 'tileshape') in z.files else None
         return ksp.Conv2dTiledMatrix.fromtaps(tuple(int(v) for v in z[p + 'inshape']), tuple(int(v) for v in z[p + 'outshape']), z[p + 'taps'],
-                                              z[p + 'ent_out'], z[p + 'ent_in'], z[p + 'ent_tap'], g('ent_coef'), g('lastcol'))
+                                              z[p + 'ent_out'], z[p + 'ent_in'], z[p + 'ent_tap'], g('ent_coef'), g('lastcol'), tileshape=ts)
     shape = tuple(int(v) for v in z[p + 'shape'])
     if kind == 'csr':
         data = z[p + 'data']
@@ -68,6 +76,8 @@ def operator_to_arrays(W, p, out):
             (out[p + 'inshape'], out[p + 'outshape']) = (np.array(W._inshape, dtype=np.int64), np.array(W._outshape, dtype=np.int64))
             for (k, v) in W._taps.items():
                 out[p + k] = v if v is not None else np.zeros(0, np.float32)
+            if W._tileshape is not None:
+                out[p + 'tileshape'] = np.array(W._tileshape, dtype=np.int64)
             return
         out[p + 'kind'] = np.array('conv2dtiled')
         (bl, tk, ib, ch, bs) = W._golden_arrays()
@@ -95,13 +105,16 @@ def keynet_from_arrays(z):
         if str(z[p + 'kind']) == 'relu':
             layers[name] = nn.ReLU()
         else:
-            layers[name] = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']))
+            exact = bool(z[p + 'exact']) if (p + 'exact') in z.files else None
+            layers[name] = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']), exact=exact)
     last = [l for l in layers.values() if isinstance(l, KeyedLayer)][-1]
     outshape = tuple(int(v) for v in z['outshape']) if 'outshape' in z.files else (last.W.shape[0] - 1, 1, 1)
     return KeyedModel.fromlayers(layers, outshape)
 
 
-def sensor_from_arrays(z, inshape):
+def sensor_from_arrays(z, inshape=None):
+    """KeyedSensor from the 'sensor.*' arrays of an archive (inshape from 'sensor.inshape' unless given)."""
+    inshape = tuple(int(v) for v in z['sensor.inshape']) if inshape is None else inshape
     shape = tuple(int(v) for v in z['sensor.shape'])
     enc = scipy.sparse.csr_matrix((z['sensor.enc.data'], z['sensor.enc.indices'], z['sensor.enc.indptr']), shape=shape)
     dec = scipy.sparse.csr_matrix((z['sensor.dec.data'], z['sensor.dec.indices'], z['sensor.dec.indptr']), shape=shape)
@@ -115,6 +128,7 @@ def save_keynet(knet, filename, sensor=None):
         if isinstance(c, KeyedLayer):
             operator_to_arrays(c.W, p, out)
             out[p + 'layertype'] = np.array(c._layertype)
+            out[p + 'exact'] = np.array(bool(getattr(c, '_exact', True)))
         else:
             out[p + 'kind'] = np.array('relu')
     if sensor is not None:
@@ -122,9 +136,16 @@ def save_keynet(knet, filename, sensor=None):
             (ip, ix, dt) = ksp._stored_order_csr(M.tocsr() if M.format not in ('csr', 'coo', 'csc') else M)
             (out['sensor.%s.indptr' % tag], out['sensor.%s.indices' % tag], out['sensor.%s.data' % tag]) = (ip, ix, dt)
         out['sensor.shape'] = np.array(sensor._encryptkey.shape, dtype=np.int64)
+        out['sensor.inshape'] = np.array(sensor._inshape[1:], dtype=np.int64)
     np.savez_compressed(filename, **out)
     return filename
 
 
-def load_keynet(filename):
-    return keynet_from_arrays(np.load(filename, allow_pickle=False))
+def load_keynet(filename, with_sensor=False):
+    """KeyedModel from an archive written by save_keynet (or by tests/golden/import_pickle.py); `with_sensor` also returns the
+    KeyedSensor when the archive holds the image keys: (sensor, model) like the reference's factories."""
+    z = np.load(filename, allow_pickle=False)
+    knet = keynet_from_arrays(z)
+    if not with_sensor:
+        return knet
+    return (sensor_from_arrays(z) if 'sensor.shape' in z.files and 'sensor.inshape' in z.files else None, knet)

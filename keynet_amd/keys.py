@@ -56,93 +56,126 @@ def uniform_random_diagonal(n, scale=1, bias=0, eps=1E-6, dtype=np.float32, with
     return (D.astype(dtype), scipy.sparse.diags(1.0 / D.diagonal()).astype(dtype)) if withinverse else D.astype(dtype)
 
 
+def _givens_plan(n, k_iter):
+    """RNG protocol of the reference's 'balanced' Givens product (keynet/sparse.py:288-309), separated from the algebra: per
+    rotation one np.random.rand() for the angle, then -- only when fewer than two indices are left -- one
+    np.random.permutation(n) pushed UNDER the leftovers; the plane is the two indices popped off the top.
+    Returns [(i, j, theta)] in application order."""
+    (plan, pool) = ([], [])
+    for _ in range(k_iter):
+        theta = 2 * np.pi * np.random.rand()
+        if len(pool) < 2:
+            pool = np.random.permutation(n).tolist() + pool
+        (i, j) = (pool.pop(), pool.pop())
+        plan.append((i, j, theta))
+    return plan
+
+
+def _plane_rotation(n, i, j, theta):
+    """The n x n rotation by theta in the (i, j) plane as canonical float64 CSR, assembled from index arithmetic."""
+    (c, s) = (np.cos(theta), np.sin(theta))
+    keep = np.setdiff1d(np.arange(n), (i, j))
+    rows = np.concatenate((keep, (i, i, j, j)))
+    cols = np.concatenate((keep, (i, j, i, j)))
+    vals = np.concatenate((np.ones(len(keep)), (c, -s, s, c)))
+    return scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(n, n))
+
+
 def givens_orthogonal(n, k_iter, withinverse=False, dtype=np.float32):
-    """Product of k_iter random Givens rotations on index pairs drawn without replacement ('balanced';
-    keynet/sparse.py:288-309).  Per rotation: theta first, then a fresh permutation whenever fewer than two indices are left."""
+    """Product G_k ... G_2 G_1 of k_iter random Givens rotations (float64 products, cast at the end); the inverse of an
+    orthogonal matrix is its transpose."""
     assert n >= 2
     S = None
-    pool = []
-    for _ in range(0, k_iter):
-        theta = np.random.rand() * 2 * np.pi
-        pool = np.random.permutation(range(0, n)).tolist() + pool if len(pool) <= 1 else pool
-        G = scipy.sparse.eye(n).todok()
-        (i, j) = (pool.pop(), pool.pop())
-        G[i, i] = np.cos(theta)
-        G[i, j] = -np.sin(theta)
-        G[j, i] = np.sin(theta)
-        G[j, j] = np.cos(theta)
-        S = G.dot(S) if S is not None else G
+    for (i, j, theta) in _givens_plan(n, k_iter):
+        G = _plane_rotation(n, i, j, theta)
+        S = G if S is None else G.dot(S)
     return S.astype(dtype) if not withinverse else (S.astype(dtype), S.transpose().astype(dtype))
 
 
+def _band_offsets(k):
+    """Diagonal offsets of a k-banded matrix, main diagonal first, then the others in ascending order (for even k the extra
+    diagonal goes below the main one)."""
+    lo = -((k - 1) // 2) if k % 2 else -(k // 2)
+    hi = (k - 1) // 2 if k % 2 else k // 2 - 1
+    return [0] + [o for o in range(lo, hi + 1) if o != 0]
+
+
+def _sinkhorn(A, n_iter):
+    """Alternate column / row l1 normalisation (sklearn's normalize, as the reference uses: its summation order is part of the
+    bit-exact contract of the key values)."""
+    for _ in range(n_iter):
+        A = normalize(normalize(A, norm='l1', axis=0), norm='l1', axis=1)
+    return A
+
+
 def diagonally_dominant_doubly_stochastic(n, k, n_iter=100, withinverse=False):
-    """Banded (k diagonals) diagonally dominant matrix, Sinkhorn-normalised to doubly stochastic, conjugated by two
-    random permutations; dense inverse (keynet/sparse.py:335-353)."""
-    n_iter = 10 if k <= 3 else n_iter
-    d = np.random.rand(k, n)
-    d[0, :] = np.maximum(d[0, :], np.sum(d[1:, :], axis=0) + 0.1)
-    d = d / np.sum(d, axis=0).reshape(1, n)
-    offs = list(range(-((k - 1) // 2), 1 + ((k - 1) // 2))) if k % 2 == 1 else list(range(-(k // 2), k // 2))
-    offs.remove(0)
-    offs = [0] + offs
-    A = scipy.sparse.spdiags(d, offs, n, n, format='csr')
-    for _ in range(0, n_iter):
-        A = normalize(A, norm='l1', axis=0)
-        A = normalize(A, norm='l1', axis=1)
-    A = sparse_permutation_matrix(n).dot(A).dot(sparse_permutation_matrix(n))
-    if withinverse and n > 8096:
+    """k-banded, diagonally dominant, (numerically) doubly stochastic matrix, hidden between two random permutations; the inverse
+    is dense (keynet/sparse.py:335-353).  Draw order: one rand(k, n) for the bands, then the left and the right permutation."""
+    bands = np.random.rand(k, n)
+    bands[0] = np.maximum(bands[0], bands[1:].sum(axis=0) + 0.1)       # main diagonal dominates the sum of the others
+    bands /= bands.sum(axis=0, keepdims=True)
+    A = _sinkhorn(scipy.sparse.spdiags(bands, _band_offsets(k), n, n, format='csr'), 10 if k <= 3 else n_iter)
+    (left, right) = (sparse_permutation_matrix(n), sparse_permutation_matrix(n))
+    A = left.dot(A).dot(right)
+    if not withinverse:
+        return A
+    if n > 8096:
         warnings.warn('direct inverse of large matrix (%dx%d)' % (n, n))
-    return A if not withinverse else (A, scipy.sparse.coo_matrix(np.linalg.inv(A.todense())))
+    return (A, scipy.sparse.coo_matrix(np.linalg.inv(A.todense())))
 
 
-def _block_permute(img, cropshape):
-    """Permute the non-overlapping cropshape blocks of an HxWxC image, rows and columns independently
-    (keynet/blockpermute.py:6-19): two np.random.permutation draws."""
-    assert img.shape[0] % cropshape[0] == 0 and img.shape[1] % cropshape[1] == 0, 'Blocksize must be evenly divisible with image shape'
-    (ri, cj) = (np.arange(0, img.shape[0], cropshape[0]), np.arange(0, img.shape[1], cropshape[1]))
-    (U, V) = (np.random.permutation(ri), np.random.permutation(cj))
-    out = np.copy(img)
-    for (i, ip) in zip(ri, U):
-        for (j, jp) in zip(cj, V):
-            out[ip:ip + cropshape[0], jp:jp + cropshape[1]] = img[i:i + cropshape[0], j:j + cropshape[1]]
+def _permuted_pixel_indices(P, blockshape, levels, min_blocksize, twist, strict):
+    """Index form of the reference's top-down hierarchical block permutation (keynet/blockpermute.py:22-68).  P is an [h, w]
+    array holding, per position, the flat index of the SOURCE pixel currently there; the result is P after the permutation of
+    this region.  Level 0 permutes the block rows and the block columns of the region independently (two np.random.permutation
+    draws; a 'twist' is one np.random.rand() choosing a quarter turn), deeper levels descend into every block in row-major
+    order -- which fixes the order of the draws."""
+    levels = [int(l) for l in levels]
+    if not levels:
+        return P.copy()
+    (h, w) = P.shape
+    (bh, bw) = blockshape
+    if h % bh != 0 and w % bw != 0:
+        if strict:
+            raise ValueError('Recursive image size %s and block layout %s must be divisible' % (str((h, w)), str(blockshape)))
+        (bh, bw) = (find_closest_positive_divisor(h, bh), find_closest_positive_divisor(w, bw))
+    (ch, cw) = (h // bh, w // bw)
+    out = P.copy()
+    if 0 in levels:
+        if twist:
+            out = np.rot90(out, k=(1 if np.random.rand() > 0.5 else 3)).copy()
+        else:
+            assert h % ch == 0 and w % cw == 0, 'Blocksize must be evenly divisible with image shape'
+            (to_row, to_col) = (np.random.permutation(h // ch), np.random.permutation(w // cw))   # source block a lands on block to_*[a]
+            blocks = out.reshape(h // ch, ch, w // cw, cw)
+            out = blocks[np.argsort(to_row)][:, :, np.argsort(to_col)].reshape(h, w)
+    if levels == [0] or max(levels) <= 0:
+        return out
+    if min(ch, cw) < min_blocksize:
+        raise ValueError('Recursive blockshape=%s < minimum blockshape=%d' % (str((ch, cw)), min_blocksize))
+    deeper = [l - 1 for l in levels]
+    for i in range(0, h, ch):
+        for j in range(0, w, cw):
+            out[i:i + ch, j:j + cw] = _permuted_pixel_indices(out[i:i + ch, j:j + cw], (bh, bw), deeper, min_blocksize, twist, True)
     return out
 
 
 def hierarchical_block_permute(img, blockshape, permute_at_level, min_blocksize=8, twist=False, strict=True):
-    """Top-down hierarchical block permutation (or 90-degree 'twist') of an HxWxC image: level 0 acts on the whole image
-    split into `blockshape` blocks, level k on each block of level k-1 (keynet/blockpermute.py:22-68)."""
-    if len(permute_at_level) == 0 or blockshape == img.shape:
-        return np.copy(img)
-    if (img.shape[0] % blockshape[0] != 0 and img.shape[1] % blockshape[1] != 0):
-        if strict:
-            raise ValueError('Recursive image size %s and block layout %s must be divisible' % (str(img.shape[0:2]), str(blockshape)))
-        blockshape = (find_closest_positive_divisor(img.shape[0], blockshape[0]), find_closest_positive_divisor(img.shape[1], blockshape[1]))
-    cropshape = (img.shape[0] // blockshape[0], img.shape[1] // blockshape[1])
-    out = np.copy(img)
-    if 0 in permute_at_level:
-        if twist:
-            out = np.rot90(out, k=(1 if np.random.rand() > 0.5 else 3))
-        else:
-            out = _block_permute(out, cropshape)
-    if len(permute_at_level) == 1 and permute_at_level[0] == 0:
-        return out
-    for i in range(0, img.shape[0], cropshape[0]):
-        for j in range(0, img.shape[1], cropshape[1]):
-            sub = out[i:i + cropshape[0], j:j + cropshape[1]]
-            if min(cropshape) >= min_blocksize and max(permute_at_level) > 0:
-                out[i:i + cropshape[0], j:j + cropshape[1]] = hierarchical_block_permute(sub, blockshape, np.array(permute_at_level) - 1,
-                                                                                         min_blocksize=min_blocksize, twist=twist)
-            elif max(permute_at_level) > 0:
-                raise ValueError('Recursive blockshape=%s < minimum blockshape=%d' % (sub.shape[0:2], min_blocksize))
-    return out
+    """The hierarchically block-permuted (or twisted) HxWxC image: every pixel moves with all its channels."""
+    (H, W) = img.shape[0:2]
+    src = _permuted_pixel_indices(np.arange(H * W).reshape(H, W), blockshape, list(np.atleast_1d(permute_at_level)), min_blocksize, twist, strict)
+    return img.reshape((H * W,) + img.shape[2:])[src.ravel()].reshape(src.shape + img.shape[2:])
 
 
 def hierarchical_block_permutation_matrix(imgshape, blockshape, permute_at_level, min_blocksize=8, seed=None, twist=False, withinverse=False, strict=True):
-    """The permutation matrix of hierarchical_block_permute acting on the HxWxC-flattened image (keynet/blockpermute.py:71-79)."""
+    """P with P.dot(img.flatten()).reshape(shape) == hierarchical_block_permute(img) for an HxWxC image
+    (keynet/blockpermute.py:71-79): row (y, x, c) picks source pixel src[y, x], channel c."""
     if seed is not None:
         np.random.seed(seed)
-    n = int(np.prod(imgshape))
-    cols = hierarchical_block_permute(np.arange(n).reshape(imgshape), blockshape, permute_at_level, min_blocksize, twist=twist, strict=strict).flatten()
+    (H, W, C) = imgshape
+    src = _permuted_pixel_indices(np.arange(H * W).reshape(H, W), blockshape, list(np.atleast_1d(permute_at_level)), min_blocksize, twist, strict)
+    cols = (src.reshape(-1, 1) * C + np.arange(C)[None, :]).ravel()
+    n = H * W * C
     P = scipy.sparse.coo_matrix((np.ones(n, dtype=np.int64), (np.arange(n), cols)), shape=(n, n), dtype=np.float32)
     return P if not withinverse else (P, P.transpose())
 
@@ -150,22 +183,23 @@ def hierarchical_block_permutation_matrix(imgshape, blockshape, permute_at_level
 # ------------------------------------------------------------------------------------------------------------------
 # keygen: one layer's key pair, composed from five stages
 def diagonal_affine_to_linear(A, bias=None, withinverse=False, dtype=np.float32):
-    """[[A, b], [0, 1]] for a diagonal A; the inverse comes from the rank-one (Woodbury) update of the diagonal part
-    (keynet/sparse.py:99-119).  Arithmetic in float64, cast at the end, as the reference does."""
+    """L = [[D, b], [0, 1]] for a diagonal D, and its inverse in closed form [[D^-1, -D^-1 b], [0, 1]] (float64, cast at the end).
+    The reference reaches the same numbers through a rank-one (Woodbury) update (keynet/sparse.py:99-119); its last column is
+    -((1/d_i) * b_i) -- the reciprocal first, then the product -- which is the association kept here."""
     assert is_scipy_sparse(A) and A.shape[0] == A.shape[1]
-    n = A.shape[0] + 1
+    m = A.shape[0]
     L = sparse_affine_to_linear(A, bias=bias, dtype=np.float64)
     if not withinverse:
         return L.astype(dtype)
+    rdiag = 1.0 / np.asarray(A.diagonal(), dtype=np.float64)
     if bias is None:
-        return (L.astype(dtype), scipy.sparse.spdiags(1.0 / L.diagonal(), 0, n, n).tocoo().astype(dtype))
-    d = L.diagonal()
-    d[-1] = 0.5
-    Dinv = scipy.sparse.spdiags(1.0 / d, 0, n, n)
-    u = scipy.sparse.csr_matrix(np.vstack((bias, np.array([0.5]))))
-    v = scipy.sparse.csr_matrix(np.hstack((np.zeros_like(bias).flatten(), np.array([1.0]))))
-    Linv = Dinv - ((Dinv.dot(u).dot(v.dot(Dinv))) / float(1 + (v.dot(Dinv).dot(u).todense())))
-    return (L.astype(dtype), Linv.astype(dtype))
+        return (L.astype(dtype), scipy.sparse.spdiags(np.concatenate((rdiag, [1.0])), 0, m + 1, m + 1).tocoo().astype(dtype))
+    lastcol = -(rdiag * np.asarray(bias, dtype=np.float64).ravel())
+    nz = np.flatnonzero(lastcol)                                       # exact zeros are not stored
+    rows = np.concatenate((np.arange(m), nz, [m]))
+    cols = np.concatenate((np.arange(m), np.full(len(nz), m), [m]))
+    vals = np.concatenate((rdiag, lastcol[nz], [1.0]))
+    return (L.astype(dtype), scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(m + 1, m + 1)).astype(dtype))
 
 
 class _Ctx(object):

@@ -44,8 +44,24 @@ def _stored_order_csr(M):
     return (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), np.asarray(vals, dtype=np.float32)[order])
 
 
-def _run_torchdot(op, shape, x, relu=False, exact=True):
-    """Y = W.X on the GPU.  x: torch tensor [cols, N] (any device / strides).  Returns [rows, N] on x's device."""
+def _on_device(W, attr, make, device=None):
+    """Per-device cache of a container's operator handle: a kn_handle_t lives in ONE GPU's HBM, so it is created under the
+    device of the activations it will multiply (not whatever device happens to be current) and looked up by device index.
+    `W.<attr> = None` anywhere else drops every cached handle."""
+    idx = torch.cuda.current_device() if (device is None or device.index is None) else device.index
+    cache = getattr(W, attr, None)
+    if not isinstance(cache, dict):
+        cache = {}
+        setattr(W, attr, cache)
+    if idx not in cache:
+        with torch.cuda.device(idx):
+            cache[idx] = make()
+    return cache[idx]
+
+
+def _run_torchdot(get_op, shape, x, relu=False, exact=True):
+    """Y = W.X on the GPU.  x: torch tensor [cols, N] (any device / strides); get_op(device) -> the operator handle resident
+    on that device.  Returns [rows, N] on x's device."""
     assert shape[1] == x.shape[0], 'Non-conformal shape for W=%s, x=%s' % (str(shape), str(tuple(x.shape)))
     if not torch.cuda.is_available():
         raise _capi.KeynetHipError('keynet_amd: no MI355X visible -- the keyed forward has no CPU fallback')
@@ -61,7 +77,7 @@ def _run_torchdot(op, shape, x, relu=False, exact=True):
     y = torch.empty((shape[0], n), dtype=torch.float32, device=xd.device)
     flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if exact else 0)
     with torch.cuda.device(xd.device):
-        op.spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr())
+        get_op(xd.device).spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr())
     return y if src_device.type == 'cuda' else y.to(src_device)
 
 
@@ -94,45 +110,42 @@ class SparseMatrix(object):
         return self
 
     # -- device side
-    def _device_op(self):
-        if self._op is None:
+    def _device_op(self, device=None):
+        def make():
             M = self._matrix
             if isinstance(M, np.ndarray):
                 M = scipy.sparse.csr_matrix((np.asarray(M, dtype=np.float32).ravel(), np.tile(np.arange(M.shape[1]), M.shape[0]),
                                              np.arange(0, M.size + 1, M.shape[1])), shape=M.shape)
             (ip, ix, dt) = _stored_order_csr(M)
-            self._op = _capi.Operator.csr(self.shape, ip, ix, dt)
-        return self._op
+            return _capi.Operator.csr(self.shape, ip, ix, dt)
+        return _on_device(self, '_op', make, device)
 
     DENSE_MIN_ELEMENTS = 1 << 20
 
-    def _dense_device_op(self):
+    def _dense_device_op(self, device=None):
         """kn_dense_create handle for a (nearly) dense operator such as a keyed nn.Linear, or None when not eligible."""
         if getattr(self, '_matrix', None) is None:
             return None          # tiled containers have no single host matrix: never dense-eligible
-        if getattr(self, '_op_dense', None) is None:
+
+        def make():
             M = self._matrix
             (r, c) = self.shape
             ok = (M is not None and r * c >= self.DENSE_MIN_ELEMENTS and (c - 1) % 256 == 0 and
                   (M.nnz if is_scipy_sparse(M) else M.size) >= 0.5 * r * c)
             if ok:
                 D = np.asarray(M.todense() if is_scipy_sparse(M) else M, dtype=np.float32)
-                ok = bool(np.all(D[-1, :-1] == 0))
-                if ok:
-                    self._op_dense = _capi.Operator.dense(D)
-            if not ok:
-                self._op_dense = False
-        return self._op_dense or None
+                if bool(np.all(D[-1, :-1] == 0)):
+                    return _capi.Operator.dense(D)
+            return False
+        return _on_device(self, '_op_dense', make, device) or None
 
     def torchdot(self, x_torch, relu=False, exact=True):
         """W . x for x of shape [W.shape[1], N]: the hot path (keynet/sparse.py:488-492).  exact=True (default): bit-exact
         with scipy (order-preserving CSR kernels).  exact=False: a large dense operator (keyed nn.Linear) may run as a
         split-K f32-MFMA GEMM instead (within 1e-5; used by the tiled key-nets whose conv layers are on MFMA anyway)."""
-        if not exact:
-            op = self._dense_device_op()
-            if op is not None:
-                return _run_torchdot(op, self.shape, x_torch, relu=relu, exact=False)
-        return _run_torchdot(self._device_op(), self.shape, x_torch, relu=relu, exact=True)
+        if not exact and torch.cuda.is_available() and self._dense_device_op(x_torch.device if x_torch.is_cuda else None) is not None:
+            return _run_torchdot(self._dense_device_op, self.shape, x_torch, relu=relu, exact=False)
+        return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True)
 
     def dot(self, x_numpy):
         assert isinstance(x_numpy, np.ndarray)
@@ -233,17 +246,17 @@ class TiledMatrix(SparseMatrix):
         cat = (lambda L, dt: np.concatenate(L).astype(dt) if len(L) else np.zeros(0, dt))
         return (ptr, cat([t.row for t in tiles], np.int32), cat([t.col for t in tiles], np.int32), cat([t.data for t in tiles], np.float32))
 
-    def _device_op(self):
-        if self._op is None:
+    def _device_op(self, device=None):
+        def make():
             (ptr, tr, tc, tv) = self._tile_arrays()
-            self._op = _capi.Operator.tiled(self.shape, np.array(list(self), dtype=np.int64).reshape(-1, 3), ptr, tr, tc, tv)
-        return self._op
+            return _capi.Operator.tiled(self.shape, np.array(list(self), dtype=np.int64).reshape(-1, 3), ptr, tr, tc, tv)
+        return _on_device(self, '_op', make, device)
 
     def torchdot(self, x, relu=False, exact=True):
         """[cols, N] -> [rows, N] (keynet/sparse.py:603-612); always the order-preserving path (bit-exact)."""
         if isinstance(x, np.ndarray):
             x = torch.as_tensor(x)
-        return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=True)
+        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=True)
 
     def dot(self, x):
         assert isinstance(x, np.ndarray)
@@ -335,34 +348,39 @@ def _tile_sparse(T, tileshape):
 
 
 class DiagonalTiledMatrix(TiledMatrix):
-    """One block repeated down the main diagonal, identity remainder (keynet/sparse.py:657-687)."""
+    """One block repeated down the main diagonal; where the block does not divide the matrix, the last (partial) diagonal
+    position holds the matching corner of an identity instead (keynet/sparse.py:657-687)."""
 
     def __init__(self, B, shape):
         assert B.ndim == 2, 'Invalid block, must be 2D'
         assert isinstance(shape, tuple) and len(shape) == 2, 'invalid shape'
-        if B.shape[0] > shape[0] or B.shape[1] > shape[1]:
-            B = B.tocsr()[0:shape[0], 0:shape[1]]
-        if not scipy.sparse.issparse(B):
-            off = np.abs(np.min(B)) + 1.0
-            B = scipy.sparse.coo_matrix(B + off)
-            B.data -= off
-            B = B.tocsr()
-        self._tileshape = B.shape
-        self.shape = shape
-        self.dtype = B.dtype
-        self.ndim = 2
-        self._op = None
         (H, W) = shape
-        (h, w) = self._tileshape
+        if B.shape[0] > H or B.shape[1] > W:
+            B = B.tocsr()[0:H, 0:W]                            # an oversized block is clipped to the matrix
+        if not scipy.sparse.issparse(B):
+            B = _dense_block_as_sparse(B)
+        (h, w) = B.shape
+        (self._tileshape, self.shape, self.dtype, self.ndim, self._op, self._blocks) = ((h, w), shape, B.dtype, 2, None, None)
         self._tiles = [B.astype(np.float32)]
-        self._blocks = None
-        if (H % h != 0) or (W % w != 0):
+        if H % h or W % w:
             self._tiles.append(scipy.sparse.eye(max(h, w)).tocsr()[0:H % h, 0:W % w].astype(np.float32))
 
     def __iter__(self):
+        """(row0, col0, tile id) along the diagonal: tile 0 wherever the block fits strictly inside, else the last tile."""
         ((H, W), (h, w)) = (self.shape, self._tileshape)
-        for (i, j) in zip(range(0, H, h), range(0, W, w)):
-            yield (i, j, 0) if (i + h < H and j + w < W) else (i, j, len(self._tiles) - 1)
+        n = min(len(range(0, H, h)), len(range(0, W, w)))
+        (i, j) = (np.arange(n) * h, np.arange(n) * w)
+        k = np.where((i + h < H) & (j + w < W), 0, len(self._tiles) - 1)
+        return iter([(int(a), int(b), int(c)) for (a, b, c) in zip(i, j, k)])
+
+
+def _dense_block_as_sparse(B):
+    """Dense block -> CSR keeping EVERY entry stored, zeros included (shift by |min| + 1 before the conversion, shift the stored
+    values back afterwards): the tile then has the full h x w structure, as the reference's 'sparsity preserving' round trip."""
+    off = np.abs(np.min(B)) + 1.0
+    S = scipy.sparse.coo_matrix(B + off)
+    S.data -= off
+    return S.tocsr()
 
 
 class Conv2dTiledMatrix(TiledMatrix):
@@ -450,41 +468,138 @@ class Conv2dTiledMatrix(TiledMatrix):
         return (np.array(self._blocks, dtype=np.int64).reshape(-1, 3), np.array(keys, dtype=np.int64).reshape(-1, 3), isbias,
                 np.stack(chan) if len(chan) else np.zeros((0, Cout, Cin), np.float32), np.array(bvals, dtype=np.float32))
 
-    def _device_op(self):
-        if self._op is None:
+    def _device_op(self, device=None):
+        def make():
             if self._taps is not None:
                 t = self._taps
-                self._op = _capi.Operator.convtaps(self._inshape, self._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'], t['ent_coef'], t['lastcol'])
-            else:
-                (bl, tk, ib, ch, bs) = self._golden_arrays()
-                self._op = _capi.Operator.conv2dtiled(self.shape, self._inshape, self._outshape, bl, tk, ib, ch, bs)
-        return self._op
+                return _capi.Operator.convtaps(self._inshape, self._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'], t['ent_coef'], t['lastcol'])
+            (bl, tk, ib, ch, bs) = self._golden_arrays()
+            return _capi.Operator.conv2dtiled(self.shape, self._inshape, self._outshape, bl, tk, ib, ch, bs)
+        return _on_device(self, '_op', make, device)
 
     def torchdot(self, x, relu=False, exact=False):
         """[cols, N] -> [rows, N].  Default: f32 MFMA path (within 1e-5 of the reference); exact=True: the reference's
         accumulation order and rounding via the expanded CSR (small operators / parity tests)."""
         if isinstance(x, np.ndarray):
             x = torch.as_tensor(x)
-        return _run_torchdot(self._device_op(), self.shape, x, relu=relu, exact=exact)
+        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=exact)
 
-    def _expand_taps_host(self):
-        """Canonical CSR of a factored operator, on the host (small operators / tests; kn_export_csr does the same)."""
+    def _expand_taps_host(self, pixels=None, channels=None):
+        """Canonical CSR of a factored operator -- or of its output rows (co, o) for o in `pixels` only, numbered
+        co * len(pixels) + position of o -- on the host: the reference's expansion rule (keynet/sparse.py:802-812; kn_export_csr
+        does the same on the C side; `channels` further restricts the rows to the first `channels` output channels).  Built
+        directly in CSR order, one block copy + one table gather per output channel: row (co, o) holds,
+        for ci ascending, the pixel's slots by ascending input pixel, then the bias entry -- exactly the column-sorted row scipy's
+        csr_matrix((v,(r,c))) would produce, without ever holding a COO copy (conv5_1 of VGG-16: 420 M entries)."""
         t = self._taps
         (Cout, Hout, Wout) = self._outshape
         (Cin, Hin, Win) = self._inshape
         (HoWo, HiWi) = (Hout * Wout, Hin * Win)
-        coef = t['ent_coef'] if t['ent_coef'] is not None else np.ones(len(t['ent_out']), np.float32)
+        pixels = np.arange(HoWo, dtype=np.int64) if pixels is None else np.asarray(pixels, dtype=np.int64)
+        npx = len(pixels)
+        pos = -np.ones(HoWo, dtype=np.int64)
+        pos[pixels] = np.arange(npx)
+        sel = np.flatnonzero(pos[t['ent_out']] >= 0)
+        order = sel[np.lexsort((t['ent_in'][sel], pos[t['ent_out'][sel]]))]          # by (pixel position, input pixel), stable
+        (eo, ei, et) = (pos[t['ent_out'][order]], t['ent_in'][order].astype(np.int64), t['ent_tap'][order])
+        coef = None if t['ent_coef'] is None else t['ent_coef'][order]
+        if len(eo) > 1 and np.any((eo[1:] == eo[:-1]) & (ei[1:] == ei[:-1])):
+            assert channels is None, 'channel subsets are not supported for operators with duplicate (out, in) pairs'
+            return self._expand_taps_host_coo(pixels)
+        Cout = Cout if channels is None else int(channels)                                  # several taps on one (out, in) pair: scipy sums them
+        ns = np.bincount(eo, minlength=npx)                                           # slots per selected pixel
+        first = np.concatenate(([0], np.cumsum(ns)))[:-1]
+        has_last = t['lastcol'] is not None
+        rows_n = Cout * npx + (1 if (has_last and npx == HoWo and channels is None) else 0)
+        counts = np.tile(ns * Cin, Cout)
+        if has_last:
+            lastv = t['lastcol'][(np.arange(Cout)[:, None] * HoWo + pixels[None, :]).ravel()]
+            counts = counts + (lastv != 0)
+        if rows_n > Cout * npx:
+            counts = np.concatenate((counts, [1 if t['lastcol'][-1] != 0 else 0]))
+        indptr = np.zeros(rows_n + 1, dtype=np.int64)
+        np.cumsum(counts, out=indptr[1:])
+        total = int(indptr[-1])
+        idt = np.int32 if max(total, self.shape[1]) < 2 ** 31 - 1 else np.int64
+        indices = np.empty(total, dtype=idt)
+        data = np.empty(total, dtype=np.float32)
+        taps = t['taps']
+        ntaps = taps.shape[0]
+        # The Cout rows of a pixel share one column sequence, and the rows of one output channel are contiguous in the result:
+        # the channel's block is ONE copy of a precomputed column image and ONE gather from that channel's small [ntaps, Cin]
+        # value table.  The image is rebuilt only when the bias column's zero pattern differs between channels.
+        cached_mask = None
+        for co in range(Cout):
+            mask = (lastv[co * npx:(co + 1) * npx] != 0) if has_last else np.zeros(npx, dtype=bool)
+            if cached_mask is None or not np.array_equal(mask, cached_mask):
+                cached_mask = mask
+                cnt = ns * Cin + mask
+                loc = np.concatenate(([0], np.cumsum(cnt)))
+                col_img = np.empty(int(loc[-1]), dtype=idt)
+                src_img = np.zeros(int(loc[-1]), dtype=np.int64)                       # index into taps[:, co, :].ravel()
+                ent_img = np.zeros(int(loc[-1]), dtype=np.int64)                       # entry id (for the coefficients)
+                for k in np.unique(ns):
+                    if k == 0:
+                        continue
+                    P = np.flatnonzero(ns == k)
+                    g = first[P][:, None] + np.arange(k)[None, :]                      # [P, k] entry ids, input pixels ascending
+                    dest = loc[P][:, None] + np.arange(Cin * k)[None, :]
+                    col_img[dest] = ((np.arange(Cin) * HiWi)[None, :, None] + ei[g][:, None, :]).reshape(len(P), Cin * k)
+                    src_img[dest] = (et[g].astype(np.int64)[:, None, :] * Cin + np.arange(Cin)[None, :, None]).reshape(len(P), Cin * k)
+                    ent_img[dest] = np.broadcast_to(g[:, None, :], (len(P), Cin, k)).reshape(len(P), Cin * k)
+                bias_at = loc[1:][mask] - 1
+                col_img[bias_at] = self.shape[1] - 1
+            (lo, hi) = (int(indptr[co * npx]), int(indptr[(co + 1) * npx]))
+            indices[lo:hi] = col_img
+            v = taps[:, co, :].ravel()[src_img]
+            if coef is not None:
+                cf = coef[ent_img]
+                v = np.where(cf == 1.0, v, cf * v)
+            if has_last:
+                v[bias_at] = lastv[co * npx:(co + 1) * npx][mask]
+            data[lo:hi] = v
+        if rows_n > Cout * npx and t['lastcol'][-1] != 0:
+            indices[-1] = self.shape[1] - 1
+            data[-1] = t['lastcol'][-1]
+        return scipy.sparse.csr_matrix((data, indices, indptr.astype(idt)), shape=(rows_n, self.shape[1]))
+
+    def _expand_taps_host_coo(self, pixels):
+        """General route of _expand_taps_host (duplicate (out, in) pairs are summed by scipy's COO -> CSR conversion)."""
+        t = self._taps
+        (Cout, Hout, Wout) = self._outshape
+        (Cin, Hin, Win) = self._inshape
+        (HoWo, HiWi) = (Hout * Wout, Hin * Win)
+        npx = len(pixels)
+        pos = -np.ones(HoWo, dtype=np.int64)
+        pos[pixels] = np.arange(npx)
+        sel = np.flatnonzero(pos[t['ent_out']] >= 0)
+        coef = t['ent_coef'][sel] if t['ent_coef'] is not None else np.ones(len(sel), np.float32)
         (ic, jc) = np.meshgrid(np.arange(Cout), np.arange(Cin), indexing='ij')
-        rows = (t['ent_out'].astype(np.int64)[:, None, None] + (ic * HoWo)[None]).ravel()
-        cols = (t['ent_in'].astype(np.int64)[:, None, None] + (jc * HiWi)[None]).ravel()
-        tv = t['taps'][t['ent_tap']]
+        rows = (pos[t['ent_out'][sel]][:, None, None] + (ic * npx)[None]).ravel()
+        cols = (t['ent_in'][sel].astype(np.int64)[:, None, None] + (jc * HiWi)[None]).ravel()
+        tv = t['taps'][t['ent_tap'][sel]]
         vals = np.where(coef[:, None, None] == 1.0, tv, coef[:, None, None] * tv).astype(np.float32).ravel()
+        rows_n = Cout * npx
         if t['lastcol'] is not None:
-            nz = np.flatnonzero(t['lastcol'])
+            lastv = t['lastcol'][(np.arange(Cout)[:, None] * HoWo + pixels[None, :]).ravel()]
+            if npx == HoWo:
+                lastv = np.concatenate((lastv, t['lastcol'][-1:]))
+                rows_n += 1
+            nz = np.flatnonzero(lastv)
             rows = np.concatenate((rows, nz))
-            cols = np.concatenate((cols, np.full(len(nz), Cin * HiWi, dtype=np.int64)))
-            vals = np.concatenate((vals, t['lastcol'][nz]))
-        return scipy.sparse.csr_matrix((vals, (rows, cols)), shape=self.shape)
+            cols = np.concatenate((cols, np.full(len(nz), self.shape[1] - 1, dtype=np.int64)))
+            vals = np.concatenate((vals, lastv[nz]))
+        M = scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(rows_n, self.shape[1]))
+        M.sort_indices()
+        return M
+
+    def rows_csr(self, pixels=None, channels=None):
+        """Canonical CSR of the output rows (co, o), o in `pixels` (channel-major: row = co * len(pixels) + index of o), of a
+        factored operator: the reference's expansion rule (keynet/sparse.py:802-812) restricted to those rows.  Host side;
+        lets a CPU checker or a CPU baseline work on a slice of an operator whose full CSR would be tens of GB.  With every
+        pixel selected this is the whole operator incl. its homogeneous row."""
+        assert self._taps is not None, 'rows_csr needs the factored form (fromtaps / direct keying)'
+        return self._expand_taps_host(pixels, channels)
 
     def nnz(self):
         """Stored parameters: sum of tile sizes (keynet/sparse.py:778) -- or, for a factored operator, taps + entries +
@@ -610,15 +725,14 @@ def sparse_toeplitz_avgpool2d(inshape, filtershape, stride):
 
 
 def sparse_affine_to_linear(A, bias=None, dtype=np.float32):
-    """[[A, b], [0, 1]] (keynet/sparse.py:87-96)."""
+    """The homogeneous form [[A, b], [0, 1]] of x -> A x + b as one sparse matrix (keynet/sparse.py:87-96); b = 0 when no bias."""
     assert is_scipy_sparse(A)
+    (m, n) = A.shape
     if bias is not None:
-        assert bias.shape[0] == A.shape[0] and bias.shape[1] == 1
-        lastcol = scipy.sparse.coo_matrix(bias)
-    else:
-        lastcol = scipy.sparse.coo_matrix((A.shape[0], 1), dtype=dtype)
-    lastrow = scipy.sparse.coo_matrix(([1], ([0], [A.shape[1]])), shape=(1, A.shape[1] + 1), dtype=dtype)
-    return scipy.sparse.vstack((scipy.sparse.hstack((A, lastcol)), lastrow))
+        assert bias.shape[0] == m and bias.shape[1] == 1
+    b = scipy.sparse.coo_matrix(bias) if bias is not None else scipy.sparse.coo_matrix((m, 1), dtype=dtype)
+    one = scipy.sparse.coo_matrix(([1], ([0], [n])), shape=(1, n + 1), dtype=dtype)
+    return scipy.sparse.vstack((scipy.sparse.hstack((A, b)), one))
 
 
 def sparse_identity_matrix(n, dtype=np.float32):
@@ -626,7 +740,8 @@ def sparse_identity_matrix(n, dtype=np.float32):
 
 
 def sparse_permutation_matrix(n, dtype=np.float32, withinverse=False):
-    """Random permutation matrix from numpy's GLOBAL RNG, one np.random.permutation(n) draw (keynet/sparse.py:280-285)."""
-    col_ind = np.random.permutation(list(range(0, n)))
-    P = scipy.sparse.csr_matrix((np.ones(n).astype(dtype), (list(range(0, n)), col_ind)), shape=(n, n))
+    """Random n x n permutation matrix, row r holding its one in column perm[r]; ONE np.random.permutation(n) draw from numpy's
+    global RNG (keynet/sparse.py:280-285).  The inverse of a permutation matrix is its transpose."""
+    perm = np.random.permutation(n)
+    P = scipy.sparse.csr_matrix((np.ones(n, dtype=dtype), perm, np.arange(n + 1)), shape=(n, n))
     return (P, P.transpose()) if withinverse else P

@@ -144,6 +144,18 @@ class KeyedModel(object):
                 raise ValueError('unsupported module in a key-net: %s' % str(type(c)))
         return y
 
+    def exact_mode(self, flag):
+        """Switch every keyed layer between the two arithmetic contracts WITHOUT re-keying: True = the reference's accumulation
+        order and mul-then-add rounding in every layer (bit-exact with scipy: order-preserving kernels, no MFMA); False =
+        float-key tolerance (1e-5: conv-taps and large dense operators on the matrix cores); None = back to the per-layer
+        setting the key-net was built with.  Returns self."""
+        for c in self._keynet.children():
+            if isinstance(c, klayer.KeyedLayer):
+                if not hasattr(c, '_exact_built'):
+                    c._exact_built = getattr(c, '_exact', True)
+                c._exact = c._exact_built if flag is None else bool(flag)
+        return self
+
     def capture(self, img_cipher):
         """Capture forward_linear for this input shape into a HIP graph (torch.cuda.CUDAGraph on ROCm) and return a callable
         `replay(x) -> [N, classes+1]`.  Small key-nets are launch-bound (LeNet at N=1024: 7 kernels in 0.25 ms); one graph

@@ -65,11 +65,13 @@ def affine_to_linear_matrix(W_affine, bias=None):
 
 
 def fuse_conv2d_and_bn(conv2d_weight, conv2d_bias, bn_running_mean, bn_running_var, bn_eps, bn_weight, bn_bias):
-    """Fold an eval-mode BatchNorm2d into the preceding conv (keynet/torch.py:99-113)."""
-    scale = bn_weight / torch.sqrt(bn_running_var + np.float32(bn_eps))
-    b = conv2d_bias if conv2d_bias is not None else torch.zeros_like(bn_running_mean)
-    w = conv2d_weight * scale.reshape(-1, 1, 1, 1)
-    return (w, (b - bn_running_mean) * scale + bn_bias)
+    """Fold an eval-mode BatchNorm2d into the preceding conv (keynet/torch.py:99-113).  The association of the f32
+    operations is the reference's -- weights scaled by (bn_weight / std), bias as ((b - mean) / std) * bn_weight + bn_bias --
+    because the folded parameters feed the stored keyed operators, which must match bit for bit under the same seed."""
+    std = torch.sqrt(bn_running_var + np.float32(bn_eps))
+    b = conv2d_bias if conv2d_bias is not None else bn_running_mean.new_zeros(bn_running_mean.shape)
+    w = conv2d_weight * (bn_weight / std).reshape(-1, 1, 1, 1)
+    return (w, ((b - bn_running_mean) / std) * bn_weight + bn_bias)
 
 
 def count_parameters(model):

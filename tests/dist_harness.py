@@ -1,0 +1,76 @@
+"""World-size-N harness shared by the CPU (gloo, stand-in operator) and the GPU (gloo, REAL KeyedModel on a shared cuda:0)
+tests of the N>1 path: every rank builds the key-net, shards the same encrypted batch with keynet_amd.dist, runs its shard
+and all-gathers the logits; each rank reports whether the gathered result equals the single-process forward bit for bit."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from keynet_amd import dist as kdist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class StandInKeynet(object):
+    """A KeyedModel stand-in for a GPU-less box: a fixed linear map with a homogeneous column (the sharding and the
+    collective are what the CPU test covers; the kernels run in the GPU test through the same harness)."""
+    def __init__(self):
+        g = torch.Generator().manual_seed(0)
+        self.M = torch.randn(13, 5, generator=g)
+
+    def forward_linear(self, x):
+        return torch.cat((x[:, :-1] @ self.M, x[:, -1:]), dim=1)
+
+
+def make_case(kind, n):
+    """(knet, full encrypted batch [n, D+1]) -- identical on every rank."""
+    if kind == 'standin':
+        g = torch.Generator().manual_seed(1)
+        return (StandInKeynet(), torch.cat((torch.randn(n, 13, generator=g), torch.ones(n, 1)), dim=1))
+    from keynet_amd import io as kio
+    z = np.load(os.path.join(HERE, 'golden', {'lenet': 'lenet_perm.npz', 'tiled': 'mini_tiled_permutation.npz'}[kind]), allow_pickle=False)
+    knet = kio.keynet_from_arrays(z)
+    xc = torch.as_tensor(z['x_cipher'])
+    reps = (n + xc.shape[0] - 1) // xc.shape[0]
+    x = torch.cat([xc] * reps, dim=0)[:n].clone()
+    x[:, :-1] += 0.01 * torch.arange(n, dtype=torch.float32)[:, None]       # distinct rows, so a mis-ordered gather cannot pass
+    return (knet, x.to('cuda:0'))
+
+
+def worker(rank, world_size, port, kind, n, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        (knet, x) = make_case(kind, n)
+        y = kdist.sharded_forward(knet, x)                     # this rank's shard through the real path + all-gather
+        ref = knet.forward_linear(x)[:, :-1]                   # the single-process result of the SAME batch
+        (lo, hi) = kdist.shard_bounds(n, rank, world_size)
+        q.put((rank, bool(torch.equal(y, ref)), (lo, hi), tuple(y.shape), str(y.device)))
+    finally:
+        dist.destroy_process_group()
+
+
+def run(kind, n, world_size=2, timeout=300):
+    ctx = mp.get_context('spawn')        # fresh processes: a forked child must never inherit an initialised GPU runtime
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world_size, port, kind, n, q)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=timeout) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res

@@ -15,6 +15,8 @@ Fixtures:
   F4 tiled_cases.npz     TiledMatrix / Conv2dTiledMatrix / DiagonalTiledMatrix cases mirroring test/test_sparse.py:122-199
   F5 allconv_tiny_perm.npz  reduced-channel AllConvNet-shaped PermutationKeynet (stride 2, 1x1 conv, dropout bypass)
   F6 keygen_cases.npz    (A, Ainv) of keynet.system.keygen for every key family on small shapes (host-keying parity)
+  F7 bn_tiny_{perm,identity}.npz  conv -> '<conv>_bn' BatchNorm2d (random running stats) -> dropout -> relu nets: the batch-norm fold
+                         (keynet/torch.py:99-113) feeds the stored operators, so its f32 association is part of the contract
 """
 import os
 import sys
@@ -380,6 +382,64 @@ def f5():
     return save('allconv_tiny_perm.npz', out, manifest)
 
 
+class TinyBN(nn.Module):
+    """Generator-owned net with the batch-norm placement of AllConvNet(batchnorm=True) (keynet/cifar10.py:14-45):
+    conv -> '<conv>_bn' -> dropout -> relu, twice (stride 2 and stride 1), then a Linear."""
+    def __init__(self):
+        super(TinyBN, self).__init__()
+        self.conv1 = nn.Conv2d(3, 6, 3, padding=1)
+        self.relu1 = nn.ReLU()
+        self.conv3 = nn.Conv2d(6, 8, 3, padding=1, stride=2)
+        self.conv3_bn = nn.BatchNorm2d(8)
+        self.dropout3 = nn.Dropout(p=0.5)
+        self.relu3 = nn.ReLU()
+        self.conv4 = nn.Conv2d(8, 5, 3, padding=1)
+        self.conv4_bn = nn.BatchNorm2d(5)
+        self.relu4 = nn.ReLU()
+        self.fc1 = nn.Linear(5 * 4 * 4, 7)
+
+    def forward(self, x):
+        x = self.relu1(self.conv1(x))
+        x = self.relu3(self.dropout3(self.conv3_bn(self.conv3(x))))
+        x = self.relu4(self.conv4_bn(self.conv4(x)))
+        return self.fc1(x.view(-1, 5 * 4 * 4))
+
+
+def randomize_bn(net, seed):
+    """Non-trivial eval-mode statistics and affine parameters (a fresh BatchNorm2d folds to the identity)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g))
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) * 2 + 0.25)
+            m.weight.data.copy_(torch.randn(m.num_features, generator=g))
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g))
+
+
+def f7():
+    import warnings
+    ms = []
+    for (tag, factory) in [('perm', lambda s, n: keynet.system.PermutationKeynet(s, n)), ('identity', lambda s, n: keynet.system.IdentityKeynet(s, n))]:
+        torch.manual_seed(0)
+        net = TinyBN().eval()
+        randomize_bn(net, 3)
+        np.random.seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (sensor, knet) = factory((3, 8, 8), net)
+        out = {}
+        manifest = {'layers': {}, 'recipe': 'torch.manual_seed(0); TinyBN(); randomize_bn(net, 3); np.random.seed(0); %s((3,8,8), net); torch.manual_seed(1); x=randn(5,3,8,8)' % tag}
+        state_arrays(net, out)
+        torch.manual_seed(1)
+        x = torch.randn(5, 3, 8, 8)
+        dump_keynet(sensor, knet, net, x, out, manifest)
+        err = np.abs(out['logits_keyed'] - out['logits_plain']).max()
+        print('tiny bn %s: |keyed-plain|=%g' % (tag, err))
+        assert err < 1e-4
+        ms.append(save('bn_tiny_%s.npz' % tag, out, manifest))
+    return ms
+
+
 from keygen_case_table import KEYGEN_CASES  # noqa: E402  (pure data: names, shapes, keyword arguments)
 
 
@@ -407,12 +467,12 @@ def f6():
 
 if __name__ == '__main__':
     os.chdir('/tmp')
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7']
     mf = os.path.join(HERE, 'MANIFEST.json')
     manifest = json.load(open(mf)) if os.path.exists(mf) else {}
     manifest['_versions'] = {'numpy': np.__version__, 'scipy': scipy.__version__, 'torch': torch.__version__, 'python': sys.version.split()[0]}
     for w in which:
-        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5, 'f6': f6}[w]()
+        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5, 'f6': f6, 'f7': f7}[w]()
         manifest[w] = r
     with open(mf, 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -46,6 +46,24 @@ class TinyAllConv(_Chain):
         self.fc2 = nn.Linear(12, 10)
 
 
+class TinyBN(_Chain):
+    """conv -> '<conv>_bn' -> dropout -> relu (the batch-norm placement of AllConvNet(batchnorm=True)), see make_golden.py f7."""
+    flatten_before = 'fc1'
+
+    def __init__(self):
+        super(TinyBN, self).__init__()
+        self.conv1 = nn.Conv2d(3, 6, 3, padding=1)
+        self.relu1 = nn.ReLU()
+        self.conv3 = nn.Conv2d(6, 8, 3, padding=1, stride=2)
+        self.conv3_bn = nn.BatchNorm2d(8)
+        self.dropout3 = nn.Dropout(p=0.5)
+        self.relu3 = nn.ReLU()
+        self.conv4 = nn.Conv2d(8, 5, 3, padding=1)
+        self.conv4_bn = nn.BatchNorm2d(5)
+        self.relu4 = nn.ReLU()
+        self.fc1 = nn.Linear(5 * 4 * 4, 7)
+
+
 def load_weights(net, z):
     """Copy the 'net.*' arrays of a golden file into `net` (same parameter names)."""
     sd = {k[4:]: torch.as_tensor(np.array(z[k])) for k in z.files if k.startswith('net.')}

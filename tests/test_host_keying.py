@@ -7,7 +7,7 @@ import torch
 import keynet_amd.system as ksys
 import keynet_amd.sparse as ksp
 from keynet_amd.layer import KeyedLayer
-from nets import LeNet_AvgPool, MiniNet, TinyAllConv, load_weights
+from nets import LeNet_AvgPool, MiniNet, TinyAllConv, TinyBN, load_weights
 
 
 def _check_layers(z, knet):
@@ -74,6 +74,21 @@ def test_tiled_keynets_match_reference(golden, tag, tilesize):
     np.random.seed(0)
     factory = ksys.TiledIdentityKeynet if tag == 'identity' else ksys.TiledPermutationKeynet
     (sensor, knet) = factory((2, 16, 16), net, tilesize)
+    _check_sensor(z, sensor)
+    _check_layers(z, knet)
+
+
+@pytest.mark.parametrize('tag', ['perm', 'identity'])
+def test_batchnorm_fold_matches_reference(golden, tag):
+    """conv -> '<conv>_bn' -> (dropout) -> relu: the folded conv (keynet/torch.py:99-113 association) and the separately keyed
+    ReLU reproduce the reference's stored operators bit for bit (random running statistics, so the fold is not the identity)."""
+    import warnings
+    z = golden('bn_tiny_%s.npz' % tag)
+    net = load_weights(TinyBN(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = (ksys.PermutationKeynet if tag == 'perm' else ksys.IdentityKeynet)((3, 8, 8), net)
     _check_sensor(z, sensor)
     _check_layers(z, knet)
 

@@ -64,3 +64,14 @@ def test_hierarchical_permutation_matrix_is_the_image_permutation():
         assert np.array_equal(P.dot(img.flatten()).reshape(img.shape), ref)
         assert np.array_equal(Pinv.dot(P.dot(img.flatten())), img.flatten())
         assert not np.array_equal(ref, img)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference is only mounted in the build container')
+def test_generators_against_reference_randomised():
+    """tests/golden/diff_generators.py: every rewritten generator against the reference itself on randomised arguments (same seed
+    -> same matrix, same stored triplets, same RNG consumption).  Runs in a subprocess: importing the reference needs stand-ins for
+    third-party packages that must not leak into this process."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'diff_generators.py')],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and 'ALL OK' in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

@@ -15,7 +15,7 @@ from nets import LeNet_AvgPool, MiniNet, TinyAllConv, load_weights
 
 pytestmark = pytest.mark.gpu
 
-EXACT_NETS = ['lenet_perm.npz', 'allconv_tiny_perm.npz']
+EXACT_NETS = ['lenet_perm.npz', 'allconv_tiny_perm.npz', 'bn_tiny_perm.npz', 'bn_tiny_identity.npz']
 TILED_NETS = ['mini_tiled_identity.npz', 'mini_tiled_permutation.npz', 'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz']
 TOL = 1e-5   # north_star: within 1e-5 for float keyed layers (MFMA path); bit-exact elsewhere
 
@@ -226,6 +226,103 @@ def test_dense_linear_mfma_vs_oracle(n_vecs):
     small = ksp.SparseMatrix(Ms)
     assert small._dense_device_op() is None                                       # not eligible -> exact CSR path
     assert np.array_equal(small.torchdot(xd, exact=False).cpu().numpy(), oracle.csr_matvecs(Ms.shape, Ms.indptr, Ms.indices, Ms.data, X))
+
+
+def test_dense_handle_on_two_streams_concurrently():
+    """include/keynet_hip.h: one handle may be driven from several streams at once.  A dense (split-K MFMA) operator keeps its
+    partial sums in a PER-STREAM workspace: two streams hammering one handle with different inputs (and batch sizes that force
+    the workspace to grow mid-flight) must each reproduce what a lone stream computes, bit for bit."""
+    rng = np.random.RandomState(11)
+    (outs, ins) = (512, 2048)
+    D = np.zeros((outs + 1, ins + 1), dtype=np.float32)
+    D[:-1, :-1] = (rng.randn(outs, ins) / np.sqrt(ins)).astype(np.float32)
+    D[:-1, -1] = rng.randn(outs).astype(np.float32)
+    D[-1, -1] = 1.0
+    W = ksp.SparseMatrix(D)
+    d = dev()
+    op = W._dense_device_op(d)
+    assert op is not None
+
+    def inputs(n, seed):
+        g = torch.Generator(device=d).manual_seed(seed)
+        x = torch.randn((ins + 1, n), generator=g, device=d)
+        x[-1] = 1.0
+        return x
+    xs = [inputs(128, 1), inputs(384, 2), inputs(256, 3), inputs(640, 4)]
+    lone = []
+    for x in xs:                                                # reference: one stream, one call at a time
+        y = torch.empty((outs + 1, x.shape[1]), device=d)
+        op.spmm(x.data_ptr(), x.shape[1], x.shape[1], y.data_ptr(), x.shape[1], 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        lone.append(y)
+    W2 = ksp.SparseMatrix(D)                                    # a fresh handle: workspaces start empty and must grow under load
+    op2 = W2._dense_device_op(d)
+    streams = [torch.cuda.Stream(device=d), torch.cuda.Stream(device=d)]
+    outs_ = [[None] * len(xs) for _ in streams]
+    for rep in range(6):
+        for (k, x) in enumerate(xs):
+            for (si, st) in enumerate(streams):
+                xi = xs[(k + si) % len(xs)]                     # the two streams work on DIFFERENT inputs at the same time
+                y = torch.empty((outs + 1, xi.shape[1]), device=d)
+                st.wait_stream(torch.cuda.current_stream())
+                op2.spmm(xi.data_ptr(), xi.shape[1], xi.shape[1], y.data_ptr(), xi.shape[1], 0, st.cuda_stream)
+                outs_[si][(k + si) % len(xs)] = y
+    torch.cuda.synchronize()
+    for si in range(len(streams)):
+        for k in range(len(xs)):
+            assert torch.equal(outs_[si][k], lone[k]), (si, k)
+
+
+def test_operator_is_bound_to_its_device():
+    """kn_spmm refuses a handle that lives on another device than the current one (KN_ERR_INVALID) instead of dereferencing
+    foreign memory; the Python containers create and cache their handles per device of the activations."""
+    W = ksp.SparseMatrix(scipy.sparse.eye(6, dtype=np.float32).tocsr())
+    x = torch.ones(6, 3).to(dev())
+    assert torch.equal(W.torchdot(x), x)
+    assert isinstance(W._op, dict) and list(W._op.keys()) == [dev().index if dev().index is not None else 0]
+    if torch.cuda.device_count() > 1:
+        op = W._device_op(dev())
+        y = torch.empty(6, 3, device='cuda:1')
+        with torch.cuda.device(1):
+            with pytest.raises(_capi.KeynetHipError):
+                op.spmm(x.data_ptr(), 3, 3, y.data_ptr(), 3, 0, torch.cuda.current_stream().cuda_stream)
+            x1 = x.to('cuda:1')
+            assert torch.equal(W.torchdot(x1), x1) and sorted(W._op.keys()) == [0, 1]
+
+
+def test_empty_operator_arrays():
+    """An all-zero operator (nnz == 0: numpy hands over non-null pointers to empty arrays) must not read host memory."""
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((5, 7), dtype=np.float32))
+    y = W.torchdot(torch.ones(7, 4).to(dev()))
+    assert tuple(y.shape) == (5, 4) and float(y.abs().max()) == 0.0
+
+
+def test_padded_contraction_rows_do_not_leak_nan():
+    """Cin = 3 on the chunked MFMA kernel (KC = 4: one zero-padded contraction row per chunk; a 5x5 window keeps the operator off
+    the one-shot small-K kernel): the padding rows are stored as zeros, so NaN / Inf in live activations reach exactly the outputs
+    whose window contains them -- the same rows as on the order-preserving path -- and every other output stays finite and
+    within tolerance."""
+    rng = np.random.RandomState(3)
+    (Cin, Cout, H) = (3, 64, 8)
+    from keynet_amd import direct as kdirect
+    (eo, ei, et) = ([], [], [])
+    for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((H, H), 5, 1)):
+        S = S.tocoo()
+        eo.append(S.row); ei.append(S.col); et.append(np.full(S.nnz, t))
+    taps = rng.randn(25, Cout, Cin).astype(np.float32)
+    lastcol = np.concatenate((rng.randn(Cout * H * H), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), None, lastcol)
+    x = torch.randn(Cin * H * H + 1, 256, device=dev())
+    x[-1] = 1.0
+    x[2 * H * H + 3 * H + 3, :] = float('nan')      # pixel (3,3) of the LAST channel: 25 windows contain it
+    x[1 * H * H + 0, 7] = float('inf')              # and one Inf in a corner pixel of channel 1, one image only
+    y = W.torchdot(x, exact=False)
+    ye = W.torchdot(x, exact=True)
+    bad = ~torch.isfinite(ye)
+    assert bool(torch.equal(~torch.isfinite(y), bad)), 'non-finite pattern of the MFMA path differs from the order-preserving path'
+    assert int(torch.isnan(ye).any(dim=1).sum()) == 25 * Cout
+    ok = ~bad
+    assert float((y[ok] - ye[ok]).abs().max()) <= 1e-5 * max(1.0, float(ye[ok].abs().max()))
 
 
 @pytest.mark.parametrize('n_vecs', [1, 3, 64, 130, 256, 1024, 2048])

@@ -65,30 +65,6 @@ def test_keyed_vgg16_equals_plain_network(vgg):
     assert np.allclose(y128.cpu().numpy(), y256[:128].cpu().numpy(), atol=1e-4)
 
 
-def _rows_csr(W, pixels):
-    """Canonical CSR of the rows (co, o), o in `pixels`, of a factored conv operator (the reference's expansion rule,
-    keynet/sparse.py:802-812, restricted to those rows) -- small enough for the CPU oracle at full layer size."""
-    import scipy.sparse
-    t = W._taps
-    (Cout, Hout, Wout) = W._outshape
-    (Cin, Hin, Win) = W._inshape
-    sel = np.isin(t['ent_out'], pixels)
-    remap = -np.ones(Hout * Wout, dtype=np.int64)
-    remap[pixels] = np.arange(len(pixels))
-    (ic, jc) = np.meshgrid(np.arange(Cout), np.arange(Cin), indexing='ij')
-    rows = (remap[t['ent_out'][sel]][:, None, None] + (ic * len(pixels))[None]).ravel()
-    cols = (t['ent_in'][sel].astype(np.int64)[:, None, None] + (jc * Hin * Win)[None]).ravel()
-    vals = t['taps'][t['ent_tap'][sel]].ravel()
-    last = t['lastcol'][(np.arange(Cout)[:, None] * Hout * Wout + np.asarray(pixels)[None, :]).ravel()]
-    nz = np.flatnonzero(last)
-    rows = np.concatenate((rows, nz))
-    cols = np.concatenate((cols, np.full(len(nz), W.shape[1] - 1, dtype=np.int64)))
-    vals = np.concatenate((vals, last[nz]))
-    M = scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(Cout * len(pixels), W.shape[1]))
-    M.sort_indices()
-    return M
-
-
 def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
     """KN_FLAG_EXACT on the real conv1_2 (3.2M x 3.2M, 1.84 G nnz) and conv4_2 (401k x 401k, 1.76 G nnz) operators: the
     order-preserving kernel on the factored operator equals the CPU oracle (scipy csr_matvecs restated) bit for bit on
@@ -110,7 +86,7 @@ def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
             ym = W.torchdot(xin, relu=True, exact=False)
             (Cout, Hout, Wout) = W._outshape
             pix = np.sort(rng.choice(Hout * Wout, size=6, replace=False))
-            M = _rows_csr(W, pix)
+            M = W.rows_csr(pix)
             ref = np.maximum(oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), xin.cpu().numpy()), 0)
             rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
             assert np.array_equal(ye.cpu().numpy()[rows], ref), name
