@@ -1,0 +1,80 @@
+"""BASELINE configs[2] at FULL size on the GPU: PermutationKeynet AllConvNet (3,32,32), width 96, batch 4096 -- the global
+permutation key makes every layer a plain stored-order CSR (261.6 M non-zeros, 2.09 GB), applied by the order-preserving
+kernels.  The CPU oracle is fast enough to run EVERY layer of the full-width net on the first images, so parity at this size is
+direct: per layer, bit for bit (reference anchors: keynet/cifar10.py:14-65, test/test_keynet.py:222-261)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from keynet_amd import system as ksys
+from keynet_amd import sparse as ksp
+from keynet_amd.layer import KeyedLayer
+from keynet_amd.models import AllConvNet
+
+pytestmark = pytest.mark.gpu
+
+BATCH = 4096
+N_CHECK = 8
+
+
+@pytest.fixture(scope='module')
+def allconv():
+    assert torch.cuda.is_available()
+    torch.manual_seed(0)
+    net = AllConvNet(batchnorm=False).eval()
+    np.random.seed(0)
+    (sensor, knet) = ksys.PermutationKeynet((3, 32, 32), net)
+    return (net, sensor, knet)
+
+
+def test_operator_sizes_match_the_survey(allconv):
+    (net, sensor, knet) = allconv
+    layers = {n: c for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)}
+    expect = {'conv1': ((98305, 3073), 2643073), 'conv2': ((98305, 98305), 81530881), 'conv3': ((24577, 98305), 20382721), 'conv5': ((49153, 49153), 78053377),
+              'conv8': ((12289, 12289), 2371585), 'conv9': ((641, 12289), 123521), 'fc1': ((101, 641), 64101), 'fc2': ((11, 101), 1011)}
+    for (n, (shape, nnz)) in expect.items():
+        assert type(layers[n].W) is ksp.SparseMatrix and tuple(layers[n].W.shape) == shape and layers[n].W.nnz() == nnz, n
+    assert knet.num_parameters() == 261589345          # SURVEY appendix A total
+
+
+def test_every_layer_bit_exact_at_full_width_and_batch(allconv):
+    """B = 4096 through the HIP path; the oracle (scipy csr_matvecs restated) recomputes the first 8 images through every layer of
+    the same full-width operators: equal bit for bit, layer by layer, incl. the fused ReLUs and the final logits."""
+    (net, sensor, knet) = allconv
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn((BATCH, 3, 32, 32), generator=g, device=dev)
+    xc = sensor.fromtensor(x).encrypt().astensor()
+    assert tuple(xc.shape) == (BATCH, 3073)
+    children = list(knet._keynet.named_children())
+    y = xc
+    yo = xc[:N_CHECK].cpu().numpy()                          # the oracle's copy of the first images, advanced layer by layer
+    perm_in = sensor._encryptkey.tocsr()
+    assert np.array_equal(yo[:, :-1], x[:N_CHECK].reshape(N_CHECK, -1).cpu().numpy()[:, perm_in.indices[:-1]])   # permutation image key = exact gather
+    i = 0
+    checked = 0
+    while i < len(children):
+        (name, c) = children[i]
+        assert isinstance(c, KeyedLayer), name
+        fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+        y = c.forward(y, fuse_relu=fuse)
+        (ip, ix, dt) = ksp._stored_order_csr(c.W._matrix)
+        yo = oracle.csr_matvecs(c.W.shape, ip, ix, dt, np.ascontiguousarray(yo.T)).T
+        if fuse:
+            yo = np.maximum(yo, 0)
+        assert np.array_equal(y[:N_CHECK].cpu().numpy(), yo), 'layer %s differs from the oracle' % name
+        checked += 1
+        i += 2 if fuse else 1
+    assert checked == 11
+    logits = y[:, :-1]
+    assert bool(torch.isfinite(logits).all()) and bool((y[:, -1] == 1).all())          # the homogeneous coordinate survives 11 layers exactly
+    with torch.no_grad():
+        plain = net(x[:N_CHECK].cpu()).numpy()
+    assert np.allclose(logits[:N_CHECK].cpu().numpy(), plain, atol=1e-4)                # the reference's integration criterion
+    # batch-column independence: the same images as a batch of 4 take other kernel instantiations (narrower vectors, thinner row
+    # bundles) yet every output element sees the same ordered sum: bit-identical to their columns in the 4096-image run
+    y4 = knet.forward_linear(xc[:4])
+    assert torch.equal(y4, y[:4])
+    y1027 = knet.forward_linear(xc[:1027])                                              # ragged batch
+    assert torch.equal(y1027, y[:1027])

@@ -101,6 +101,38 @@ def test_tiled_keynet_layers(golden, name):
     assert np.allclose(out[:, :-1], z['logits_plain'], atol=1e-4)      # the reference's criterion is 1e-5..1e-3 (test_keynet.py)
 
 
+@pytest.mark.parametrize('name', ['mini_tiled_orthogonal.npz', 'mini_tiled_permutation.npz'])
+def test_float_key_error_is_no_worse_than_the_references_own(golden, name):
+    """Evidence for the conditioned bound above.  Per keyed conv layer (inputs = the reference's own previous-layer outputs) the
+    float64 product of the stored f32 operator is the truth; the reference's f32 output (scipy: every product AND every sum
+    rounded) misses it by e_ref, the MFMA path (one rounding per term) by e_hip.  The orthogonal family's gamma = 100 bias key
+    makes e_ref itself exceed 1e-5, so an absolute 1e-5 against the reference cannot be demanded of ANY f32 evaluation; what can
+    is that the HIP path is at least as close to the truth as the reference is: max error within 2x, RMS error within 1.25x
+    (measured: the MFMA errors are smaller), and the absolute 1e-5 contract wherever the reference itself meets it."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    prev = z['x_cipher']
+    report = []
+    for (lname, child) in knet._keynet.named_children():
+        ref = z['Y.%s' % lname]
+        if isinstance(child, KeyedLayer) and isinstance(child.W, ksp.Conv2dTiledMatrix):
+            (shape, ip, ix, dt) = oracle.operator_from_golden(z, 'L.%s.' % lname)
+            W64 = scipy.sparse.csr_matrix((dt.astype(np.float64), ix, ip), shape=shape)
+            truth = W64.dot(prev.T.astype(np.float64)).T                      # [N, Dout+1]; no ReLU inside a KeyedLayer of these nets
+            y = child.forward(torch.as_tensor(prev).to(dev())).cpu().numpy()
+            (e_ref, e_hip) = (np.abs(ref.astype(np.float64) - truth), np.abs(y.astype(np.float64) - truth))
+            report.append((lname, float(e_ref.max()), float(e_hip.max()), float(np.sqrt((e_ref ** 2).mean())), float(np.sqrt((e_hip ** 2).mean()))))
+            assert e_hip.max() <= 2.0 * e_ref.max() + 1e-7, report[-1]
+            assert np.sqrt((e_hip ** 2).mean()) <= 1.25 * np.sqrt((e_ref ** 2).mean()) + 1e-8, report[-1]
+            if e_ref.max() <= 0.5e-5 * max(1.0, float(np.abs(truth).max())):
+                assert np.abs(y - ref).max() <= 1e-5 * max(1.0, float(np.abs(ref).max())), report[-1]
+        prev = ref
+    print('float-key error vs f64 truth (layer, max ref, max hip, rms ref, rms hip):', report)
+    assert len(report) == 2
+    if 'orthogonal' in name:
+        assert max(r[1] for r in report) > 1e-5      # the premise: the reference's own f32 result is further than 1e-5 from the truth
+
+
 def test_export_csr_matches_reference_tocsr(golden):
     z = golden('mini_tiled_permutation.npz')
     for lname in ('conv1', 'conv2', 'pool1'):
