@@ -97,7 +97,22 @@ struct ConvArgs {
     int32_t n_mt, n_bt, n_pix, max_slots, ntaps, wide_store;
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
     int32_t tail_main;     // work items per XCD chunk computed as full tiles; the rest of the chunk runs as 4 quarter tiles each
+    int32_t bt_inner;      // item order: 0 = (bt, pixel, mt) with the batch tile slowest; 1 = (pixel, bt, mt): an XCD owns a pixel range for every batch tile
+    int32_t prio_stagger;  // small-K kernel: co-resident workgroups take different wave priorities (breaks the lockstep of their phases)
 };
+
+// item -> (Cout tile, position in the pixel order, batch tile); the Cout tile is always fastest (its workgroups share one gathered X tile)
+__device__ __forceinline__ void decode_conv_item(const ConvArgs& p, const int64_t item, int& mt, int& pi, int& bt) {
+    mt = (int)(item % p.n_mt);
+    const int64_t t1 = item / p.n_mt;
+    if (p.bt_inner) {
+        bt = (int)(t1 % p.n_bt);
+        pi = (int)(t1 / p.n_bt);
+    } else {
+        pi = (int)(t1 % p.n_pix);
+        bt = (int)(t1 / p.n_pix);
+    }
+}
 
 // FAST = (batch 16-byte aligned and a multiple of the batch tile NB) && (all coefficients 1: identity / permutation keys) && (Cin % KC == 0):
 // the loaders are straight-line code, so the next chunk's global loads stay in flight in registers during the MFMAs.
@@ -449,10 +464,8 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
         quad = (int)(t & 3);
     }
     if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
-    const int mt = (int)(item % p.n_mt);
-    const int64_t t1 = item / p.n_mt;
-    const int pi = (int)(t1 % p.n_pix);
-    const int bt = (int)(t1 / p.n_pix);
+    int mt, pi, bt;
+    decode_conv_item(p, item, mt, pi, bt);
     const int o = p.pix_order[pi];
     if constexpr (TAIL) {
         if (quad >= 0) {
@@ -481,10 +494,17 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
     const int64_t xl = blockIdx.x & 7;
     const int64_t item = xl * chunk + (blockIdx.x >> 3);
     if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
-    const int mt = (int)(item % p.n_mt);
-    const int64_t t1 = item / p.n_mt;
-    const int pi = (int)(t1 % p.n_pix);
-    const int bt = (int)(t1 / p.n_pix);
+    int mt, pi, bt;
+    decode_conv_item(p, item, mt, pi, bt);
+    if (p.prio_stagger) {
+        // Workgroups that share a CU run the same three phases (gather / MFMA / store) and, arbitrated fairly, stay in lockstep:
+        // each phase is then bound by its own resource in bursts and the phases ADD.  Distinct static priorities let one
+        // workgroup's waves win the matrix pipe, finish, and move on to their stores while the others compute.
+        const unsigned q = (unsigned)(blockIdx.x >> 3) & 3u;
+        if (q == 1) __builtin_amdgcn_s_setprio(1);
+        else if (q == 2) __builtin_amdgcn_s_setprio(2);
+        else if (q == 3) __builtin_amdgcn_s_setprio(3);
+    }
     const int o = p.pix_order[pi];
     const int m0 = mt * MT;
     const int b0 = bt * NB;
@@ -830,29 +850,44 @@ static int64_t xcd_slots(K kernel) {
     return (int64_t)occ * (prop.multiProcessorCount / 8);
 }
 
+// Dynamic LDS that caps a kernel at `want` workgroups per CU (0 = no cap): the smallest allocation of which want + 1 copies no
+// longer fit the CU's 160 KiB.  The kernel never touches it.
+static unsigned lds_pad_for_occupancy(size_t static_lds, int want) {
+    if (want <= 0) return 0;
+    const size_t total = 160 * 1024;
+    const size_t need = total / (size_t)(want + 1) + 256;           // per-workgroup footprint that admits only `want`
+    if (need <= static_lds) return 0;
+    const size_t pad = need - static_lds;
+    return (static_lds + pad <= 64 * 1024) ? (unsigned)pad : 0;     // beyond 64 KiB per workgroup needs a function attribute: not used
+}
+
 template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(ConvArgs a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t chunk = (items + 7) / 8;
+    const int occ_cap = getenv("KN_OCC") ? atoi(getenv("KN_OCC")) : 0;            // experiment knob, read per call
+    constexpr size_t static_lds = sizeof(float) * (2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS + 2 * (MT + NB));
+    const unsigned pad = lds_pad_for_occupancy(static_lds, occ_cap);
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     a.tail_main = (int32_t)chunk;
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
         static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
         if (fast && a.wide_store && !no_tail) {
-            static const int64_t slots = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>);
+            static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>);
+            const int64_t slots = (pad > 0 && slots_free > 0) ? std::min<int64_t>(slots_free, (int64_t)occ_cap * 32) : slots_free;
             const int64_t rem = slots > 0 ? chunk % slots : 0;
             if (rem > 0) {   // the last, partial round of resident workgroups (measured: pays even when it fills half the machine)
                 a.tail_main = (int32_t)(chunk - rem);
                 const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
-                hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 return;
             }
         }
     }
     const int64_t grid = 8 * chunk;
-    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
@@ -883,6 +918,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
     a.last_in_row = A.Cin * A.Hin * A.Win;
+    const int bt_inner = getenv("KN_BT_INNER") ? atoi(getenv("KN_BT_INNER")) : 0;              // experiment knobs, read per call
+    const int prio_stagger = getenv("KN_SMALLK_PRIO") ? atoi(getenv("KN_SMALLK_PRIO")) : 0;
+    a.bt_inner = bt_inner;
+    a.prio_stagger = prio_stagger;
+    a.tail_main = 0;
     if (flags & KN_FLAG_EXACT) {
         const bool v4 = a.vec_ok && n_vecs >= 256;
         const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
