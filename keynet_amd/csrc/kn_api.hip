@@ -238,7 +238,41 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     h->nnz_expanded = (int64_t)nent * Cout * Cin + (int64_t)b.last_rows.size();
     h->nnz_stored = b.nnz_stored > 0 ? b.nnz_stored : ntaps * Cout * Cin + (int64_t)nent + (int64_t)b.last_rows.size();
 
-    if ((rc = upload(&c.tapsT, tapsT.data(), tapsT.size())) || (rc = upload(&c.pix_ptr, pix_ptr.data(), pix_ptr.size())) ||
+    // small-K pipeline descriptors (layout: kn_conv.hip SK_DESC_HDR): eligible when one pixel's whole contraction (slots x Cin + bias
+    // row) fits 28 rows, one 64-wide Cout tile covers the layer and the tap matrix fits its LDS table
+    std::vector<int32_t> sk_desc;
+    if ((int64_t)mx * Cin + (b.has_last ? 1 : 0) <= 28 && Cout == 64 && c.cout_pad == 64 && ntaps * c.cin_pad <= 61 && cols < INT32_MAX - 1) {
+        const int64_t stride = 96 + c.cout_pad;
+        const int32_t zero_off = (int32_t)(ntaps * c.cin_pad * 64);
+        sk_desc.assign((size_t)(HoWo * stride), 0);
+        for (int64_t pi = 0; pi < HoWo; pi++) {
+            const int32_t o = pix_order[(size_t)pi];
+            int32_t* d = sk_desc.data() + (size_t)(pi * stride);
+            float* df = reinterpret_cast<float*>(d);
+            for (int k = 0; k < 32; k++) {
+                d[k] = -1;
+                d[32 + k] = zero_off;
+                df[64 + k] = 0.0f;
+            }
+            int k = 0;
+            for (int32_t sl = pix_ptr[(size_t)o]; sl < pix_ptr[(size_t)o + 1]; sl++)
+                for (int64_t ci = 0; ci < Cin; ci++, k++) {
+                    d[k] = (int32_t)(ci * HiWi + slot_in[(size_t)sl]);
+                    d[32 + k] = (int32_t)((slot_tap[(size_t)sl] * c.cin_pad + ci) * 64);
+                    df[64 + k] = slot_coef[(size_t)sl];
+                }
+            if (b.has_last) {
+                d[k] = (int32_t)(Cin * HiWi);             // homogeneous coordinate of X against the bias row
+                d[32 + k] = zero_off + 64;                 // marker: "this buffer's bias row"
+                df[64 + k] = 1.0f;
+                for (int64_t m = 0; m < Cout; m++) df[96 + m] = lastcol[(size_t)(m * HoWo + o)];
+            }
+            d[31] = o;
+        }
+        c.sk_stride = stride;
+        c.sk_tab_rows = ntaps * c.cin_pad;
+    }
+    if ((!sk_desc.empty() && (rc = upload(&c.sk_desc, sk_desc.data(), sk_desc.size()))) || (rc = upload(&c.tapsT, tapsT.data(), tapsT.size())) || (rc = upload(&c.pix_ptr, pix_ptr.data(), pix_ptr.size())) ||
         (rc = upload(&c.slot_in, slot_in.data(), slot_in.size())) || (rc = upload(&c.slot_tap, slot_tap.data(), slot_tap.size())) ||
         (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
         (rc = upload(&c.lastcol, lastcol.data(), lastcol.size()))) {

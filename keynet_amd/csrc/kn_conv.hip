@@ -46,9 +46,13 @@ __device__ __forceinline__ void kn_order() { __builtin_amdgcn_sched_barrier(0); 
 // pointer into the first row it stores (sub-tile row `lane / (TN*8)`); the rows a lane visits are a constant RPI apart, so the
 // address is ONE running pointer plus a wave-uniform byte step -- no per-store 64-bit multiplies.  `rows_ok` (wave-uniform) says
 // that every row of the sub-tile exists (< Cout): the per-row test disappears for channel counts that fill the tile.
-template <int TM, int TN>
+template <int TM, int TN, bool ALL_ROWS = false>
 __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float* stage, const int lane, float* yp, const int64_t row_step_bytes,
                                               const int m_first, const int Cout, const bool rows_ok, const int relu) {
+    // ReLU without a branch: clamp from below at 0, or at -inf (a no-op; NaN stays NaN either way).  ALL_ROWS (compile time: the
+    // tile lies inside Cout) additionally removes the per-row test, so the 16 stores are straight-line code and a caller that
+    // keeps loads in flight across them gets an exact counted vmcnt from the compiler instead of a drain.
+    const float lo = relu ? 0.0f : -__builtin_inff();
     constexpr int COLS = TN * 32;                 // columns of this wave's sub-tile
     constexpr int LPR = COLS / 4;                 // lanes per row (16 B each)
     constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
@@ -67,13 +71,11 @@ __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float
             for (int h = 0; h < 8 / RPI; h++) {
                 const int rloc = rl + h * RPI;
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + rloc * COLS + c4 * 4);
-                if (relu) {
-                    v.x = (v.x < 0.0f) ? 0.0f : v.x;
-                    v.y = (v.y < 0.0f) ? 0.0f : v.y;
-                    v.z = (v.z < 0.0f) ? 0.0f : v.z;
-                    v.w = (v.w < 0.0f) ? 0.0f : v.w;
-                }
-                if (rows_ok || m_first + i * 32 + 8 * g + rloc < Cout) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ypb));
+                v.x = (v.x < lo) ? lo : v.x;
+                v.y = (v.y < lo) ? lo : v.y;
+                v.z = (v.z < lo) ? lo : v.z;
+                v.w = (v.w < lo) ? lo : v.w;
+                if (ALL_ROWS || rows_ok || m_first + i * 32 + 8 * g + rloc < Cout) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ypb));
                 ypb += row_step_bytes;            // next visited row: RPI rows further (also across g and i: 8 and 32 are multiples of RPI steps)
             }
             kn_wave_sync();
@@ -98,7 +100,8 @@ struct ConvArgs {
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
     int32_t tail_main;     // work items per XCD chunk computed as full tiles; the rest of the chunk runs as 4 quarter tiles each
     int32_t bt_inner;      // item order: 0 = (bt, pixel, mt) with the batch tile slowest; 1 = (pixel, bt, mt): an XCD owns a pixel range for every batch tile
-    int32_t prio_stagger;  // small-K kernel: co-resident workgroups take different wave priorities (breaks the lockstep of their phases)
+    const int32_t* sk_desc;   // small-K pipeline: per-pixel descriptors in processing order (ConvTapsDev::sk_desc), or null
+    int32_t sk_stride, sk_tab_rows;
 };
 
 // item -> (Cout tile, position in the pixel order, batch tile); the Cout tile is always fastest (its workgroups share one gathered X tile)
@@ -496,15 +499,6 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
     if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
     int mt, pi, bt;
     decode_conv_item(p, item, mt, pi, bt);
-    if (p.prio_stagger) {
-        // Workgroups that share a CU run the same three phases (gather / MFMA / store) and, arbitrated fairly, stay in lockstep:
-        // each phase is then bound by its own resource in bursts and the phases ADD.  Distinct static priorities let one
-        // workgroup's waves win the matrix pipe, finish, and move on to their stores while the others compute.
-        const unsigned q = (unsigned)(blockIdx.x >> 3) & 3u;
-        if (q == 1) __builtin_amdgcn_s_setprio(1);
-        else if (q == 2) __builtin_amdgcn_s_setprio(2);
-        else if (q == 3) __builtin_amdgcn_s_setprio(3);
-    }
     const int o = p.pix_order[pi];
     const int m0 = mt * MT;
     const int b0 = bt * NB;
@@ -588,6 +582,155 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
     float* stage = lds + wave * (8 * COLS);
     float* yp = p.Y + ((int64_t)(m0 + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wave * COLS + (lane % LPR) * 4);
     kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m0, p.Cout, m0 + TM * 32 <= p.Cout, p.relu);
+}
+
+// ---- small-K path, persistent and software-pipelined ------------------------------------------------------------------------
+// The one-shot kernel above runs gather -> MFMA -> store once per workgroup; a workgroup's LDS and wave slots stay allocated until
+// its last store is acknowledged, so the three phases of a CU's resident workgroups largely ADD (measured: 0.22 ms of gathers,
+// 0.31 ms of matrix pipe and 0.5 ms of stores take 0.9 ms together).  Here a workgroup is PERSISTENT: it walks its XCD's share
+// of the output pixels, and while the 16 row-segment stores of pixel t drain, the activation rows of pixel t+1 (requested before
+// those stores were issued, so the in-order vmcnt wait for them leaves the stores in flight) are written to the other LDS buffer
+// and multiplied.  Per-pixel control data comes from a descriptor table built once at create time in PROCESSING order (one
+// coalesced record per pixel, fetched two pixels ahead): X row of every contraction row, LDS offset of its tap row, coefficient,
+// output pixel, bias values.  The tap matrix of the layer (9 x 3 x 64 floats for VGG conv1_1) stays resident in LDS for the
+// workgroup's lifetime, so the A operand is never re-staged: fragments are read straight from the table through the descriptor's
+// row offsets.
+constexpr int SK_DESC_HDR = 96;       // dwords: [0..27] X row (-1 = none), [31] output pixel, [32..59] tap-row LDS offset, [64..91] coefficient
+constexpr int SK_TAB_MAX = 61;        // tap-table rows that fit the LDS budget (+1 zero row, +2 bias rows = 16 KiB)
+
+__global__ __launch_bounds__(256, 2) void convtaps_smallk_pipe_kernel(ConvArgs p) {
+    constexpr int MT = 64, NB = 256, TM = 2, TN = 2, KM = SMALLK_MAX, KR = KM / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * KM * NB + (SK_TAB_MAX + 3) * MT];
+    float* Tab = lds + 2 * KM * NB;                               // [tab_rows][64] taps, then a zero row, then two bias rows (double buffered)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int zero_off = p.sk_tab_rows * MT;                      // LDS element offset of the zero row; bias rows follow
+
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt;            // n_mt == 1 on this path
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t step = gridDim.x >> 3;
+    const int64_t first = xl * chunk + (blockIdx.x >> 3);
+    const int64_t end = (xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items;
+    if (first >= end) return;
+    const int64_t last = first + ((end - 1 - first) / step) * step;     // last item of this workgroup
+
+    for (int i = tid; i < (p.sk_tab_rows + 3) * MT / 4; i += 256) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < p.sk_tab_rows * MT / 4) v = reinterpret_cast<const f32x4*>(p.tapsT)[i];
+        reinterpret_cast<f32x4*>(Tab)[i] = v;
+    }
+
+    // per-item control data, one dword per lane and section (every wave keeps its own copy)
+    struct Ctl {
+        int x, a;
+        float c, bias;
+        int b0;
+    };
+    auto fetch_ctl = [&](int64_t item) -> Ctl {
+        item = item <= last ? item : last;                        // past the end: re-read the last record (results unused)
+        const int pi = (int)(item % p.n_pix);
+        const int bt = (int)(item / p.n_pix);
+        const int32_t* d = p.sk_desc + (int64_t)pi * p.sk_stride;
+        Ctl c;
+        c.x = d[lane];                                            // lanes 0..27: X rows; lane 31: output pixel; lanes 32..59: tap-row offsets
+        c.a = c.x;
+        c.c = reinterpret_cast<const float*>(d)[64 + (lane & 31)];
+        c.bias = reinterpret_cast<const float*>(d)[SK_DESC_HDR + lane];
+        c.b0 = bt * NB;
+        return c;
+    };
+    f32x4 g[KR];
+    auto gather = [&](const Ctl& c) {
+        const float* xb = p.X + c.b0 + lane * 4;
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+            const int xr = __builtin_amdgcn_readlane(c.x, wave + 4 * r);
+            g[r] = *reinterpret_cast<const f32x4*>(xb + (int64_t)(xr < 0 ? 0 : xr) * p.ldx);
+        }
+    };
+    auto stage_in = [&](const Ctl& c, const int buf) {            // registers -> LDS: contraction rows (scaled), bias row
+        float* B = lds + buf * KM * NB;
+#pragma unroll
+        for (int r = 0; r < KR; r++) {
+            const int k = wave + 4 * r;
+            const int xr = __builtin_amdgcn_readlane(c.x, k);
+            const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c.c), k));
+            f32x4 v = g[r];
+            if (!p.unit_coef) v = v * cf;
+            if (xr < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};            // padding rows are stored as zeros whatever the dummy load returned
+            *reinterpret_cast<f32x4*>(B + k * NB + lane * 4) = v;
+        }
+        if (wave == 0) Tab[zero_off + (1 + buf) * MT + lane] = c.bias;
+    };
+
+    // The descriptor registers are carried around the loop.  hipcc's waitcnt pass merges the loop-entry state (their loads are the
+    // youngest requests) with the back-edge state (16 younger stores) and would wait vmcnt(2) at their first use in EVERY iteration,
+    // draining the stores.  An empty asm that "reads" them pins that wait to a point where the count is exact on its own path: in
+    // the prologue, and behind the stores at the bottom of the loop body (vmcnt(16)); later uses see plain registers.
+    auto settle = [](Ctl& c) { asm volatile("" : "+v"(c.x), "+v"(c.a), "+v"(c.c), "+v"(c.bias)); };
+    Ctl cur = fetch_ctl(first);
+    settle(cur);
+    gather(cur);
+    Ctl nxt = fetch_ctl(first + step);
+    __syncthreads();                                              // tap table complete
+    stage_in(cur, 0);
+    settle(nxt);
+    __syncthreads();
+
+    const int arow = lane >> 5;
+    const int acol = lane & 31;
+    const int bcol = wave * (TN * 32) + (lane & 31);
+    constexpr int COLS = TN * 32, LPR = COLS / 4;
+    int buf = 0;
+    for (int64_t it = first; it <= last; it += step) {
+        gather(nxt);                                              // rows of the NEXT pixel: issued before this pixel's stores
+        Ctl nn = fetch_ctl(it + 2 * step);
+        kn_order();                                               // keep these requests ahead of the matrix phase (the scheduler would sink them to their use)
+        // ---- MFMA phase of the current pixel --------------------------------------------------------------------------------
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+        const float* B = lds + buf * KM * NB;
+        // tap-row offset of lane's k (even k in lanes 0..31, odd k in lanes 32..63); the bias marker selects this buffer's bias row
+        int a_adj = cur.a;
+        a_adj = (a_adj == zero_off + MT) ? a_adj + buf * MT : a_adj;
+#pragma unroll
+        for (int st = 0; st < KM / 2; st++) {
+            const int a0 = __builtin_amdgcn_readlane(a_adj, 32 + 2 * st);
+            const int a1 = __builtin_amdgcn_readlane(a_adj, 32 + 2 * st + 1);
+            const float* ar = Tab + (arow ? a1 : a0) + acol;
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = ar[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = B[(2 * st + arow) * NB + bcol + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                          // every wave is done with this buffer's rows: reuse it as store staging
+        // ---- epilogue of the current pixel: 16 row-segment stores per wave, left in flight ----------------------------------
+        {
+            const int o = __builtin_amdgcn_readlane(cur.x, 31);
+            float* stage = lds + buf * KM * NB + wave * (8 * COLS);
+            float* yp = p.Y + ((int64_t)(lane / LPR) * p.HoWo + o) * p.ldy + (cur.b0 + wave * COLS + (lane % LPR) * 4);
+            kn_store_tile<TM, TN, true>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, 0, p.Cout, true, p.relu);   // Cout == 64 on this path
+        }
+        // ---- next pixel's rows -> the other buffer (their loads are older than the stores above: the wait leaves those in flight) ----
+        stage_in(nxt, buf ^ 1);
+        cur = nxt;
+        nxt = nn;
+        settle(nxt);                                              // wait for the record fetched at the top: 16 younger stores stay in flight
+        __syncthreads();
+        buf ^= 1;
+    }
 }
 
 // ---- order-preserving path on the factored operator (KN_FLAG_EXACT) ------------------------------------------------
@@ -833,7 +976,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();
@@ -919,9 +1062,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.n_pix = a.HoWo;
     a.last_in_row = A.Cin * A.Hin * A.Win;
     const int bt_inner = getenv("KN_BT_INNER") ? atoi(getenv("KN_BT_INNER")) : 0;              // experiment knobs, read per call
-    const int prio_stagger = getenv("KN_SMALLK_PRIO") ? atoi(getenv("KN_SMALLK_PRIO")) : 0;
+
     a.bt_inner = bt_inner;
-    a.prio_stagger = prio_stagger;
+    a.sk_desc = A.sk_desc;
+    a.sk_stride = (int32_t)A.sk_stride;
+    a.sk_tab_rows = (int32_t)A.sk_tab_rows;
     a.tail_main = 0;
     if (flags & KN_FLAG_EXACT) {
         const bool v4 = a.vec_ok && n_vecs >= 256;
@@ -957,7 +1102,14 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         a.n_mt = (int32_t)(A.cout_pad / 64);
         a.n_bt = (int32_t)(n_vecs / 256);
         const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
-        hipLaunchKernelGGL(convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
+        const bool no_pipe = getenv("KN_NO_SMALLK_PIPE") != nullptr;      // A/B switch (read per call)
+        if (a.sk_desc && a.n_mt == 1 && !no_pipe) {
+            static const int64_t slots = xcd_slots(convtaps_smallk_pipe_kernel);
+            const int64_t per_xcd = std::min<int64_t>(std::max<int64_t>(slots, 32), (items + 7) / 8);
+            hipLaunchKernelGGL(convtaps_smallk_pipe_kernel, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
+        }
     } else if (big_m) {
         a.n_mt = (int32_t)(A.cout_pad / 128);
         a.n_bt = (int32_t)((n_vecs + 127) / 128);

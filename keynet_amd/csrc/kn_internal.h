@@ -68,6 +68,10 @@ struct ConvTapsDev {
     bool unit_coef = true;
     bool has_dups = false;              // some (output pixel, input pixel) pair is hit by more than one slot
     int max_slots = 0;
+    // small-K pipeline (first layer of an image net: kn_conv.hip, convtaps_smallk_pipe_kernel): per-pixel descriptor records in
+    // processing order, or null when the operator is not eligible
+    int32_t* sk_desc = nullptr;
+    int64_t sk_stride = 0, sk_tab_rows = 0;
 };
 
 }  // namespace kn

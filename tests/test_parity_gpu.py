@@ -570,6 +570,38 @@ def test_convtaps_small_k_path(Cin, Cout, k, stride, n_vecs, unit, has_last):
     _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, (Cin, Cout, k, stride, n_vecs, unit, has_last))
 
 
+@pytest.mark.parametrize('Cin,H,k,stride,n_vecs,unit,has_last', [
+    (3, 32, 3, 1, 512, True, True),      # VGG conv1_1 shape, 2048 work items on 512 persistent workgroups: 4 pipelined pixels each
+    (3, 24, 3, 1, 256, True, True),      # 576 pixels: ragged shares per XCD, most workgroups get one or two pixels
+    (1, 32, 3, 1, 768, False, True),     # float coefficients scale the activation rows at LDS-write time; 3 batch tiles
+    (3, 32, 3, 2, 256, True, False),     # stride 2, no bias column (no homogeneous row in the contraction)
+    (2, 40, 3, 1, 256, False, True),     # Cin = 2 with float coefficients: up to 26 contraction rows + bias... or the chunked kernel
+])
+def test_convtaps_small_k_pipeline(Cin, H, k, stride, n_vecs, unit, has_last):
+    """The persistent, software-pipelined small-K kernel (kn_conv.hip convtaps_smallk_pipe_kernel: Cout == 64, contraction <= 28 rows,
+    batch a multiple of 256) on enough pixels that every workgroup walks several of them with stores, gathers and MFMAs of
+    neighbouring pixels in flight together: same bar as every MFMA launch against the oracle, and bit-identical to the one-shot
+    kernel it replaces (same K order, same MFMA shape; KN_NO_SMALLK_PIPE selects the old kernel for the comparison)."""
+    import os
+    rng = np.random.RandomState(100 * Cin + H + n_vecs)
+    W = _random_convtaps(rng, Cin, 64, H, k, stride, unit, has_last)
+    _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, (Cin, H, k, stride, n_vecs, unit, has_last))
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    if has_last:
+        X[-1] = 1.0
+    xd = torch.as_tensor(X).to(dev())
+    for relu in (False, True):
+        y_pipe = W.torchdot(xd, relu=relu)
+        os.environ['KN_NO_SMALLK_PIPE'] = '1'
+        try:
+            y_one = W.torchdot(xd, relu=relu)
+        finally:
+            os.environ.pop('KN_NO_SMALLK_PIPE', None)
+        assert torch.equal(y_pipe, y_one), (Cin, H, relu)
+    y2 = W.torchdot(xd)                                         # repeated launches reuse nothing stale (LDS tables, descriptors)
+    assert torch.equal(y2, W.torchdot(xd))
+
+
 def _keyed_vs_plain(net, inshape, n, factory_kwargs, atol):
     """The reference's own integration criterion (test/test_keynet.py): keyed logits == source-network logits."""
     import warnings

@@ -7,10 +7,25 @@ rocprofv3 commands listed in profiles/README.md) into the committed profiles/rNN
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
+import subprocess
 import sys
+
+csv.field_size_limit(1 << 30)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha():
+    """sha256 over keynet_amd/csrc/*.{hip,h} (same function as bench.py): ties a PMC pass to the kernel sources it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'keynet_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()
 
 
 def per_kernel(d, counter):
@@ -22,7 +37,7 @@ def per_kernel(d, counter):
     return agg
 
 
-def main(R, tag, out='profiles', forwards=4):
+def main(R, tag, out='profiles', forwards=None):
     os.makedirs(out, exist_ok=True)
     for f in glob.glob(out + '/%s_*' % tag):
         os.remove(f)
@@ -38,11 +53,13 @@ def main(R, tag, out='profiles', forwards=4):
     shutil.copy(R + '/stats_bench.json', pre + 'bench_under_rocprof.json')
     open(pre + 'layers.log', 'w').write(''.join(l for l in open(R + '/bench.log') if 'bench' in l))
     (fe, wr) = (per_kernel(R + '/pmc_fetch', 'FETCH_SIZE'), per_kernel(R + '/pmc_write', 'WRITE_SIZE'))
+    if forwards is None:      # conv1_1 runs the small-K kernel exactly once per forward
+        forwards = max([len(v) for (k, v) in fe.items() if 'convtaps_smallk' in k] + [1])
     tr = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES '
                      'SQ_LDS_BANK_CONFLICT / TCC_HIT_sum TCC_MISS_sum) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline',
           'units': 'FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads: MI355X_MICROARCH.md HBM section; calibrated in the '
                    'same kind of run on kn::transpose_kernel: 147.0 MiB read -> FETCH_SIZE 73.5 MiB, WRITE_SIZE 147.0 MiB exact)',
-          'forwards_in_run': forwards, 'kernels': {}}
+          'forwards_in_run': forwards, 'mode': 'tolerance', 'csrc_sha256': kernel_sources_sha(), 'kernels': {}}
     (tot_f, tot_w) = (0.0, 0.0)
     for k in fe:
         if 'convtaps' not in k and 'csr_' not in k and 'dense_reduce' not in k:
@@ -77,6 +94,8 @@ def main(R, tag, out='profiles', forwards=4):
         pm.setdefault(k, {})['l2_hit_rate'] = v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum'])
     tr['convtaps_pmc'] = pm
     json.dump(tr, open(pre + 'traffic.json', 'w'), indent=1)
+    if os.path.exists(R + '/per_layer.csv'):
+        shutil.copy(R + '/per_layer.csv', pre + 'per_layer_pmc.csv')
     b = json.load(open(R + '/bench.json'))
     print('value %.1f img/s, %.2f ms/step, roofline frac %.4f (%.1f TF), conv traffic %.1f GB (fetch %.1f + write %.1f), alg bytes %.1f GB' %
           (b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline']['achieved'], (tot_f + tot_w) / 1e9, tot_f / 1e9, tot_w / 1e9, b['roofline']['algorithmic_bytes'] / 1e9))
