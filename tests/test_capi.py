@@ -54,3 +54,16 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'kn_oracle' not in src, f
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference is only mounted in the build container')
+def test_integration_md_stub_is_real_code():
+    """INTEGRATION.md's `keynet/hip.py` is extracted and run against the reference's own classes (tests/golden/check_integration_stub.py)."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'check_integration_stub.py')],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'STUB OK' in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])

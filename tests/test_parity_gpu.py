@@ -580,8 +580,8 @@ def test_convtaps_small_k_path(Cin, Cout, k, stride, n_vecs, unit, has_last):
 def test_convtaps_small_k_pipeline(Cin, H, k, stride, n_vecs, unit, has_last):
     """The persistent, software-pipelined small-K kernel (kn_conv.hip convtaps_smallk_pipe_kernel: Cout == 64, contraction <= 28 rows,
     batch a multiple of 256) on enough pixels that every workgroup walks several of them with stores, gathers and MFMAs of
-    neighbouring pixels in flight together: same bar as every MFMA launch against the oracle, and bit-identical to the one-shot
-    kernel it replaces (same K order, same MFMA shape; KN_NO_SMALLK_PIPE selects the old kernel for the comparison)."""
+    neighbouring pixels in flight together: same bar as every MFMA launch against the oracle, and (unit coefficients) bit-identical
+    to the one-shot kernel it replaces (same K order, same MFMA shape; KN_NO_SMALLK_PIPE selects the old kernel for the comparison)."""
     import os
     rng = np.random.RandomState(100 * Cin + H + n_vecs)
     W = _random_convtaps(rng, Cin, 64, H, k, stride, unit, has_last)
@@ -597,7 +597,10 @@ def test_convtaps_small_k_pipeline(Cin, H, k, stride, n_vecs, unit, has_last):
             y_one = W.torchdot(xd, relu=relu)
         finally:
             os.environ.pop('KN_NO_SMALLK_PIPE', None)
-        assert torch.equal(y_pipe, y_one), (Cin, H, relu)
+        if unit:       # float coefficients: the one-shot kernel scales the tap rows, the pipeline the activation rows (both within the bar above)
+            assert torch.equal(y_pipe, y_one), (Cin, H, relu)
+        else:
+            assert float((y_pipe - y_one).abs().max()) <= 1e-5 * max(1.0, float(y_one.abs().max()))
     y2 = W.torchdot(xd)                                         # repeated launches reuse nothing stale (LDS tables, descriptors)
     assert torch.equal(y2, W.torchdot(xd))
 
