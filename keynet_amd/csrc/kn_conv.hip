@@ -1008,8 +1008,18 @@ template <int MT, int NB, int KC, int WM, int WN>
 static void launch_conv(ConvArgs a, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t chunk = (items + 7) / 8;
-    const int occ_cap = getenv("KN_OCC") ? atoi(getenv("KN_OCC")) : 0;            // experiment knob, read per call
     constexpr size_t static_lds = sizeof(float) * (2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS + 2 * (MT + NB));
+    // Workgroups per CU.  All of a launch's workgroups take the same time, so a launch proceeds in "rounds" of the resident set; with
+    // only a few rounds (VGG conv5_x: 196 items per XCD = 1.53 rounds of 128) a third of the work would fall into the last, partial
+    // round.  Three workgroups per CU run as fast as four on the long layers (-1.5 %), and 196 items = 2.04 rounds of 96: when a
+    // launch has fewer than four rounds, the resident set whose partial round is the smaller fraction wins (measured on conv5_x:
+    // 122.9 -> 125.4 TFLOP/s, same-process A/B).  KN_OCC forces a cap (A/B knob, read per call).
+    int occ_cap = getenv("KN_OCC") ? atoi(getenv("KN_OCC")) : 0;
+    if (occ_cap == 0 && MT == 128 && NB == 128 && KC == 16) {
+        const double r4 = (double)chunk / 128.0, r3 = (double)chunk / 96.0;
+        const double f4 = r4 - (double)(int64_t)r4, f3 = r3 - (double)(int64_t)r3;
+        if (r4 < 4.0 && f4 > 0.0 && f3 < f4) occ_cap = 3;
+    }
     const unsigned pad = lds_pad_for_occupancy(static_lds, occ_cap);
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;

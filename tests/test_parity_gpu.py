@@ -133,6 +133,36 @@ def test_float_key_error_is_no_worse_than_the_references_own(golden, name):
         assert max(r[1] for r in report) > 1e-5      # the premise: the reference's own f32 result is further than 1e-5 from the truth
 
 
+@pytest.mark.parametrize('name,n', [('lenet_perm.npz', 1024), ('mini_tiled_permutation.npz', 512), ('allconv_tiny_perm.npz', 256)])
+def test_overlapped_forward_is_bit_identical(golden, name, n):
+    """KeyedModel.forward_linear's default for large device-resident batches -- two half-batch column windows on two side streams,
+    one kernel apart, ping-pong workspaces -- against the plain single-stream forward and the reference vectors: bit for bit
+    (every batch column is computed by the same kernel instantiation either way), repeatedly (workspaces are reused)."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    xc = torch.as_tensor(z['x_cipher'])
+    m = xc.shape[0]
+    x = torch.cat([xc] * ((n + m - 1) // m), dim=0)[:n].to(dev()).t().contiguous().t()
+    plan = knet._overlap_plan(x.device, n)
+    assert plan is not None and len(plan['steps']) - plan['split_at'] >= 2
+    y0 = knet.forward_linear(x, overlap=False)
+    for _ in range(3):
+        y1 = knet.forward_linear(x)                             # auto: overlapped
+        assert torch.equal(y0, y1)
+    if 'tiled' not in name:
+        assert np.array_equal(y0[:m].cpu().numpy(), z['Y.%s' % [str(k) for k in z['layer_names']][-1]])
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                  # also from a non-default caller stream
+        s.wait_stream(torch.cuda.default_stream())
+        y2 = knet.forward_linear(x)
+    s.synchronize()
+    assert torch.equal(y0, y2)
+    knet.exact_mode(True)
+    assert knet._overlap_plan(x.device, n) is not plan          # contracts changed: the launch lists are rebuilt
+    ye = knet.forward_linear(x)
+    assert torch.equal(ye, knet.forward_linear(x, overlap=False))
+
+
 def test_export_csr_matches_reference_tocsr(golden):
     z = golden('mini_tiled_permutation.npz')
     for lname in ('conv1', 'conv2', 'pool1'):

@@ -54,9 +54,15 @@ def test_keyed_vgg16_equals_plain_network(vgg):
     assert np.array_equal(back.cpu().numpy(), x[:2].numpy())                # permutation image key: exact round trip
     # batch-column independence: 256 vs 512 images run the SAME kernel instantiations => bit-identical columns; smaller /
     # ragged batches take other instantiations (different K order on the MFMA path) => equal to rounding
-    x256 = torch.cat([xc] * 64, dim=0)
+    x256 = torch.cat([xc] * 64, dim=0).t().contiguous().t()        # feature-major block, as the sensor hands it over
     y256 = knet.forward_linear(x256)
-    y512 = knet.forward_linear(torch.cat([x256, x256], dim=0))
+    # the overlapped forward (two half-batch windows on two streams, one kernel apart: the default at this batch) and the plain
+    # single-stream forward run the same kernels on the same columns: bit-identical
+    plan = knet._overlap_plan(x256.device, 256)
+    assert plan is not None and plan['split_at'] == 2 and len(plan['steps']) == 21      # conv1_1 / conv1_2 need 256-wide tiles: run whole
+    assert torch.equal(y256, knet.forward_linear(x256, overlap=False))
+    assert torch.equal(y256, knet.forward_linear(x256, overlap=True))                    # and repeatable on reused workspaces
+    y512 = knet.forward_linear(torch.cat([x256, x256], dim=0).t().contiguous().t())
     assert torch.equal(y256, y512[:256]) and torch.equal(y256, y512[256:])
     del y512
     assert torch.equal(y256[:4], y256[4:8]) and torch.equal(y256[:4], y256[252:256])

@@ -98,7 +98,38 @@ def main():
             main_s.wait_stream(st)
         return bufs[-1]
 
-    variants = [('single stream', forward_single), ('two streams (half after half)', forward_two_streams), ('two streams (interleaved issue)', forward_interleaved)]
+    def forward_offset(delay_layers):
+        """Stream B starts `delay_layers` kernels behind stream A, so that the two streams' launch boundaries (drain of one kernel,
+        fill of the next) never coincide: one stream's queued workgroups take over the CUs the other one's draining kernel frees."""
+        def f():
+            main_s = torch.cuda.current_stream()
+            src = x0
+            for k in range(split_at):
+                (name, op, rows, flags) = plan[k]
+                op.spmm(src.data_ptr(), B, B, bufs[k].data_ptr(), B, flags, main_s.cuda_stream)
+                src = bufs[k]
+            for st in streams:
+                st.wait_stream(main_s)
+            ev = None
+            for k in range(split_at, len(plan) + delay_layers):
+                for (h, st) in enumerate(streams):
+                    kk = k - (delay_layers if h == 1 else 0)
+                    if kk < split_at or kk >= len(plan):
+                        continue
+                    (name, op, rows, flags) = plan[kk]
+                    s_in = src if kk == split_at else bufs[kk - 1]
+                    op.spmm(s_in.data_ptr() + 4 * H * h, B, H, bufs[kk].data_ptr() + 4 * H * h, B, flags, st.cuda_stream)
+                if k - split_at < delay_layers:              # hold stream B back until A has finished this kernel
+                    ev = torch.cuda.Event()
+                    ev.record(streams[0])
+                    streams[1].wait_event(ev)
+            for st in streams:
+                main_s.wait_stream(st)
+            return bufs[-1]
+        return f
+
+    variants = [('two streams, B one kernel behind', forward_offset(1)), ('two streams, B two kernels behind', forward_offset(2)),
+                ('single stream', forward_single), ('two streams (half after half)', forward_two_streams), ('two streams (interleaved issue)', forward_interleaved)]
     for (nm, f) in variants:
         out = f()
         torch.cuda.synchronize()
