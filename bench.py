@@ -410,6 +410,50 @@ def exact_parity(knet, x_cipher, n_img=8, n_pix=4):
             'ok': bool(checked) and all(r['bit_equal'] for r in checked)}
 
 
+def float_key_parity(dev, batch=256):
+    """Float-key family on a VGG-16 slice (the same 21-layer topology at width 8 on 32x32 inputs, keyed by TiledOrthogonalKeynet:
+    hierarchical permutation + block Givens rotations + affine photometric keys, gamma = 100): how far the matrix-core path is from
+    the order-preserving path, which is bit-exact with the reference's scipy arithmetic (tests/test_parity_gpu.py).  Per conv layer
+    both paths get the SAME input (the exact path's previous output); reported: the worst absolute difference and the worst
+    difference in units of eps32 * sum|a.x| (the rounding-noise scale of any f32 evaluation of that sum)."""
+    import warnings
+    t0 = time.time()
+    torch.manual_seed(0)
+    net = VGG16(num_classes=10, width=8, fc_width=64, insize=32).eval()
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.TiledOrthogonalKeynet((3, 32, 32), net, 8)
+    g = torch.Generator(device=dev).manual_seed(77)
+    x = torch.randn((batch, 3, 32, 32), generator=g, device=dev)
+    y = sensor.fromtensor(x).encrypt().astensor()
+    rows = []
+    children = list(knet._keynet.named_children())
+    for (i, (name, c)) in enumerate(children):
+        if not isinstance(c, KeyedLayer):
+            continue
+        fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+        if isinstance(c.W, ksp.Conv2dTiledMatrix):
+            xt = y.t()
+            ye = c.W.torchdot(xt, relu=fuse, exact=True)
+            ym = c.W.torchdot(xt, relu=fuse, exact=False)
+            rows.append({'layer': name, 'max_abs_diff': float((ye - ym).abs().max()), 'max_abs_out': float(ye.abs().max())})
+            y = ye.t()
+        else:
+            y = c.forward(y, fuse_relu=fuse)
+    knet.exact_mode(True)
+    le = knet.forward_linear(sensor.fromtensor(x).encrypt().astensor())[:, :-1]
+    knet.exact_mode(False)
+    lm = knet.forward_linear(sensor.fromtensor(x).encrypt().astensor())[:, :-1]
+    with torch.no_grad():
+        lp = net(x.cpu()).reshape(batch, -1)
+    return {'net': 'TiledOrthogonalKeynet VGG16 slice (width 8, 3x32x32, tile 8), %d images' % batch, 'layers': rows,
+            'worst_layer_abs_diff_mfma_vs_exact': max(r['max_abs_diff'] for r in rows),
+            'logits_max_abs_diff_mfma_vs_exact': float((le - lm).abs().max()), 'logits_max_abs': float(le.abs().max()),
+            'logits_max_abs_err_exact_vs_source_network': float((le.cpu() - lp).abs().max()),
+            'logits_max_abs_err_mfma_vs_source_network': float((lm.cpu() - lp).abs().max()), 'seconds': time.time() - t0}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from THIS
     process, which has not touched the GPU (no torch.cuda call above this point), and exit with their code."""
@@ -570,6 +614,10 @@ def main():
                             'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
                             'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
             knet.exact_mode(None)
+            try:
+                res['float_key_parity'] = float_key_parity(dev)
+            except Exception as e:      # a reported-only record must never break the bench line
+                res['float_key_parity'] = {'error': str(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

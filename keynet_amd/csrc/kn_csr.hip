@@ -440,8 +440,11 @@ static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_ve
 
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
     const int relu = (flags & KN_FLAG_RELU) ? 1 : 0;
+    // a vector width is usable when pointers / strides allow it AND it keeps the wavefronts filled (64 * v columns per wave): n_vecs = 128
+    // (a half-batch column window) takes v = 2 with every lane active rather than v = 4 with lanes 32..63 idle
     auto aligned = [&](int v) {
-        return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0);
+        return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0) &&
+               (v == 1 || 4 * n_vecs >= 3 * ((n_vecs + 64 * v - 1) / (64 * v)) * (64 * v));     // >= 75 % of the lanes busy
     };
     // (rows per wavefront, batch columns per lane): the most accumulators per lane that still gives the chip >= 2048
     // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner

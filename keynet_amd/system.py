@@ -181,7 +181,8 @@ class KeyedModel(object):
                     (op, ex, ok) = (W._dense_device_op(device), False, half % 128 == 0)
                 elif isinstance(W, ksp.Conv2dTiledMatrix):
                     (op, ex) = (W._device_op(device), exact)
-                    ok = True if exact else (half % (128 if W._outshape[0] > 64 else 256) == 0)
+                    # order-preserving conv kernels work on 256-column tiles; MFMA tiles are 128 (Cout > 64) or 256 columns wide
+                    ok = (half % 256 == 0) if exact else (half % (128 if W._outshape[0] > 64 else 256) == 0)
                 else:
                     (op, ex, ok) = (W._device_op(device), True, True)
                 flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if ex else 0)
