@@ -1024,7 +1024,7 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     a.tail_main = (int32_t)chunk;
-    if constexpr ((MT == 128 || MT == 256) && NB == 128 && KC == 16) {
+    if constexpr (MT == 128 && NB == 128 && KC == 16) {
         static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
         if (fast && a.wide_store && !no_tail) {
             static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>);
@@ -1120,11 +1120,6 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         } else {
             hipLaunchKernelGGL(convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
         }
-    } else if (big_m && k16 && A.cout_pad % 256 == 0 && getenv("KN_MT256") && atoi(getenv("KN_MT256")) > 0) {
-        // experiment: 256 x 128 tile (each wave 128 x 64): half as many workgroups gather each activation tile
-        a.n_mt = (int32_t)(A.cout_pad / 256);
-        a.n_bt = (int32_t)((n_vecs + 127) / 128);
-        launch_conv<256, 128, 16, 2, 2>(a, s);
     } else if (big_m) {
         a.n_mt = (int32_t)(A.cout_pad / 128);
         a.n_bt = (int32_t)((n_vecs + 127) / 128);

@@ -140,6 +140,65 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict
     }
 }
 
+// Loose rows when the batch window is 128 columns wide (a half batch of the overlapped forward): one row per HALF wavefront, so
+// all 64 lanes carry 16-byte accesses (a whole wave on one row would leave lanes 32..63 idle, 8-byte accesses would halve the
+// bytes per request).  Each lane reads its row's (col, val) pairs itself -- the 32 lanes of a half read one address, i.e. one
+// request -- which suits the short rows this path sees (keyed pooling: ~9 non-zeros).  Same serial, stored-order mul-then-add.
+__global__ __launch_bounds__(256) void csr_rows_pair_kernel(const int32_t* __restrict__ row_list, int64_t n_rows, const int32_t* __restrict__ indptr,
+                                                            const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                                            const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs,
+                                                            int relu, int64_t n_rb) {
+    const int64_t n_ct = (n_vecs + 127) / 128;
+    int64_t item;
+    if (!decode_item(n_ct * n_rb, item)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int lane = threadIdx.x & 63;
+    const int64_t ri = (rb * WAVES + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const int64_t c = ct * 128 + (int64_t)(lane & 31) * 4;
+    if (ri >= n_rows || c >= n_vecs) return;                       // n_vecs % 4 == 0 is guaranteed by the launcher
+    const int row = row_list ? row_list[ri] : (int)ri;
+    const int start = indptr[row];
+    const int end = indptr[row + 1];
+    const float* xc = X + c;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = start;
+    for (; k + 4 <= end; k += 4) {
+        int col[4];
+        float a[4], xv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            col[u] = indices[k + u];
+            a[u] = data[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) load_vec<4>(xv[u], xc + (int64_t)col[u] * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const float p = a[u] * xv[u][v];
+                acc[v] = acc[v] + p;
+            }
+    }
+    for (; k < end; k++) {
+        const int col = indices[k];
+        const float a = data[k];
+        float xv[4];
+        load_vec<4>(xv, xc + (int64_t)col * ldx);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float p = a * xv[v];
+            acc[v] = acc[v] + p;
+        }
+    }
+    if (relu) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = relu_f(acc[v]);
+    }
+    store_vec<4>(Y + (int64_t)row * ldy + c, acc);
+}
+
 // Grouped rows: work item w = RB member rows [r0, r0+RB) of group g; all share the column sequence grp_cols[colptr[g]..].
 // grp_vals layout per group: [j][Rpad] (Rpad = members rounded up to RB), so the RB values of column j are contiguous.
 template <int VEC, int RBK>
@@ -450,6 +509,16 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner
     // bundles / narrower vectors -- the walk over a row's columns is serial by contract, so parallelism can only come
     // from rows and batch columns.
+    // short loose rows over a batch window that fills only half of a 256-column wave tile: one row per half wavefront
+    if (A.n_work == 0 && A.n_loose >= 4096 && A.nnz <= 32 * A.n_loose && n_vecs % 128 == 0 && (n_vecs / 128) % 2 == 1 && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+        (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0)) {
+        const int64_t n_rb = (A.n_loose + 2 * WAVES - 1) / (2 * WAVES);
+        const int64_t items = ((n_vecs + 127) / 128) * n_rb;
+        hipLaunchKernelGGL(csr_rows_pair_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y,
+                           ldy, n_vecs, relu, n_rb);
+        KN_HIP(hipGetLastError());
+        return KN_OK;
+    }
     const int64_t loose = (A.n_loose + WAVES - 1) / WAVES * WAVES;
     auto waves = [&](int v, int rbk) { return (A.n_work * (RB / rbk) + loose) * ((n_vecs + 64 * v - 1) / (64 * v)); };
     constexpr int64_t ENOUGH = 2048;

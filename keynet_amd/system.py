@@ -186,15 +186,19 @@ class KeyedModel(object):
                 else:
                     (op, ex, ok) = (W._device_op(device), True, True)
                 flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if ex else 0)
-                steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok))
+                steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok, 'Linear' in c._layertype))
                 i += 2 if fuse else 1
             if steps:
-                split_at = len(steps)
+                # the trailing fully connected layers are too small to fill the chip per half: the streams join before them
+                join_at = len(steps)
+                while join_at > 0 and steps[join_at - 1][5]:
+                    join_at -= 1
+                split_at = join_at
                 while split_at > 0 and steps[split_at - 1][4]:
                     split_at -= 1
-                if len(steps) - split_at >= 2:
+                if join_at - split_at >= 2:
                     rows_max = max(st[1] for st in steps)
-                    plan = dict(steps=steps, split_at=split_at,
+                    plan = dict(steps=steps, split_at=split_at, join_at=join_at,
                                 bufs=[torch.empty(rows_max * batch, dtype=torch.float32, device=device) for _ in range(2)],
                                 streams=[torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)])
         plans[key] = plan
@@ -211,7 +215,7 @@ class KeyedModel(object):
         stream 0: the two streams' launch boundaries then never coincide, and the workgroups one stream has queued take over the
         CUs that the other stream's draining kernel frees (the drain of a launch costs ~0.3 ms of a 6.5 ms conv layer otherwise).
         Same kernels, same per-column arithmetic: bit-identical to the single-stream forward."""
-        (steps, split_at, bufs, side) = (plan['steps'], plan['split_at'], plan['bufs'], plan['streams'])
+        (steps, split_at, join_at, bufs, side) = (plan['steps'], plan['split_at'], plan['join_at'], plan['bufs'], plan['streams'])
         N = x.shape[0]
         half = N // 2
         main = torch.cuda.current_stream(x.device)
@@ -219,18 +223,18 @@ class KeyedModel(object):
         ptr_in = xt.data_ptr()
         with torch.cuda.device(x.device):
             for k in range(split_at):
-                (op, rows, cols, flags, _) = steps[k]
+                (op, rows, cols, flags) = steps[k][:4]
                 op.spmm(ptr_in, N, N, bufs[k % 2].data_ptr(), N, flags, main.cuda_stream)
                 ptr_in = bufs[k % 2].data_ptr()
             for st in side:
                 st.wait_stream(main)
             n = len(steps)
-            for k in range(split_at, n + 1):
+            for k in range(split_at, join_at + 1):
                 for (h, st) in enumerate(side):
                     kk = k - h                                     # stream 1 runs one kernel behind stream 0
-                    if kk < split_at or kk >= n:
+                    if kk < split_at or kk >= join_at:
                         continue
-                    (op, rows, cols, flags, _) = steps[kk]
+                    (op, rows, cols, flags) = steps[kk][:4]
                     src = ptr_in if kk == split_at else bufs[(kk - 1) % 2].data_ptr()
                     op.spmm(src + 4 * half * h, N, half, bufs[kk % 2].data_ptr() + 4 * half * h, N, flags, st.cuda_stream)
                 if k == split_at:
@@ -239,6 +243,9 @@ class KeyedModel(object):
                     side[1].wait_event(ev)
             for st in side:
                 main.wait_stream(st)
+            for k in range(join_at, n):                            # whole batch again, on the caller's stream
+                (op, rows, cols, flags) = steps[k][:4]
+                op.spmm(bufs[(k - 1) % 2].data_ptr(), N, N, bufs[k % 2].data_ptr(), N, flags, main.cuda_stream)
             rows_out = steps[-1][1]
             out = bufs[(n - 1) % 2][:rows_out * N].view(rows_out, N).clone()      # the workspace is reused by the next call
         return out.t()

@@ -144,7 +144,7 @@ def test_overlapped_forward_is_bit_identical(golden, name, n):
     m = xc.shape[0]
     x = torch.cat([xc] * ((n + m - 1) // m), dim=0)[:n].to(dev()).t().contiguous().t()
     plan = knet._overlap_plan(x.device, n)
-    assert plan is not None and len(plan['steps']) - plan['split_at'] >= 2
+    assert plan is not None and plan['join_at'] - plan['split_at'] >= 2 and plan['join_at'] < len(plan['steps'])    # trailing fc layers run whole
     y0 = knet.forward_linear(x, overlap=False)
     for _ in range(3):
         y1 = knet.forward_linear(x)                             # auto: overlapped
@@ -416,6 +416,39 @@ def test_csr_kernel_vs_oracle_random(n_vecs):
     # non-contiguous input view (what x_affine.t() is for a row-major batch)
     Xt = torch.as_tensor(np.ascontiguousarray(X.T)).to(dev())
     assert np.array_equal(W.torchdot(Xt.t()).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('n_vecs,window', [(128, None), (384, None), (128, 256), (128, 512)])
+def test_csr_short_rows_half_wave_path(n_vecs, window):
+    """Keyed-pooling-shaped operators (thousands of loose rows, ~9 unsorted non-zeros each, a few empty or longer rows) over a batch
+    that fills half of a 256-column wave tile -- what each stream of the overlapped forward hands the pooling layers: one row
+    per half wavefront (csr_rows_pair_kernel).  Bit-exact vs the oracle; `window` = the operand is a column window of a wider
+    activation block (ldx = ldy = window > n_vecs), through the C ABI directly."""
+    rng = np.random.RandomState(n_vecs + (window or 0))
+    (m, n) = (6000, 2500)
+    lens = rng.randint(6, 12, m)
+    lens[::97] = 0
+    lens[5::501] = 40
+    indptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+    indices = rng.randint(0, n, int(indptr[-1])).astype(np.int32)
+    data = rng.randn(len(indices)).astype(np.float32)
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    if window is None:
+        X = rng.randn(n, n_vecs).astype(np.float32)
+        ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+        for relu in (False, True):
+            y = W.torchdot(torch.as_tensor(X).to(dev()), relu=relu).cpu().numpy()
+            assert np.array_equal(y, np.maximum(ref, 0) if relu else ref)
+        return
+    Xw = rng.randn(n, window).astype(np.float32)
+    xd = torch.as_tensor(Xw).to(dev())
+    yd = torch.full((m, window), 7.0, device=dev())
+    c0 = window - n_vecs                                           # the LAST window of the block
+    W._device_op(dev()).spmm(xd.data_ptr() + 4 * c0, window, n_vecs, yd.data_ptr() + 4 * c0, window, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = oracle.csr_matvecs((m, n), indptr, indices, data, np.ascontiguousarray(Xw[:, c0:]))
+    y = yd.cpu().numpy()
+    assert np.array_equal(y[:, c0:], ref) and np.all(y[:, :c0] == 7.0)          # nothing outside the window is touched
 
 
 def test_batch_columns_are_independent(golden):
