@@ -847,8 +847,8 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX>
-__global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
+template <int RBX, bool ASMMAC = true, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
     const int64_t n_ct = (p.n_vecs + 255) / 256;
     const int64_t n_items = n_ct * n_rb;
     const int64_t chunk = (n_items + 7) >> 3;
@@ -861,13 +861,15 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     const int lane = threadIdx.x & 63;
     const int64_t w = rb * 4 + wave;
     if (w >= (int64_t)p.n_pix * n_cob) return;
-    const int o = p.pix_order[w / n_cob];
-    const int co0 = (int)(w % n_cob) * RBX;
-    const int s_beg = p.pix_ptr[o];
-    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    // wave-uniform by construction; pinned to SGPRs here so that the whole step-advance logic below stays on the scalar ALU (a value
+    // that comes out of a vector-memory load counts as divergent for the compiler, and would drag the loop counters into VGPRs)
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[w / n_cob]);
+    const int co0 = __builtin_amdgcn_readfirstlane((int)(w % n_cob) * RBX);
+    const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
+    const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
     const int64_t c = ct * 256 + (int64_t)lane * 4;
     const bool active = c < p.n_vecs;
-    const uint32_t lane_off = (uint32_t)(active ? c : 0);
+    const uint32_t lane_off_bytes = 4u * (uint32_t)(active ? c : 0);      // byte offset: (uniform base) + zext(VGPR) selects the saddr load form
 
     f32x4 acc[RBX];
 #pragma unroll
@@ -888,7 +890,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         auto fetch = [&](f32x4& xr, float (&ar)[RBX]) {
             const int xo = __builtin_amdgcn_readlane(my_xoff, s) + ci_x;
             const int ao = __builtin_amdgcn_readlane(my_aoff, s) + ci_a;
-            xr = *reinterpret_cast<const f32x4*>((p.X + xo) + lane_off);
+            xr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.X + xo) + lane_off_bytes);
             const float* a = a_base + ao;
 #pragma unroll
             for (int r = 0; r < RBX; r++) ar[r] = a[r];
@@ -897,15 +899,25 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             q_next++;
             const bool more = q_next < n_q;
             const bool wrap = (s + 1 == n_slots);
-            s = __builtin_amdgcn_readfirstlane(more ? (wrap ? 0 : s + 1) : s);
-            ci_x = __builtin_amdgcn_readfirstlane(ci_x + ((more && wrap) ? ch_x : 0));
-            ci_a = __builtin_amdgcn_readfirstlane(ci_a + ((more && wrap) ? p.cout_pad : 0));
+            s = more ? (wrap ? 0 : s + 1) : s;
+            ci_x = ci_x + ((more && wrap) ? ch_x : 0);
+            ci_a = ci_a + ((more && wrap) ? p.cout_pad : 0);
         };
         // acc[r] += x * av[r] (separate IEEE multiply and add).  The tap values sit in SGPR pairs; the packed multiply reads the
         // pair directly and broadcasts its low or high half with op_sel -- the compiler would copy every odd value into a fresh
         // aligned pair first (s_mov + hazard s_nop per value).
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         auto mac = [&](const f32x4& xv, const float (&av)[RBX]) {
+            if constexpr (!ASMMAC) {
+                // plain C: hipcc (ROCm 7.2) emits the same v_pk_mul_f32 with the SGPR pair and op_sel broadcast, but still copies some
+                // values into fresh pairs (16 s_mov + 22 s_nop per two steps): measured 2 % slower than the asm form (same-process A/B)
+#pragma unroll
+                for (int r = 0; r < RBX; r++) {
+                    const f32x4 pr = xv * av[r];
+                    acc[r] = acc[r] + pr;
+                }
+                return;
+            }
             const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
 #pragma unroll
             for (int r = 0; r < RBX; r += 2) {
@@ -1089,8 +1101,10 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        if (pipe && rbx == 16) hipLaunchKernelGGL(convtaps_exact_pipe_kernel<16>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe) hipLaunchKernelGGL(convtaps_exact_pipe_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        // experiment knob (read per call): 6 waves per SIMD (80 VGPRs, 3 dwords of scratch) instead of 5 (88 VGPRs)
+        if (pipe && rbx == 16 && getenv("KN_EXACT_OCC6")) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true, 6>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {
