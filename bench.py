@@ -298,10 +298,13 @@ def layer_table(knet, batch):
     return rows
 
 
-def time_layers(x_cipher, table, iters):
+def time_layers(x_cipher, table, iters, reps=3):
     """Per-layer kernel time with HIP events on the launch stream (torch's current stream is the one kn_spmm launches on).
-    Every iteration is timed on its own and the MEDIAN is kept: a multi-GB output allocation can occasionally fall out of
-    the caching allocator and cost tens of ms, which must not leak into a kernel's average."""
+    In the forward the kernels run back to back, so each timing is over `reps` back-to-back launches behind one untimed launch:
+    a launch that follows an idle period runs 1-20 % slower while the clock ramps back up (measured with per-workgroup time
+    stamps, profiles/r02_workgroup_timeline_conv_layers.txt), which is not what happens inside the timed step.  The MEDIAN over
+    `iters` such timings is kept: a multi-GB output allocation can occasionally fall out of the caching allocator and cost tens
+    of ms, which must not leak into a kernel's average."""
     y = x_cipher
     for row in table:
         c = row['layer']
@@ -312,12 +315,15 @@ def time_layers(x_cipher, table, iters):
         times = []
         for _ in range(max(iters, 1)):
             del out
+            out = c.forward(xin, fuse_relu=row['fuse'])
             (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             e0.record()
-            out = c.forward(xin, fuse_relu=row['fuse'])
+            for _ in range(reps):
+                del out
+                out = c.forward(xin, fuse_relu=row['fuse'])
             e1.record()
             torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1))
+            times.append(e0.elapsed_time(e1) / reps)
         row['ms'] = float(np.median(times))
         row['ms_min'] = float(np.min(times))
         y = out

@@ -22,6 +22,8 @@
 // accumulation order and rounding on the VALU, bit-exact), conv_lastrow_kernel (homogeneous output row).
 #include "kn_internal.h"
 #include <type_traits>
+#include <cstdio>
+#include <vector>
 
 namespace kn {
 
@@ -100,6 +102,7 @@ struct ConvArgs {
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
     int32_t tail_main;     // work items per XCD chunk computed as full tiles; the rest of the chunk runs as 4 quarter tiles each
     int32_t bt_inner;      // item order: 0 = (bt, pixel, mt) with the batch tile slowest; 1 = (pixel, bt, mt): an XCD owns a pixel range for every batch tile
+    int64_t* stamps;          // diagnostic build only (KN_STAMPS): per-workgroup {start, end} of s_memrealtime, XCC id, kind; null otherwise
     const int32_t* sk_desc;   // small-K pipeline: per-pixel descriptors in processing order (ConvTapsDev::sk_desc), or null
     int32_t sk_stride, sk_tab_rows;
 };
@@ -470,13 +473,20 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     int mt, pi, bt;
     decode_conv_item(p, item, mt, pi, bt);
     const int o = p.pix_order[pi];
+    if (p.stamps && threadIdx.x == 0) {
+        p.stamps[4 * (int64_t)blockIdx.x + 0] = (int64_t)__builtin_amdgcn_s_memrealtime();
+        p.stamps[4 * (int64_t)blockIdx.x + 2] = (int64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+        p.stamps[4 * (int64_t)blockIdx.x + 3] = quad;
+    }
+    bool done = false;
     if constexpr (TAIL) {
         if (quad >= 0) {
             convtaps_mfma_tile<MT / 2, NB / 2, KC, WM, WN, FAST>(p, o, mt * MT + (quad & 1) * (MT / 2), bt * NB + (quad >> 1) * (NB / 2), lds);
-            return;
+            done = true;
         }
     }
-    convtaps_mfma_tile<MT, NB, KC, WM, WN, FAST>(p, o, mt * MT, bt * NB, lds);
+    if (!done) convtaps_mfma_tile<MT, NB, KC, WM, WN, FAST>(p, o, mt * MT, bt * NB, lds);
+    if (p.stamps && threadIdx.x == 0) p.stamps[4 * (int64_t)blockIdx.x + 1] = (int64_t)__builtin_amdgcn_s_memrealtime();
 }
 
 // ---- one-shot small-K path -----------------------------------------------------------------------------------------------
@@ -847,8 +857,8 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX, bool ASMMAC = true, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
+template <int RBX, bool ASMMAC = true>
+__global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
     const int64_t n_ct = (p.n_vecs + 255) / 256;
     const int64_t n_items = n_ct * n_rb;
     const int64_t chunk = (n_items + 7) >> 3;
@@ -1045,6 +1055,27 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
             if (rem > 0) {   // the last, partial round of resident workgroups (measured: pays even when it fills half the machine)
                 a.tail_main = (int32_t)(chunk - rem);
                 const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
+                if (const char* path = getenv("KN_STAMPS")) {       // DIAGNOSTIC: per-workgroup time stamps of this launch, appended to a file
+                    static int64_t* dbuf = nullptr;
+                    static int seq = 0;
+                    const size_t cap = (size_t)1 << 22;
+                    if (!dbuf && hipMalloc((void**)&dbuf, cap * 4 * sizeof(int64_t)) != hipSuccess) dbuf = nullptr;
+                    if (dbuf && (size_t)grid <= cap) {
+                        (void)hipMemsetAsync(dbuf, 0, (size_t)grid * 4 * sizeof(int64_t), s);
+                        a.stamps = dbuf;
+                        hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                        (void)hipStreamSynchronize(s);
+                        std::vector<int64_t> h((size_t)grid * 4);
+                        (void)hipMemcpy(h.data(), dbuf, h.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
+                        if (FILE* f = fopen(path, "ab")) {
+                            const int64_t hdr[4] = {(int64_t)0x7374616d70, (int64_t)seq++, grid, ((int64_t)a.n_pix << 32) | (int64_t)(a.cin_pad * 1000 + a.n_mt)};
+                            fwrite(hdr, sizeof(int64_t), 4, f);
+                            fwrite(h.data(), sizeof(int64_t), h.size(), f);
+                            fclose(f);
+                        }
+                        return;
+                    }
+                }
                 hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 return;
             }
@@ -1086,6 +1117,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     const int bt_inner = getenv("KN_BT_INNER") ? atoi(getenv("KN_BT_INNER")) : 0;              // experiment knobs, read per call
 
     a.bt_inner = bt_inner;
+    a.stamps = nullptr;
     a.sk_desc = A.sk_desc;
     a.sk_stride = (int32_t)A.sk_stride;
     a.sk_tab_rows = (int32_t)A.sk_tab_rows;
@@ -1101,9 +1133,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        // experiment knob (read per call): 6 waves per SIMD (80 VGPRs, 3 dwords of scratch) instead of 5 (88 VGPRs)
-        if (pipe && rbx == 16 && getenv("KN_EXACT_OCC6")) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true, 6>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
