@@ -9,6 +9,7 @@ the MI355X: layers exchange feature-major [D+1, N] blocks, ReLU is fused into th
 supported (the reference's KeyedModel.forward is N=1 only).
 """
 import copy
+import os
 import warnings
 from collections import OrderedDict
 import numpy as np
@@ -130,11 +131,14 @@ class KeyedModel(object):
         producing layer's kernel epilogue.  Stream-ordered on torch's current HIP stream; no host sync.
         `overlap`: run the batch as two half-batch column windows on two side streams, one kernel apart (see _forward_overlapped);
         None = automatically for device-resident feature-major batches that are a multiple of 256 images, False = never."""
+        forced = overlap is True
+        if overlap is None and os.environ.get('KN_NO_OVERLAP') == '1':      # A/B switch
+            overlap = False
         if overlap is None:
             overlap = (img_cipher.is_cuda and img_cipher.dtype == torch.float32 and img_cipher.dim() == 2 and img_cipher.shape[0] >= 256 and
                        img_cipher.shape[0] % 256 == 0 and img_cipher.t().is_contiguous() and not torch.cuda.is_current_stream_capturing())
         if overlap:
-            plan = self._overlap_plan(img_cipher.device, img_cipher.shape[0])
+            plan = self._overlap_plan(img_cipher.device, img_cipher.shape[0], force=forced)
             if plan is not None and img_cipher.is_cuda and img_cipher.dtype == torch.float32 and img_cipher.t().is_contiguous():
                 return self._forward_overlapped(img_cipher.detach(), plan)
         children = list(self._keynet.children())
@@ -154,18 +158,21 @@ class KeyedModel(object):
         return y
 
     # -- overlapped forward: two half-batch column windows on two HIP streams, one kernel apart ---------------------------------
-    def _overlap_plan(self, device, batch):
+    OVERLAP_MIN_MACS = 2e11      # below this much work per forward the launches are too short for the overlap to pay (LeNet: launch-bound)
+
+    def _overlap_plan(self, device, batch, force=False):
         """Per-layer launch list for the overlapped forward, or None when this key-net / batch does not qualify.  A layer is run
         per half only if the half batch keeps it on the same kernel instantiation as the whole batch (conv tiles are 128 or 256
         batch columns wide); the leading layers that do not (VGG conv1_1 / conv1_2 at 256 images) run whole on the caller's stream."""
-        key = (device.index, batch)
+        key = (device.index, batch, bool(force))
         plans = self.__dict__.setdefault('_overlap_plans', {})
         if key in plans:
             return plans[key]
         plan = None
         half = batch // 2
         children = list(self._keynet.children())
-        if batch % 8 == 0 and half % 128 == 0 and all(isinstance(c, (klayer.KeyedLayer, nn.ReLU)) for c in children):
+        big = force or self._macs_per_image() * batch >= self.OVERLAP_MIN_MACS
+        if big and batch % 8 == 0 and half % 128 == 0 and all(isinstance(c, (klayer.KeyedLayer, nn.ReLU)) for c in children):
             steps = []
             i = 0
             while i < len(children) and steps is not None:
@@ -203,6 +210,18 @@ class KeyedModel(object):
                                 streams=[torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)])
         plans[key] = plan
         return plan
+
+    def _macs_per_image(self):
+        """Multiply-adds per image of the keyed forward from the host descriptions (factored conv operators count their expansion)."""
+        total = 0.0
+        for c in self._keynet.children():
+            if isinstance(c, klayer.KeyedLayer):
+                W = c.W
+                if isinstance(W, ksp.Conv2dTiledMatrix) and W._taps is not None:
+                    total += float(len(W._taps['ent_out'])) * W._outshape[0] * W._inshape[0]
+                else:
+                    total += float(W.nnz())
+        return total
 
     def release_workspace(self):
         """Drop the activation workspaces and side streams of the overlapped forward (two ping-pong blocks per batch size)."""
