@@ -242,8 +242,10 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
 
     // U columns per step; the next step's U gathers are issued before this step's arithmetic (a dense Linear is ONE
     // group of ~500 bundles, i.e. 1-2 wavefronts per SIMD: latency must be hidden inside the wavefront).  Thin bundles
-    // (RBK <= 2: a 121-row Linear walking 785 columns) have registers to spare: 16/VEC gathers in flight.
-    constexpr int U = (RBK <= 2) ? 16 / VEC : ((VEC == 4) ? 4 : 8);
+    // (RBK <= 2: a 121-row Linear walking 785 columns, or fc6 of VGG-16: 2 x 256 outputs per wave walking 25 089 columns at two waves
+    // per SIMD) have registers to spare: 16 gathers in flight whatever the vector width (fc6 in exact mode 6.27 -> 5.30 ms; what
+    // bounds it then is re-gathering the 25.7 MB activation block once per wave from the Infinity Cache, ~10 TB/s).
+    constexpr int U = (RBK <= 2) ? 16 : ((VEC == 4) ? 4 : 8);
     int j = 0;
     float xcur[U][VEC], xnxt[U][VEC];
     if (ncol >= U) {

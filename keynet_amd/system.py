@@ -203,7 +203,10 @@ class KeyedModel(object):
                 split_at = join_at
                 while split_at > 0 and steps[split_at - 1][4]:
                     split_at -= 1
-                if join_at - split_at >= 2:
+                # what the overlap hides is the drain of the long-lived MFMA conv workgroups; the order-preserving kernels' workgroups
+                # are short (AllConvNet at 4096 images: 108.7 k images/s overlapped vs 109.2 k plain), so without such layers: plain
+                mfma = any((not (st[3] & _capi.KN_FLAG_EXACT)) for st in steps[split_at:join_at])
+                if join_at - split_at >= 2 and (mfma or force):
                     rows_max = max(st[1] for st in steps)
                     plan = dict(steps=steps, split_at=split_at, join_at=join_at,
                                 bufs=[torch.empty(rows_max * batch, dtype=torch.float32, device=device) for _ in range(2)],
