@@ -311,9 +311,124 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
     }
 }
 
+// Big pattern groups (a keyed nn.Linear under the bit-exact contract: fc6 of VGG-16 = 4 097 rows x 25 089 shared columns).  The
+// per-wave kernel above re-gathers the whole activation block once per wave (fc6: 2 049 waves x 25.7 MB = 52 GB from the Infinity
+// Cache) with two waves per SIMD to hide the gather latency.  Here a workgroup owns 32 member rows x 64 batch columns and walks the
+// shared column sequence in chunks of KS: the chunk's KS activation rows (one coalesced 256-byte segment each) and its KS x 32 values
+// are staged in LDS once for the four waves (double buffered, the next chunk's loads in flight in registers during the arithmetic),
+// each wave then reads one activation dword per lane and its 8 row values as two broadcast ds_read_b128 per column.  Strictly serial
+// over the stored columns per output element, mul then add: same rounding sequence as the reference.
+constexpr int BIG_ROWS = 32, BIG_KS = 32;
+
+__global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const int32_t* __restrict__ big_grp, const int32_t* __restrict__ big_r0,
+                                                            const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
+                                                            const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
+                                                            const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
+                                                            const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * BIG_KS * 64 + 2 * BIG_KS * BIG_ROWS];
+    float* Xs = lds;                          // [2][KS][64]
+    float* Vs = lds + 2 * BIG_KS * 64;        // [2][KS][32]
+    const int64_t n_ct = (n_vecs + 63) / 64;
+    int64_t item;
+    if (!decode_item(n_ct * n_big, item)) return;
+    const int64_t ct = item / n_big;
+    const int64_t wi = item - ct * n_big;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = big_grp[wi];
+    const int r0 = big_r0[wi];
+    const int cbeg = grp_colptr[g];
+    const int ncol = grp_colptr[g + 1] - cbeg;
+    const int rbeg = grp_rowptr[g];
+    const int nmem = grp_rowptr[g + 1] - rbeg;
+    const int rpad = (nmem + RB - 1) / RB * RB;
+    const int32_t* cols = grp_cols + cbeg;
+    const float* vals = grp_vals + grp_valptr[g] + r0;
+    const int64_t c = ct * 64 + lane;
+    const float* xc = X + (c < n_vecs ? c : 0);
+    // staging roles: wave w loads activation rows w, w+4, ... of the chunk (KS/4 per wave); thread t loads values (step t/8, rows 4*(t%8)..+3)
+    const int v_step = tid >> 3, v_r4 = (tid & 7) * 4;
+    const bool v_ok = (r0 + v_r4 < rpad);     // rows beyond the padded member count are not stored
+    float xr[BIG_KS / 4];
+    float vr[4];
+    auto gload = [&](int j0) {
+#pragma unroll
+        for (int u = 0; u < BIG_KS / 4; u++) {
+            const int j = j0 + wave + 4 * u;
+            xr[u] = (j < ncol) ? xc[(int64_t)cols[j] * ldx] : 0.0f;
+        }
+        const int j = j0 + v_step;
+#pragma unroll
+        for (int e = 0; e < 4; e++) vr[e] = 0.0f;
+        if (j < ncol && v_ok) {
+            const float4 t = *reinterpret_cast<const float4*>(vals + (int64_t)j * rpad + v_r4);      // rpad % 8 == 0, r0 % 32 == 0: 16-byte aligned
+            vr[0] = t.x; vr[1] = t.y; vr[2] = t.z; vr[3] = t.w;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < BIG_KS / 4; u++) Xs[(buf * BIG_KS + wave + 4 * u) * 64 + lane] = xr[u];
+        *reinterpret_cast<float4*>(Vs + (buf * BIG_KS + v_step) * BIG_ROWS + v_r4) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+    };
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) acc[r] = 0.0f;
+    const int n_chunks = (ncol + BIG_KS - 1) / BIG_KS;
+    gload(0);
+    lstore(0);
+    if (n_chunks > 1) gload(BIG_KS);
+    __syncthreads();
+    for (int q = 0; q < n_chunks; q++) {
+        const int buf = q & 1;
+        const float* xs = Xs + buf * BIG_KS * 64 + lane;
+        const float* vs = Vs + buf * BIG_KS * BIG_ROWS + wave * 8;
+        const int steps = (ncol - q * BIG_KS) < BIG_KS ? (ncol - q * BIG_KS) : BIG_KS;
+        if (steps == BIG_KS) {
+#pragma unroll
+            for (int j = 0; j < BIG_KS; j++) {
+                const float x = xs[j * 64];
+                const float4 a = *reinterpret_cast<const float4*>(vs + j * BIG_ROWS);
+                const float4 b = *reinterpret_cast<const float4*>(vs + j * BIG_ROWS + 4);
+                const float av[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float pr = av[r] * x;
+                    acc[r] = acc[r] + pr;
+                }
+            }
+        } else {
+            for (int j = 0; j < steps; j++) {
+                const float x = xs[j * 64];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const float pr = vs[j * BIG_ROWS + r] * x;
+                    acc[r] = acc[r] + pr;
+                }
+            }
+        }
+        if (q + 1 < n_chunks) {
+            lstore(buf ^ 1);                  // the other buffer's last readers finished before the barrier that ended chunk q-1
+            if (q + 2 < n_chunks) gload((q + 2) * BIG_KS);
+        }
+        __syncthreads();
+    }
+    if (c < n_vecs) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int m = r0 + wave * 8 + r;
+            if (m < nmem) {
+                float t = acc[r];
+                if (relu) t = relu_f(t);
+                Y[(int64_t)grp_rows[rbeg + m] * ldy + c] = t;
+            }
+        }
+    }
+}
+
 void csr_free(CsrDev& c) {
     void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
-                    c.work_grp, c.work_r0, c.loose_rows};
+                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c = CsrDev();
@@ -352,7 +467,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         }
         members[found].push_back((int32_t)r);
     }
-    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, loose;
+    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose;
     std::vector<int64_t> valptr{0};
     std::vector<float> vals;
     int64_t grouped_nnz = 0;
@@ -376,9 +491,16 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             in_group[(size_t)m[mi]] = 1;
         }
         valptr.push_back((int64_t)vals.size());
-        for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += RB) {
-            wgrp.push_back(gid);
-            wr0.push_back((int32_t)r0);
+        if ((int64_t)m.size() >= 256 && ncol >= 2048 && !getenv("KN_NO_BIG_GROUPS")) {      // a keyed nn.Linear: LDS-staged kernel, 32 rows per workgroup
+            for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += BIG_ROWS) {
+                bgrp.push_back(gid);
+                br0.push_back((int32_t)r0);
+            }
+        } else {
+            for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += RB) {
+                wgrp.push_back(gid);
+                wr0.push_back((int32_t)r0);
+            }
         }
         grouped_nnz += (int64_t)m.size() * ncol;
     }
@@ -392,6 +514,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     }
     A.n_groups = (int64_t)colptr.size() - 1;
     A.n_work = (int64_t)wgrp.size();
+    A.n_big = (int64_t)bgrp.size();
     A.n_loose = (int64_t)loose.size();
     A.grouped_nnz = grouped_nnz;
     int rc;
@@ -403,6 +526,8 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     if ((rc = upload(&A.grp_vals, vals.data(), vals.size()))) return rc;
     if ((rc = upload(&A.work_grp, wgrp.data(), wgrp.size()))) return rc;
     if ((rc = upload(&A.work_r0, wr0.data(), wr0.size()))) return rc;
+    if ((rc = upload(&A.big_grp, bgrp.data(), bgrp.size()))) return rc;
+    if ((rc = upload(&A.big_r0, br0.data(), br0.size()))) return rc;
     if ((rc = upload(&A.loose_rows, loose.data(), loose.size()))) return rc;
     return KN_OK;
 }
@@ -511,6 +636,13 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner
     // bundles / narrower vectors -- the walk over a row's columns is serial by contract, so parallelism can only come
     // from rows and batch columns.
+    if (A.n_big > 0) {
+        const int64_t items = ((n_vecs + 63) / 64) * A.n_big;
+        hipLaunchKernelGGL(csr_big_group_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+        KN_HIP(hipGetLastError());
+        if (A.n_work == 0 && A.n_loose == 0) return KN_OK;
+    }
     // short loose rows over a batch window that fills only half of a 256-column wave tile: one row per half wavefront
     if (A.n_work == 0 && A.n_loose >= 4096 && A.nnz <= 32 * A.n_loose && n_vecs % 128 == 0 && (n_vecs / 128) % 2 == 1 && (ldx % 4 == 0) && (ldy % 4 == 0) &&
         (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0)) {

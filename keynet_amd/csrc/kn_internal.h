@@ -46,6 +46,11 @@ struct CsrDev {
     int32_t* work_grp = nullptr;     // work items: (group, first member) pairs of RB rows
     int32_t* work_r0 = nullptr;
     int64_t n_work = 0;
+    // big groups (a keyed nn.Linear: thousands of member rows over thousands of shared columns) run in the LDS-staged kernel:
+    // work items = (group, first member) pairs of 32 rows; their members are NOT in work_grp/work_r0
+    int32_t* big_grp = nullptr;
+    int32_t* big_r0 = nullptr;
+    int64_t n_big = 0;
     int32_t* loose_rows = nullptr;
     int64_t n_loose = 0;
     int64_t grouped_nnz = 0;

@@ -291,6 +291,45 @@ def test_dense_linear_mfma_vs_oracle(n_vecs):
     assert np.array_equal(small.torchdot(xd, exact=False).cpu().numpy(), oracle.csr_matvecs(Ms.shape, Ms.indptr, Ms.indices, Ms.data, X))
 
 
+@pytest.mark.parametrize('outs,ins,n_vecs', [(300, 2500, 1), (300, 2500, 100), (1000, 4100, 256), (257, 2048, 64), (513, 3000, 130)])
+def test_big_pattern_group_kernel_vs_oracle(outs, ins, n_vecs):
+    """A keyed nn.Linear under the bit-exact contract: hundreds of rows sharing one (unsorted) column sequence of thousands of columns
+    run in the LDS-staged workgroup kernel (csr_big_group_kernel: 32 rows x 64 batch columns per workgroup, chunks of 32 columns);
+    row counts that do not fill the last 32-row block or 8-row bundle, column counts that do not fill the last chunk, ragged
+    batches, the loose homogeneous row next to it.  Bit-exact vs the oracle; KN_NO_BIG_GROUPS (read at create) gives the per-wave
+    kernel for a bit-for-bit cross-check."""
+    import os
+    rng = np.random.RandomState(outs + ins + n_vecs)
+    D = np.zeros((outs + 1, ins + 1), dtype=np.float32)
+    D[:-1, :-1] = (rng.randn(outs, ins) / np.sqrt(ins)).astype(np.float32)
+    D[:-1, -1] = rng.randn(outs).astype(np.float32)
+    D[-1, -1] = 1.0
+    perm = rng.permutation(ins + 1)
+    M = scipy.sparse.csr_matrix(D)
+    rowlen = np.diff(M.indptr)
+    assert np.all(rowlen[:-1] == ins + 1)
+    idx = M.indices.copy()
+    dat = M.data.copy()
+    for r in range(outs):                                       # the same unsorted column order in every row (what a keyed Linear stores)
+        idx[M.indptr[r]:M.indptr[r + 1]] = M.indices[M.indptr[r]:M.indptr[r + 1]][perm]
+        dat[M.indptr[r]:M.indptr[r + 1]] = M.data[M.indptr[r]:M.indptr[r + 1]][perm]
+    M = scipy.sparse.csr_matrix((dat, idx, M.indptr), shape=M.shape)
+    X = np.vstack((rng.randn(ins, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data, X)
+    xd = torch.as_tensor(X).to(dev())
+    W = ksp.SparseMatrix(M)
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu).cpu().numpy()
+        assert np.array_equal(y, np.maximum(ref, 0) if relu else ref), (outs, ins, n_vecs, relu)
+    os.environ['KN_NO_BIG_GROUPS'] = '1'
+    try:
+        W2 = ksp.SparseMatrix(M)
+        y2 = W2.torchdot(xd).cpu().numpy()
+    finally:
+        os.environ.pop('KN_NO_BIG_GROUPS', None)
+    assert np.array_equal(y2, ref)
+
+
 def test_dense_handle_on_two_streams_concurrently():
     """include/keynet_hip.h: one handle may be driven from several streams at once.  A dense (split-K MFMA) operator keeps its
     partial sums in a PER-STREAM workspace: two streams hammering one handle with different inputs (and batch sizes that force
