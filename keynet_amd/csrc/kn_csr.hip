@@ -15,6 +15,7 @@
 // Work items are dealt to XCDs in contiguous chunks (blockIdx%8 labels the XCD) so that the blocks resident on one
 // XCD share a batch-column tile of X in that XCD's 4 MiB L2.
 #include "kn_internal.h"
+#include <type_traits>
 #include <unordered_map>
 #include <algorithm>
 #include <cstring>
@@ -324,11 +325,70 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
                                                             const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
                                                             const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
                                                             const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
-                                                            const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+                                                            const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu,
+                                                            int64_t grid_big, const int32_t* __restrict__ long_rows, int64_t n_long,
+                                                            const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ data) {
     __shared__ __attribute__((aligned(16))) float lds[2 * BIG_KS * 64 + 2 * BIG_KS * BIG_ROWS];
     float* Xs = lds;                          // [2][KS][64]
     float* Vs = lds + 2 * BIG_KS * 64;        // [2][KS][32]
     const int64_t n_ct = (n_vecs + 63) / 64;
+    if ((int64_t)blockIdx.x >= grid_big) {
+        // ---- long loose rows: workgroup = one row x four 64-column tiles (one per wave); 32 gathers in flight per wave --------------
+        const int64_t tiles4 = (n_ct + 3) / 4;
+        const int64_t lb = (int64_t)blockIdx.x - grid_big;
+        const int64_t ri = lb / tiles4;
+        const int64_t ctl = (lb - ri * tiles4) * 4 + (threadIdx.x >> 6);
+        if (ri >= n_long || ctl >= n_ct) return;
+        const int lane = threadIdx.x & 63;
+        const int row = long_rows[ri];
+        const int start = indptr[row], end = indptr[row + 1];
+        const int64_t c = ctl * 64 + lane;
+        const float* xc = X + (c < n_vecs ? c : 0);
+        float acc = 0.0f;
+        float xa[32], xb[32];
+        int mycol = 0, ncol_ = 0;
+        float myval = 0.0f, nval_ = 0.0f;
+        if (start + lane < end) {
+            mycol = indices[start + lane];
+            myval = data[start + lane];
+        }
+#pragma unroll
+        for (int i = 0; i < 32; i++) xa[i] = xc[(int64_t)__builtin_amdgcn_readlane(mycol, i) * ldx];       // lanes past the end hold column 0: a valid row
+        for (int base = start; base < end; base += 64) {
+            const int n = (end - base) < 64 ? (end - base) : 64;
+            if (base + 64 + lane < end) {
+                ncol_ = indices[base + 64 + lane];
+                nval_ = data[base + 64 + lane];
+            } else {
+                ncol_ = 0;
+                nval_ = 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; i++) xb[i] = xc[(int64_t)__builtin_amdgcn_readlane(mycol, 32 + i) * ldx];
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                if (i < n) {
+                    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), i));
+                    const float pr = a * xa[i];
+                    acc = acc + pr;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 32; i++) xa[i] = xc[(int64_t)__builtin_amdgcn_readlane(ncol_, i) * ldx];
+#pragma unroll
+            for (int i = 0; i < 32; i++) {
+                if (32 + i < n) {
+                    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), 32 + i));
+                    const float pr = a * xb[i];
+                    acc = acc + pr;
+                }
+            }
+            mycol = ncol_;
+            myval = nval_;
+        }
+        if (c < n_vecs) Y[(int64_t)row * ldy + c] = relu ? relu_f(acc) : acc;
+        return;
+    }
     int64_t item;
     if (!decode_item(n_ct * n_big, item)) return;
     const int64_t ct = item / n_big;
@@ -350,9 +410,12 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
     // staging roles: wave w loads activation rows w, w+4, ... of the chunk (KS/4 per wave); thread t loads values (step t/8, rows 4*(t%8)..+3)
     const int v_step = tid >> 3, v_r4 = (tid & 7) * 4;
     const bool v_ok = (r0 + v_r4 < rpad);     // rows beyond the padded member count are not stored
-    float xr[BIG_KS / 4];
-    float vr[4];
-    auto gload = [&](int j0) {
+    // register ring: chunk k waits in set k % PD from its request until it is written to LDS, PD - 1 chunk-times later.  Two
+    // workgroups per CU (fc6: 516 work items) cannot hide an Infinity-Cache round trip behind one chunk of arithmetic; four chunks can.
+    constexpr int PD = 4;
+    float xr0[BIG_KS / 4], xr1[BIG_KS / 4], xr2[BIG_KS / 4], xr3[BIG_KS / 4];      // named sets: an indexed 2-D array would live in scratch
+    float vr0[4], vr1[4], vr2[4], vr3[4];
+    auto gload = [&](float (&xr)[BIG_KS / 4], float (&vr)[4], int j0) {
 #pragma unroll
         for (int u = 0; u < BIG_KS / 4; u++) {
             const int j = j0 + wave + 4 * u;
@@ -366,7 +429,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
             vr[0] = t.x; vr[1] = t.y; vr[2] = t.z; vr[3] = t.w;
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const float (&xr)[BIG_KS / 4], const float (&vr)[4], int buf) {
 #pragma unroll
         for (int u = 0; u < BIG_KS / 4; u++) Xs[(buf * BIG_KS + wave + 4 * u) * 64 + lane] = xr[u];
         *reinterpret_cast<float4*>(Vs + (buf * BIG_KS + v_step) * BIG_ROWS + v_r4) = make_float4(vr[0], vr[1], vr[2], vr[3]);
@@ -375,11 +438,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 #pragma unroll
     for (int r = 0; r < 8; r++) acc[r] = 0.0f;
     const int n_chunks = (ncol + BIG_KS - 1) / BIG_KS;
-    gload(0);
-    lstore(0);
-    if (n_chunks > 1) gload(BIG_KS);
-    __syncthreads();
-    for (int q = 0; q < n_chunks; q++) {
+    auto compute = [&](int q) {
         const int buf = q & 1;
         const float* xs = Xs + buf * BIG_KS * 64 + lane;
         const float* vs = Vs + buf * BIG_KS * BIG_ROWS + wave * 8;
@@ -407,11 +466,30 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
                 }
             }
         }
+    };
+    // one step of the pipeline for chunk q: arithmetic on chunk q from LDS; chunk q+1 (waiting in the register set passed in) -> the
+    // other LDS buffer; request chunk q+1+PD into that set
+    auto step = [&](int q, float (&xn)[BIG_KS / 4], float (&vn)[4]) {
+        if (q >= n_chunks) return;
+        compute(q);
         if (q + 1 < n_chunks) {
-            lstore(buf ^ 1);                  // the other buffer's last readers finished before the barrier that ended chunk q-1
-            if (q + 2 < n_chunks) gload((q + 2) * BIG_KS);
+            lstore(xn, vn, (q + 1) & 1);       // that buffer's last readers finished before the barrier that ended chunk q-1
+            if (q + 1 + PD < n_chunks) gload(xn, vn, (q + 1 + PD) * BIG_KS);
         }
         __syncthreads();
+    };
+    gload(xr0, vr0, 0);
+    gload(xr1, vr1, 1 * BIG_KS);
+    gload(xr2, vr2, 2 * BIG_KS);
+    gload(xr3, vr3, 3 * BIG_KS);
+    lstore(xr0, vr0, 0);
+    gload(xr0, vr0, PD * BIG_KS);
+    __syncthreads();
+    for (int q = 0; q < n_chunks; q += PD) {      // chunk k waits in set k % PD
+        step(q, xr1, vr1);
+        step(q + 1, xr2, vr2);
+        step(q + 2, xr3, vr3);
+        step(q + 3, xr0, vr0);
     }
     if (c < n_vecs) {
 #pragma unroll
@@ -428,7 +506,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 
 void csr_free(CsrDev& c) {
     void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
-                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0};
+                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c = CsrDev();
@@ -504,8 +582,13 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         }
         grouped_nnz += (int64_t)m.size() * ncol;
     }
+    std::vector<int32_t> longrows;
+    const bool use_long = !getenv("KN_NO_BIG_GROUPS");
     for (int64_t r = 0; r < rows; r++)
-        if (!in_group[(size_t)r]) loose.push_back((int32_t)r);   // includes empty rows (they must still be zeroed)
+        if (!in_group[(size_t)r]) {
+            if (use_long && indptr[r + 1] - indptr[r] >= 1024) longrows.push_back((int32_t)r);   // one wave would walk them latency-bound: deep-queue role
+            else loose.push_back((int32_t)r);                     // includes empty rows (they must still be zeroed)
+        }
     // loose rows of a big operator (keyed pooling: ~9 non-zeros per row, windows overlap): order them for L2 reuse of the gathers
     if (loose.size() >= 4096 && !getenv("KN_NO_ROW_ORDER")) {
         int64_t lnnz = 0;
@@ -515,6 +598,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     A.n_groups = (int64_t)colptr.size() - 1;
     A.n_work = (int64_t)wgrp.size();
     A.n_big = (int64_t)bgrp.size();
+    A.n_long = (int64_t)longrows.size();
     A.n_loose = (int64_t)loose.size();
     A.grouped_nnz = grouped_nnz;
     int rc;
@@ -528,6 +612,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     if ((rc = upload(&A.work_r0, wr0.data(), wr0.size()))) return rc;
     if ((rc = upload(&A.big_grp, bgrp.data(), bgrp.size()))) return rc;
     if ((rc = upload(&A.big_r0, br0.data(), br0.size()))) return rc;
+    if ((rc = upload(&A.long_rows, longrows.data(), longrows.size()))) return rc;
     if ((rc = upload(&A.loose_rows, loose.data(), loose.size()))) return rc;
     return KN_OK;
 }
@@ -636,10 +721,12 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner
     // bundles / narrower vectors -- the walk over a row's columns is serial by contract, so parallelism can only come
     // from rows and batch columns.
-    if (A.n_big > 0) {
-        const int64_t items = ((n_vecs + 63) / 64) * A.n_big;
-        hipLaunchKernelGGL(csr_big_group_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
-                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+    if (A.n_big > 0 || A.n_long > 0) {
+        const int64_t n_ct = (n_vecs + 63) / 64;
+        const int64_t grid_big = ((n_ct * A.n_big + 7) / 8) * 8;
+        const int64_t grid_long = A.n_long * ((n_ct + 3) / 4);
+        hipLaunchKernelGGL(csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, grid_big, A.long_rows, A.n_long, A.indptr, A.indices, A.data);
         KN_HIP(hipGetLastError());
         if (A.n_work == 0 && A.n_loose == 0) return KN_OK;
     }

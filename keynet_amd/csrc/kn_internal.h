@@ -51,6 +51,10 @@ struct CsrDev {
     int32_t* big_grp = nullptr;
     int32_t* big_r0 = nullptr;
     int64_t n_big = 0;
+    // loose rows with thousands of non-zeros (a row of a keyed nn.Linear whose pattern lost an entry to an exact zero): one wave per
+    // (row, 64 batch columns) with a deep gather queue, as extra workgroups of the big-group launch
+    int32_t* long_rows = nullptr;
+    int64_t n_long = 0;
     int32_t* loose_rows = nullptr;
     int64_t n_loose = 0;
     int64_t grouped_nnz = 0;
