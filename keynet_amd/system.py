@@ -161,9 +161,9 @@ class KeyedModel(object):
     OVERLAP_MIN_MACS = 2e11      # below this much work per forward the launches are too short for the overlap to pay (LeNet: launch-bound)
 
     def _overlap_plan(self, device, batch, force=False):
-        """Per-layer launch list for the overlapped forward, or None when this key-net / batch does not qualify.  A layer is run
+        """Launch list + segments for the overlapped forward, or None when this key-net / batch does not qualify.  A layer is run
         per half only if the half batch keeps it on the same kernel instantiation as the whole batch (conv tiles are 128 or 256
-        batch columns wide); the leading layers that do not (VGG conv1_1 / conv1_2 at 256 images) run whole on the caller's stream."""
+        batch columns wide) and it is a matrix-core conv layer; see the segment rule below."""
         key = (device.index, batch, bool(force))
         plans = self.__dict__.setdefault('_overlap_plans', {})
         if key in plans:
@@ -193,22 +193,52 @@ class KeyedModel(object):
                 else:
                     (op, ex, ok) = (W._device_op(device), True, True)
                 flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if ex else 0)
-                steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok, 'Linear' in c._layertype))
+                steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok, 'Linear' in c._layertype, isinstance(W, ksp.Conv2dTiledMatrix)))
                 i += 2 if fuse else 1
             if steps:
-                # the trailing fully connected layers are too small to fill the chip per half: the streams join before them
-                join_at = len(steps)
-                while join_at > 0 and steps[join_at - 1][5]:
-                    join_at -= 1
-                split_at = join_at
-                while split_at > 0 and steps[split_at - 1][4]:
-                    split_at -= 1
-                # what the overlap hides is the drain of the long-lived MFMA conv workgroups; the order-preserving kernels' workgroups
-                # are short (AllConvNet at 4096 images: 108.7 k images/s overlapped vs 109.2 k plain), so without such layers: plain
-                mfma = any((not (st[3] & _capi.KN_FLAG_EXACT)) for st in steps[split_at:join_at])
-                if join_at - split_at >= 2 and (mfma or force):
+                # Segments: maximal runs of >= 2 consecutive MFMA conv layers whose tiles survive the halving run SPLIT (that is where the
+                # long-lived workgroups and their drains are); everything else -- pooling (a half-batch window halves its gathered row
+                # segments: pool1_2 0.93 ms as two halves against 0.79 ms whole), the fc layers, layers that need 256-wide tiles -- runs
+                # WHOLE on the caller's stream between two joins.  Without a split segment (order-preserving nets: AllConvNet at 4096 images
+                # reads 108.7 k images/s overlapped vs 109.2 k plain) the plain forward is used.
+                def splittable(st):
+                    return st[4] and st[6] and not (st[3] & _capi.KN_FLAG_EXACT)
+                segs = []
+                k = 0
+                while k < len(steps):
+                    j = k
+                    while j < len(steps) and splittable(steps[j]):
+                        j += 1
+                    if j - k >= 2:
+                        segs.append(('split', k, j))
+                        k = j
+                    else:
+                        j = max(j, k + 1)
+                        if segs and segs[-1][0] == 'whole':
+                            segs[-1] = ('whole', segs[-1][1], j)
+                        else:
+                            segs.append(('whole', k, j))
+                        k = j
+                if force and not any(sg[0] == 'split' for sg in segs):      # tests: split every run of >= 2 layers the halving allows
+                    segs = []
+                    k = 0
+                    while k < len(steps):
+                        j = k
+                        while j < len(steps) and steps[j][4] and not steps[j][5]:
+                            j += 1
+                        if j - k >= 2:
+                            segs.append(('split', k, j))
+                            k = j
+                        else:
+                            j = max(j, k + 1)
+                            if segs and segs[-1][0] == 'whole':
+                                segs[-1] = ('whole', segs[-1][1], j)
+                            else:
+                                segs.append(('whole', k, j))
+                            k = j
+                if any(sg[0] == 'split' for sg in segs):
                     rows_max = max(st[1] for st in steps)
-                    plan = dict(steps=steps, split_at=split_at, join_at=join_at,
+                    plan = dict(steps=steps, segments=segs,
                                 bufs=[torch.empty(rows_max * batch, dtype=torch.float32, device=device) for _ in range(2)],
                                 streams=[torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)])
         plans[key] = plan
@@ -237,39 +267,44 @@ class KeyedModel(object):
         stream 0: the two streams' launch boundaries then never coincide, and the workgroups one stream has queued take over the
         CUs that the other stream's draining kernel frees (the drain of a launch costs ~0.3 ms of a 6.5 ms conv layer otherwise).
         Same kernels, same per-column arithmetic: bit-identical to the single-stream forward."""
-        (steps, split_at, join_at, bufs, side) = (plan['steps'], plan['split_at'], plan['join_at'], plan['bufs'], plan['streams'])
+        (steps, segs, bufs, side) = (plan['steps'], plan['segments'], plan['bufs'], plan['streams'])
         N = x.shape[0]
         half = N // 2
         main = torch.cuda.current_stream(x.device)
-        xt = x.t()
-        ptr_in = xt.data_ptr()
+        ptr0 = x.t().data_ptr()
+        n = len(steps)
+
+        def src_of(k):
+            return ptr0 if k == 0 else bufs[(k - 1) % 2].data_ptr()
+
         with torch.cuda.device(x.device):
-            for k in range(split_at):
-                (op, rows, cols, flags) = steps[k][:4]
-                op.spmm(ptr_in, N, N, bufs[k % 2].data_ptr(), N, flags, main.cuda_stream)
-                ptr_in = bufs[k % 2].data_ptr()
-            for st in side:
-                st.wait_stream(main)
-            n = len(steps)
-            for k in range(split_at, join_at + 1):
-                for (h, st) in enumerate(side):
-                    kk = k - h                                     # stream 1 runs one kernel behind stream 0
-                    if kk < split_at or kk >= join_at:
-                        continue
-                    (op, rows, cols, flags) = steps[kk][:4]
-                    src = ptr_in if kk == split_at else bufs[(kk - 1) % 2].data_ptr()
-                    op.spmm(src + 4 * half * h, N, half, bufs[kk % 2].data_ptr() + 4 * half * h, N, flags, st.cuda_stream)
-                if k == split_at:
-                    ev = torch.cuda.Event()
-                    ev.record(side[0])
-                    side[1].wait_event(ev)
-            for st in side:
-                main.wait_stream(st)
-            for k in range(join_at, n):                            # whole batch again, on the caller's stream
-                (op, rows, cols, flags) = steps[k][:4]
-                op.spmm(bufs[(k - 1) % 2].data_ptr(), N, N, bufs[k % 2].data_ptr(), N, flags, main.cuda_stream)
+            if plan.get('done') is not None:
+                main.wait_event(plan['done'])                      # the workspaces are shared by successive calls, whatever stream they come from
+            for (kind, k0, k1) in segs:
+                if kind == 'whole':
+                    for k in range(k0, k1):
+                        (op, rows, cols, flags) = steps[k][:4]
+                        op.spmm(src_of(k), N, N, bufs[k % 2].data_ptr(), N, flags, main.cuda_stream)
+                    continue
+                for st in side:
+                    st.wait_stream(main)
+                for k in range(k0, k1 + 1):
+                    for (h, st) in enumerate(side):
+                        kk = k - h                                 # stream 1 runs one kernel behind stream 0
+                        if kk < k0 or kk >= k1:
+                            continue
+                        (op, rows, cols, flags) = steps[kk][:4]
+                        op.spmm(src_of(kk) + 4 * half * h, N, half, bufs[kk % 2].data_ptr() + 4 * half * h, N, flags, st.cuda_stream)
+                    if k == k0:
+                        ev = torch.cuda.Event()
+                        ev.record(side[0])
+                        side[1].wait_event(ev)
+                for st in side:
+                    main.wait_stream(st)
             rows_out = steps[-1][1]
             out = bufs[(n - 1) % 2][:rows_out * N].view(rows_out, N).clone()      # the workspace is reused by the next call
+            plan['done'] = torch.cuda.Event()
+            plan['done'].record(main)
         return out.t()
 
     def exact_mode(self, flag):

@@ -145,7 +145,7 @@ def test_overlapped_forward_is_bit_identical(golden, name, n):
     x = torch.cat([xc] * ((n + m - 1) // m), dim=0)[:n].to(dev()).t().contiguous().t()
     assert knet._overlap_plan(x.device, n) is None                # these nets are small: the automatic choice is the plain forward
     plan = knet._overlap_plan(x.device, n, force=True)
-    assert plan is not None and plan['join_at'] - plan['split_at'] >= 2 and plan['join_at'] < len(plan['steps'])    # trailing fc layers run whole
+    assert plan is not None and any(sg[0] == 'split' and sg[2] - sg[1] >= 2 for sg in plan['segments']) and plan['segments'][-1][0] == 'whole'   # trailing fc layers run whole
     y0 = knet.forward_linear(x, overlap=False)
     for _ in range(3):
         y1 = knet.forward_linear(x, overlap=True)
