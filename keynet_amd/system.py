@@ -196,46 +196,23 @@ class KeyedModel(object):
                 steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok, 'Linear' in c._layertype, isinstance(W, ksp.Conv2dTiledMatrix)))
                 i += 2 if fuse else 1
             if steps:
-                # Segments: maximal runs of >= 2 consecutive MFMA conv layers whose tiles survive the halving run SPLIT (that is where the
-                # long-lived workgroups and their drains are); everything else -- pooling (a half-batch window halves its gathered row
-                # segments: pool1_2 0.93 ms as two halves against 0.79 ms whole), the fc layers, layers that need 256-wide tiles -- runs
-                # WHOLE on the caller's stream between two joins.  Without a split segment (order-preserving nets: AllConvNet at 4096 images
-                # reads 108.7 k images/s overlapped vs 109.2 k plain) the plain forward is used.
-                def splittable(st):
-                    return st[4] and st[6] and not (st[3] & _capi.KN_FLAG_EXACT)
+                # ONE split region: from the first layer after which every layer keeps its kernel instantiation on a half batch (VGG at 256
+                # images: conv1_1 / conv1_2 need 256-wide tiles and run whole) up to the trailing fully connected layers (too small to fill
+                # the chip per half: whole again after the join).  Measured alternatives: joining the streams at every pooling layer so
+                # that the pools run whole (a half-batch window halves their gathered row segments: pool1_2 0.93 ms as two halves against
+                # 0.79 ms whole) exposes two drains per conv run and is SLOWER than the plain forward (58.96 vs 58.34 ms); nets without
+                # matrix-core conv layers have short-lived workgroups and gain nothing (AllConvNet at 4096 images: 108.7 k images/s
+                # overlapped vs 109.2 k plain), so for them the plain forward is used.
+                join_at = len(steps)
+                while join_at > 0 and steps[join_at - 1][5]:
+                    join_at -= 1
+                split_at = join_at
+                while split_at > 0 and steps[split_at - 1][4]:
+                    split_at -= 1
+                mfma = any(st[6] and not (st[3] & _capi.KN_FLAG_EXACT) for st in steps[split_at:join_at])
                 segs = []
-                k = 0
-                while k < len(steps):
-                    j = k
-                    while j < len(steps) and splittable(steps[j]):
-                        j += 1
-                    if j - k >= 2:
-                        segs.append(('split', k, j))
-                        k = j
-                    else:
-                        j = max(j, k + 1)
-                        if segs and segs[-1][0] == 'whole':
-                            segs[-1] = ('whole', segs[-1][1], j)
-                        else:
-                            segs.append(('whole', k, j))
-                        k = j
-                if force and not any(sg[0] == 'split' for sg in segs):      # tests: split every run of >= 2 layers the halving allows
-                    segs = []
-                    k = 0
-                    while k < len(steps):
-                        j = k
-                        while j < len(steps) and steps[j][4] and not steps[j][5]:
-                            j += 1
-                        if j - k >= 2:
-                            segs.append(('split', k, j))
-                            k = j
-                        else:
-                            j = max(j, k + 1)
-                            if segs and segs[-1][0] == 'whole':
-                                segs[-1] = ('whole', segs[-1][1], j)
-                            else:
-                                segs.append(('whole', k, j))
-                            k = j
+                if join_at - split_at >= 2 and (mfma or force):
+                    segs = [sg for sg in (('whole', 0, split_at), ('split', split_at, join_at), ('whole', join_at, len(steps))) if sg[2] > sg[1]]
                 if any(sg[0] == 'split' for sg in segs):
                     rows_max = max(st[1] for st in steps)
                     plan = dict(steps=steps, segments=segs,

@@ -59,10 +59,9 @@ def test_keyed_vgg16_equals_plain_network(vgg):
     # the overlapped forward (two half-batch windows on two streams, one kernel apart: the default at this batch) and the plain
     # single-stream forward run the same kernels on the same columns: bit-identical
     plan = knet._overlap_plan(x256.device, 256)
-    # conv1_1 / conv1_2 need 256-wide tiles and run whole, like every pooling layer and fc6-8; the conv runs between two pools are split
+    # conv1_1 / conv1_2 need 256-wide tiles and run whole, like fc6-8 after the join; everything between is split
     assert plan is not None and len(plan['steps']) == 21
-    assert plan['segments'] == [('whole', 0, 3), ('split', 3, 5), ('whole', 5, 6), ('split', 6, 9), ('whole', 9, 10), ('split', 10, 13), ('whole', 13, 14),
-                                ('split', 14, 17), ('whole', 17, 21)]
+    assert plan['segments'] == [('whole', 0, 2), ('split', 2, 18), ('whole', 18, 21)]
     assert torch.equal(y256, knet.forward_linear(x256, overlap=False))
     assert torch.equal(y256, knet.forward_linear(x256, overlap=True))                    # and repeatable on reused workspaces
     y512 = knet.forward_linear(torch.cat([x256, x256], dim=0).t().contiguous().t())
