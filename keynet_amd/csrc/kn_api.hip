@@ -205,18 +205,6 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
         std::vector<int32_t> ids((size_t)HoWo);
         for (int64_t o = 0; o < HoWo; o++) ids[(size_t)o] = (int32_t)o;
         pix_order = locality_order(ids, pix_ptr.data(), slot_in.data(), HiWi, 64, 1 << 30);
-        // Longest work first inside every XCD's share of the order (experiment knob KN_C_BORDER_LAST, read at create): border
-        // pixels of the un-keyed image have 4 or 6 slots instead of 9, i.e. shorter K loops; dispatched LAST they shorten the
-        // drain of a launch (the final workgroups of a CU run with ever fewer partners on the matrix pipe).
-        if (getenv("KN_C_BORDER_LAST") && atoi(getenv("KN_C_BORDER_LAST")) > 0) {
-            const int64_t seg = (HoWo + 7) / 8;
-            for (int64_t x = 0; x < 8; x++) {
-                const int64_t lo = std::min<int64_t>(x * seg, HoWo), hi = std::min<int64_t>((x + 1) * seg, HoWo);
-                std::stable_sort(pix_order.begin() + lo, pix_order.begin() + hi, [&](int32_t a, int32_t b) {
-                    return (pix_ptr[(size_t)a + 1] - pix_ptr[(size_t)a]) > (pix_ptr[(size_t)b + 1] - pix_ptr[(size_t)b]);
-                });
-            }
-        }
     }
     std::vector<float> lastcol;
     if (b.has_last) {

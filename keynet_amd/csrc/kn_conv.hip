@@ -17,9 +17,11 @@
 // streams the tile out 16 bytes per lane through a per-wavefront LDS transposition (kn_store_tile).
 // Work items (pixel, batch tile, Cout tile) are dealt to the 8 XCDs in contiguous chunks with the Cout tile fastest,
 // so the workgroups that share one gathered X tile run on one XCD and hit its L2; the last partial round of workgroups is
-// split into quarter tiles (TAIL).  Other kernels in this file: convtaps_smallk_kernel (first layer of an image net: whole
-// contraction <= 28 rows, write-bound), convtaps_exact_pipe_kernel / convtaps_exact_kernel (KN_FLAG_EXACT: the reference's
-// accumulation order and rounding on the VALU, bit-exact), conv_lastrow_kernel (homogeneous output row).
+// split into quarter tiles (TAIL), and launches with only a few rounds of resident workgroups take the occupancy whose partial
+// round is smaller.  Other kernels in this file: convtaps_smallk_pipe_kernel (first layer of an image net: whole contraction
+// <= 28 rows, write-bound: persistent workgroups, the next pixel's gathers and MFMAs run under the current pixel's stores;
+// convtaps_smallk_kernel = its one-shot predecessor and fallback), convtaps_exact_pipe_kernel / convtaps_exact_kernel
+// (KN_FLAG_EXACT: the reference's accumulation order and rounding on the VALU, bit-exact), conv_lastrow_kernel (homogeneous row).
 #include "kn_internal.h"
 #include <type_traits>
 #include <cstdio>
@@ -101,23 +103,18 @@ struct ConvArgs {
     int32_t n_mt, n_bt, n_pix, max_slots, ntaps, wide_store;
     int64_t last_in_row;   // Cin*HiWi (row of X holding the homogeneous coordinate)
     int32_t tail_main;     // work items per XCD chunk computed as full tiles; the rest of the chunk runs as 4 quarter tiles each
-    int32_t bt_inner;      // item order: 0 = (bt, pixel, mt) with the batch tile slowest; 1 = (pixel, bt, mt): an XCD owns a pixel range for every batch tile
     int64_t* stamps;          // diagnostic build only (KN_STAMPS): per-workgroup {start, end} of s_memrealtime, XCC id, kind; null otherwise
     const int32_t* sk_desc;   // small-K pipeline: per-pixel descriptors in processing order (ConvTapsDev::sk_desc), or null
     int32_t sk_stride, sk_tab_rows;
 };
 
-// item -> (Cout tile, position in the pixel order, batch tile); the Cout tile is always fastest (its workgroups share one gathered X tile)
+// item -> (Cout tile, position in the pixel order, batch tile): the Cout tile is fastest (its workgroups share one gathered X tile),
+// the batch tile slowest (measured: batch tile inner, i.e. an XCD owning a pixel range for every batch tile, is neutral)
 __device__ __forceinline__ void decode_conv_item(const ConvArgs& p, const int64_t item, int& mt, int& pi, int& bt) {
     mt = (int)(item % p.n_mt);
     const int64_t t1 = item / p.n_mt;
-    if (p.bt_inner) {
-        bt = (int)(t1 % p.n_bt);
-        pi = (int)(t1 / p.n_bt);
-    } else {
-        pi = (int)(t1 % p.n_pix);
-        bt = (int)(t1 / p.n_pix);
-    }
+    pi = (int)(t1 % p.n_pix);
+    bt = (int)(t1 / p.n_pix);
 }
 
 // FAST = (batch 16-byte aligned and a multiple of the batch tile NB) && (all coefficients 1: identity / permutation keys) && (Cin % KC == 0):
@@ -1114,9 +1111,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
     a.last_in_row = A.Cin * A.Hin * A.Win;
-    const int bt_inner = getenv("KN_BT_INNER") ? atoi(getenv("KN_BT_INNER")) : 0;              // experiment knobs, read per call
 
-    a.bt_inner = bt_inner;
     a.stamps = nullptr;
     a.sk_desc = A.sk_desc;
     a.sk_stride = (int32_t)A.sk_stride;
