@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX, bool ASMMAC = true>
+template <int RBX>
 __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
     const int64_t n_ct = (p.n_vecs + 255) / 256;
     const int64_t n_items = n_ct * n_rb;
@@ -878,9 +878,10 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     const bool active = c < p.n_vecs;
     const uint32_t lane_off_bytes = 4u * (uint32_t)(active ? c : 0);      // byte offset: (uniform base) + zext(VGPR) selects the saddr load form
 
-    f32x4 acc[RBX];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc[RBX][2];                                                    // [output channel][columns 0-1 | 2-3]
 #pragma unroll
-    for (int r = 0; r < RBX; r++) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RBX; r++) acc[r][0] = acc[r][1] = f32x2{0.f, 0.f};
 
     if (n_slots > 0) {
         // lane s: element offsets of slot s (32-bit: the launcher checks the ranges)
@@ -889,71 +890,99 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             my_xoff = p.slot_in[s_beg + lane] * (int)p.ldx;
             my_aoff = p.slot_tap[s_beg + lane] * (p.cin_pad * p.cout_pad);
         }
-        const int ch_x = p.HiWi * (int)p.ldx;                   // one input channel of X
+        const int ch_x = __builtin_amdgcn_readfirstlane(p.HiWi * (int)p.ldx);      // one input channel of X
         const float* a_base = p.tapsT + co0;
         const int n_q = n_slots * p.Cin;
         int s = 0, ci_x = 0, ci_a = 0;                           // wave-uniform walk: slot inner, channel outer
         int q_next = 0;                                          // step whose operands are fetched next
-        auto fetch = [&](f32x4& xr, float (&ar)[RBX]) {
+        // Operand fetch of one step, written as inline asm so that both addresses stay scalar: the activation row is a saddr-form vector
+        // load (wave-uniform 64-bit base in SGPRs + the lane's constant byte offset: no per-step vector address arithmetic), the step's
+        // RBX tap values one s_load into an SGPR tuple that the packed multiplies read directly.  The compiler's waitcnt bookkeeping does
+        // not see these loads; the waits are written out below.
+        typedef float taps_t __attribute__((ext_vector_type(RBX)));
+        auto fetch_x = [&](f32x4& xr) {
             const int xo = __builtin_amdgcn_readlane(my_xoff, s) + ci_x;
+            const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
+        };
+        auto fetch_a = [&](taps_t& ar) {
             const int ao = __builtin_amdgcn_readlane(my_aoff, s) + ci_a;
-            xr = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.X + xo) + lane_off_bytes);
-            const float* a = a_base + ao;
-#pragma unroll
-            for (int r = 0; r < RBX; r++) ar[r] = a[r];
-            // Branch-free advance (selects on wave-uniform values: one basic block, so the ordering points below hold).  Past the
-            // end the last step's operands are fetched again: exactly one row stays in flight and the wait is a counted one.
+            const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
+            if constexpr (RBX == 16) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
+            else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
+        };
+        // Branch-free advance (selects on wave-uniform values, all on the scalar ALU).  Past the end the last step's operands are
+        // fetched again: exactly one activation row stays in flight and the wait is a counted one.
+        auto advance = [&]() {
             q_next++;
             const bool more = q_next < n_q;
             const bool wrap = (s + 1 == n_slots);
             s = more ? (wrap ? 0 : s + 1) : s;
-            ci_x = ci_x + ((more && wrap) ? ch_x : 0);
+            ci_x = __builtin_amdgcn_readfirstlane(ci_x + ((more && wrap) ? ch_x : 0));
             ci_a = ci_a + ((more && wrap) ? p.cout_pad : 0);
         };
-        // acc[r] += x * av[r] (separate IEEE multiply and add).  The tap values sit in SGPR pairs; the packed multiply reads the
-        // pair directly and broadcasts its low or high half with op_sel -- the compiler would copy every odd value into a fresh
-        // aligned pair first (s_mov + hazard s_nop per value).
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        auto mac = [&](const f32x4& xv, const float (&av)[RBX]) {
-            if constexpr (!ASMMAC) {
-                // plain C: hipcc (ROCm 7.2) emits the same v_pk_mul_f32 with the SGPR pair and op_sel broadcast, but still copies some
-                // values into fresh pairs (16 s_mov + 22 s_nop per two steps): measured 2 % slower than the asm form (same-process A/B)
-#pragma unroll
-                for (int r = 0; r < RBX; r++) {
-                    const f32x4 pr = xv * av[r];
-                    acc[r] = acc[r] + pr;
-                }
-                return;
-            }
-            const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
-#pragma unroll
-            for (int r = 0; r < RBX; r += 2) {
-                const f32x2 a2 = {av[r], av[r + 1]};
-                f32x2 p0l, p0h, p1l, p1h;
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p0l) : "v"(xlo), "s"(a2));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p0h) : "v"(xhi), "s"(a2));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p1l) : "v"(xlo), "s"(a2));
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(p1h) : "v"(xhi), "s"(a2));
-                acc[r] = acc[r] + f32x4{p0l.x, p0l.y, p0h.x, p0h.y};
-                acc[r + 1] = acc[r + 1] + f32x4{p1l.x, p1l.y, p1h.x, p1h.y};
-            }
+        // the "+" operands make the multiplies that follow depend on the wait
+        auto taps_landed = [&](taps_t& ar) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ar)); };
+        auto row_landed = [&](f32x4& xr, auto younger) {                 // vector loads return in order
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(decltype(younger)::value));
         };
+        // acc[r] += x * av[r] (separate IEEE multiply and add).  The packed multiply reads an aligned SGPR pair and broadcasts its low
+        // or high half with op_sel, so one pair serves two output channels.  The instruction order is pinned (volatile asm): the four
+        // multiplies of channel pair k are followed by the four adds of pair k-1, so no add waits on the multiply right in front of it
+        // (left to itself the scheduler serialises "mul, add, mul, add" through one temporary in the second half of the loop body).
+        auto mul4 = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, f32x2 (&pr)[4]) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "s"(a2));
+        };
+        auto add4 = [&](int r, const f32x2 (&pr)[4]) {
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(pr[0]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(pr[1]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[2]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][1]) : "v"(pr[3]));
+        };
+        auto mac = [&](const f32x4& xv, const taps_t& av) {
+            const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+            f32x2 pa[4], pb[4];
+#pragma unroll
+            for (int r = 0; r < RBX; r += 4) {
+                mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, pa);
+                if (r > 0) add4(r - 2, pb);
+                mul4(xlo, xhi, f32x2{av[r + 2], av[r + 3]}, pb);
+                add4(r, pa);
+            }
+            add4(RBX - 2, pb);
+        };
+        // Two steps per trip, operands double-buffered.  Step q+1's tap load is issued right after step q's taps have landed (scalar
+        // loads return out of order, so lgkmcnt can only be waited to zero) and its activation row right after that; both have step q's
+        // 2*RBX packed multiplies / adds to land.  kn_order() keeps the compiler from moving the arithmetic across the fetches.
         f32x4 x0, x1;
-        float a0[RBX], a1[RBX];
-        fetch(x0, a0);
+        taps_t a0, a1;
+        fetch_x(x0);
+        fetch_a(a0);
+        advance();
         int q = 0;
-        // kn_order(): step q+1's loads are issued before step q's arithmetic and never hoisted over step q-1's (that would cost a
-        // register copy and a vmcnt(0) at the loop end)
         for (; q + 1 < n_q; q += 2) {
-            fetch(x1, a1);
+            taps_landed(a0);
+            fetch_x(x1);
+            fetch_a(a1);
+            advance();
+            row_landed(x0, std::integral_constant<int, 1>());
             kn_order();
             mac(x0, a0);
             kn_order();
-            fetch(x0, a0);
+            taps_landed(a1);
+            fetch_x(x0);
+            fetch_a(a0);
+            advance();
+            row_landed(x1, std::integral_constant<int, 1>());
             kn_order();
             mac(x1, a1);
             kn_order();
         }
+        taps_landed(a0);
+        row_landed(x0, std::integral_constant<int, 0>());
         if (q < n_q) mac(x0, a0);
     }
     if (!active) return;
@@ -965,7 +994,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         const int m = co0 + r;
         if (m >= p.Cout) continue;
         const int64_t row = (int64_t)m * p.HoWo + o;
-        f32x4 t = acc[r];
+        f32x4 t = {acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y};
         if (xlast) {
             const float lc = p.lastcol[row];
             if (lc != 0.0f) {
@@ -1128,8 +1157,8 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {
