@@ -119,9 +119,18 @@ __device__ __forceinline__ void decode_conv_item(const ConvArgs& p, const int64_
 
 // FAST = (batch 16-byte aligned and a multiple of the batch tile NB) && (all coefficients 1: identity / permutation keys) && (Cin % KC == 0):
 // the loaders are straight-line code, so the next chunk's global loads stay in flight in registers during the MFMAs.
-template <int MT, int NB, int KC, int WM, int WN, bool FAST>
+// MODE 2 = FAST with wave-uniform tile pointers (SPTR): the chunk's four tile loads are saddr-form global_load_dwordx4 (SGPR-pair base +
+// one constant 32-bit offset per lane) and the pointer walk over (slot, channel chunk) runs on the scalar ALU.  What it replaces: four
+// 64-bit per-lane pointers advanced with eight VALU adds per chunk.  Measured on the way (loads left out of the loop, results
+// discarded): every register-destination dwordx4 load costs the matrix pipe of its SIMD ~29 cycles, the per-lane pointer walk 1.6 %
+// of the launch; the same tiles fetched by global_load_lds_dwordx4 (no VGPR destination, no ds_write pass, two stages with a
+// vmcnt(0) in front of each chunk's barrier) ran 3.5 % SLOWER than register staging and was dropped.
+template <int MT, int NB, int KC, int WM, int WN, int MODE>
 __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int o, const int m0, const int b0, float* lds) {
+    constexpr bool FAST = MODE >= 1;
+    constexpr bool SPTR = MODE == 2;
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    static_assert(!SPTR || KC == 16, "the scalar-pointer loader is built for 16-row chunks of whole channels");
     constexpr int TM = MT / WM / 32;
     constexpr int TN = NB / WN / 32;
     constexpr int A4 = KC * MT / 4;                 // float4s in the A tile
@@ -135,8 +144,10 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     int64_t* s_da = reinterpret_cast<int64_t*>(lds + 2 * KC * MT + 2 * KC * NB);     // FAST: per-slot byte delta to the next chunk's tap tile
     int64_t* s_db = s_da + MAX_FAST_SLOTS;                                           //       ... and to its activation tile
 
-    const int s_beg = p.pix_ptr[o];
-    const int n_slots = p.pix_ptr[o + 1] - s_beg;
+    // wave-uniform by construction; pinned to SGPRs (a value that comes out of a vector-memory load counts as divergent for the compiler,
+    // and every counter, pointer and branch derived from it would live in VGPRs / go through exec masks)
+    const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
+    const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
     const int cpk = p.cin_pad / KC;
     const int n_chunks = n_slots * cpk;
 
@@ -242,7 +253,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     const char* pa[AL];
     const char* pb[BL];
     int64_t da = 0, db = 0;
-    if constexpr (FAST) {
+    if constexpr (FAST && !SPTR) {
         if (tid < n_slots) {
             const int nxt = (tid + 1 < n_slots) ? tid + 1 : 0;
             const int64_t wrap_a = (tid + 1 < n_slots) ? 0 : a_step, wrap_b = (tid + 1 < n_slots) ? 0 : b_step;
@@ -278,8 +289,71 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         da = s_da[f_slot];      // for the NEXT call: the LDS read has a whole chunk to complete
         db = s_db[f_slot];
     };
+    // ---- SPTR state.  One load instruction of the workgroup covers 1024/MT rows of the A tile (1024/NB of the B tile); load i of a
+    // thread reads (row i*ARL + tid / row_lanes, four columns): a per-lane offset that is a constant of the launch plus a wave-uniform
+    // pointer per load, which advances by the slot table's byte deltas (lane s of every wavefront keeps slot s's deltas in registers,
+    // read back with v_readlane).
+    uint32_t a_voff = 0, b_voff = 0;
+    int dtab_a_lo = 0, dtab_a_hi = 0, dtab_b_lo = 0, dtab_b_hi = 0;
+    int g_slot = 0;
+    const int n_slots_u = __builtin_amdgcn_readfirstlane(n_slots);
+    auto uni64 = [](const char* q) {                 // readfirstlane on an already-scalar value is free; it keeps loop-carried pointers in SGPR pairs
+        const uint64_t v = reinterpret_cast<uint64_t>(q);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+    };
+    constexpr int ARL = 1024 / MT, BRL = 1024 / NB;
+    const char* sa[AL];
+    const char* sb[BL];
+    if constexpr (SPTR) {
+        static_assert(A4 % 256 == 0 && B4 % 256 == 0, "whole load instructions");
+        if (lane < n_slots) {
+            const int nxt = (lane + 1 < n_slots) ? lane + 1 : 0;
+            const int64_t wrap_a = (lane + 1 < n_slots) ? 0 : a_step, wrap_b = (lane + 1 < n_slots) ? 0 : b_step;
+            const int64_t d_a = 4 * ((int64_t)(p.slot_tap[s_beg + nxt] - p.slot_tap[s_beg + lane]) * p.cin_pad * p.cout_pad + wrap_a);
+            const int64_t d_b = 4 * ((int64_t)(p.slot_in[s_beg + nxt] - p.slot_in[s_beg + lane]) * p.ldx + wrap_b);
+            dtab_a_lo = (int)(uint32_t)d_a;
+            dtab_a_hi = (int)(d_a >> 32);
+            dtab_b_lo = (int)(uint32_t)d_b;
+            dtab_b_hi = (int)(d_b >> 32);
+        }
+        a_voff = 4u * (uint32_t)((tid / (MT / 4)) * p.cout_pad + (tid % (MT / 4)) * 4);
+        b_voff = 4u * (uint32_t)((int64_t)(tid / (NB / 4)) * p.HiWi * p.ldx + (tid % (NB / 4)) * 4);      // < 2^31: checked by the launcher
+        if (n_slots > 0) {
+            const int64_t tap0 = __builtin_amdgcn_readfirstlane(p.slot_tap[s_beg]);
+            const int64_t in0 = __builtin_amdgcn_readfirstlane(p.slot_in[s_beg]);
+#pragma unroll
+            for (int i = 0; i < AL; i++) sa[i] = uni64(reinterpret_cast<const char*>(p.tapsT + m0 + (tap0 * p.cin_pad + (int64_t)i * ARL) * p.cout_pad));
+#pragma unroll
+            for (int i = 0; i < BL; i++) sb[i] = uni64(reinterpret_cast<const char*>(p.X + b0 + ((int64_t)i * BRL * p.HiWi + in0) * p.ldx));
+        }
+    }
+    auto sptr_load = [&]() {                          // SPTR: the next chunk's tiles -> ra / rb, saddr form; then the scalar pointer walk
+        if constexpr (SPTR) {
+#pragma unroll
+            for (int i = 0; i < AL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[i]) : "v"(a_voff), "s"(reinterpret_cast<uint64_t>(sa[i])));
+#pragma unroll
+            for (int i = 0; i < BL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[i]) : "v"(b_voff), "s"(reinterpret_cast<uint64_t>(sb[i])));
+            const int64_t da = ((int64_t)__builtin_amdgcn_readlane(dtab_a_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_a_lo, g_slot);
+            const int64_t db = ((int64_t)__builtin_amdgcn_readlane(dtab_b_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_b_lo, g_slot);
+#pragma unroll
+            for (int i = 0; i < AL; i++) sa[i] = uni64(sa[i] + da);
+#pragma unroll
+            for (int i = 0; i < BL; i++) sb[i] = uni64(sb[i] + db);
+            g_slot = (g_slot + 1 == n_slots_u) ? 0 : g_slot + 1;
+        }
+    };
+    auto sptr_landed = [&]() {                        // the asm loads are invisible to the compiler's vmcnt bookkeeping: explicit wait
+        if constexpr (SPTR) {
+            if constexpr (AL == 2 && BL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(rb[0]), "+v"(rb[1]));
+            else if constexpr (AL == 1 && BL == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]));
+            else if constexpr (AL == 1 && BL == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]));
+            else static_assert(!SPTR, "tile shape without a wait statement");
+        }
+    };
     auto LOAD = [&](int q) {
-        if constexpr (FAST) gload_fast();     // chunks are requested strictly in order 0,1,2,...
+        if constexpr (SPTR) sptr_load();
+        else if constexpr (FAST) gload_fast();     // chunks are requested strictly in order 0,1,2,...
         else gload(q);
     };
     // LDS tile rows are stored with their columns permuted: column c = w*(T*32) + t*32 + l (wavefront w, its sub-tile t, lane l)
@@ -301,6 +375,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         b_lds[i] = (uint32_t)((f / (NB / 4)) * NB + ((c / 32) % TN) * (WN * 32) + (c / (TN * 32)) * 32 + (c % 32));
     }
     auto lstore = [&](int buf) {
+        sptr_landed();
         float* a = As + buf * KC * MT;
         float* b = Bs + buf * KC * NB;
 #pragma unroll
@@ -452,7 +527,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 // quarter tiles (MT/2 x NB/2) by four workgroups instead of one: a lone 128x128 workgroup on an otherwise idle CU runs at ~60 % of
 // the matrix pipe for a full tile time while most CUs wait, the quarter tiles finish in about a third of that.  Same K order and MFMA
 // shape per output element, so the result is bit-identical to the unsplit launch.
-template <int MT, int NB, int KC, int WM, int WN, bool FAST, bool TAIL>
+template <int MT, int NB, int KC, int WM, int WN, int FAST, bool TAIL>       // FAST: 0 generic loaders, 1 straight-line loaders with per-thread pointers, 2 with wave-uniform pointers (see convtaps_mfma_tile)
 __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS + 2 * (MT + NB)];
     const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
@@ -469,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
     int mt, pi, bt;
     decode_conv_item(p, item, mt, pi, bt);
-    const int o = p.pix_order[pi];
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
     if (p.stamps && threadIdx.x == 0) {
         p.stamps[4 * (int64_t)blockIdx.x + 0] = (int64_t)__builtin_amdgcn_s_memrealtime();
         p.stamps[4 * (int64_t)blockIdx.x + 2] = (int64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
@@ -1071,11 +1146,15 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     const unsigned pad = lds_pad_for_occupancy(static_lds, occ_cap);
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
+    // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  KN_NO_SPTR = A/B
+    // switch (read per call).
+    bool sptr = false;
+    if constexpr (KC == 16) sptr = fast && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && getenv("KN_NO_SPTR") == nullptr;
     a.tail_main = (int32_t)chunk;
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
         static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
         if (fast && a.wide_store && !no_tail) {
-            static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>);
+            static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
             const int64_t slots = (pad > 0 && slots_free > 0) ? std::min<int64_t>(slots_free, (int64_t)occ_cap * 32) : slots_free;
             const int64_t rem = slots > 0 ? chunk % slots : 0;
             if (rem > 0) {   // the last, partial round of resident workgroups (measured: pays even when it fills half the machine)
@@ -1089,7 +1168,7 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
                     if (dbuf && (size_t)grid <= cap) {
                         (void)hipMemsetAsync(dbuf, 0, (size_t)grid * 4 * sizeof(int64_t), s);
                         a.stamps = dbuf;
-                        hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                        hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                         (void)hipStreamSynchronize(s);
                         std::vector<int64_t> h((size_t)grid * 4);
                         (void)hipMemcpy(h.data(), dbuf, h.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
@@ -1102,14 +1181,21 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
                         return;
                     }
                 }
-                hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                if (sptr) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 return;
             }
         }
     }
     const int64_t grid = 8 * chunk;
-    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, true, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
-    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, false, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+    if constexpr (KC == 16) {
+        if (sptr) {
+            hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+            return;
+        }
+    }
+    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 0, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
