@@ -25,7 +25,7 @@
 namespace kn {
 
 static constexpr int WAVES = 4;  // wavefronts (rows / row-bundles) per 256-thread workgroup
-static constexpr int RB = 8;     // rows per bundle in the grouped kernel
+static constexpr int RB = 16;    // rows per stored bundle of a pattern group (the kernels take RBK <= RB of them per wavefront)
 
 template <int VEC> struct VecT;
 template <> struct VecT<1> { using T = float; };
@@ -688,6 +688,154 @@ std::vector<int32_t> locality_order(const std::vector<int32_t>& row_ids, const i
     return out;
 }
 
+
+// Software-pipelined instantiation of the grouped kernel for the wide case (4 batch columns per lane, RBX = 16 or 8 member rows per
+// wavefront): the permutation-keyed conv layers of configs 2-3.  Same arithmetic and order as csr_group_kernel; what differs is how a
+// step's operands arrive (compare convtaps_exact_pipe_kernel, kn_conv.hip): everything wave-uniform stays scalar.  Per stored column j
+//   * the column index comes from a scalar load (s_load_dword) issued one step ahead of the row request that needs it,
+//   * the activation row is a saddr-form global_load_dwordx4 (SGPR-pair base + the lane's constant byte offset), FOUR rows in flight
+//     per wavefront (a gathered row of a big permuted operator is an HBM / Infinity-Cache miss, ~2 us: one step of cover -- 128 packed
+//     instructions x the co-resident waves -- is not enough),
+//   * the RBX values are one s_load_dwordx16 / x8 into an SGPR tuple that the packed multiplies read directly, one step ahead,
+// so a step is 2*RBX packed multiplies and adds and no other vector instruction.  All loads of the loop are inline asm with
+// explicit waits (vector loads return in order: vmcnt(3) = "the oldest of the four rows in flight has landed"; scalar loads do not, so
+// the next step's scalar loads are issued right after this step's lgkmcnt(0)).
+template <int RBX>
+__global__ __launch_bounds__(256) void csr_group_pipe_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
+                                                             const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
+                                                             const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
+                                                             const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
+                                                             const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                             int64_t n_vecs, int relu, int64_t n_rb) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float vals_t __attribute__((ext_vector_type(RBX)));
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    int64_t item;
+    if (!decode_item(n_ct * n_rb, item)) return;
+    const int64_t ct = item / n_rb;
+    const int64_t rb = item - ct * n_rb;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    constexpr int SUB = RB / RBX;
+    const int64_t w = rb * WAVES + wave;
+    if (w >= n_work * SUB) return;
+    // wave-uniform by construction; pinned to SGPRs so that the whole walk below stays on the scalar ALU
+    const int g = __builtin_amdgcn_readfirstlane(work_grp[w / SUB]);
+    const int r0 = __builtin_amdgcn_readfirstlane(work_r0[w / SUB]) + (int)(w % SUB) * RBX;
+    const int cbeg = __builtin_amdgcn_readfirstlane(grp_colptr[g]);
+    const int ncol = __builtin_amdgcn_readfirstlane(grp_colptr[g + 1]) - cbeg;
+    const int rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
+    const int nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
+    const int rpad = (nmem + RB - 1) / RB * RB;
+    if (r0 >= nmem) return;
+    const int64_t c = ct * 256 + (int64_t)lane * 4;
+    const bool active = c < n_vecs;
+    const uint32_t lane_off_bytes = 4u * (uint32_t)(active ? c : 0);
+
+    f32x2 acc[RBX][2];                                                    // [member row][columns 0-1 | 2-3]
+#pragma unroll
+    for (int r = 0; r < RBX; r++) acc[r][0] = acc[r][1] = f32x2{0.f, 0.f};
+
+    if (ncol > 0) {
+        // readfirstlane on a value that is already scalar is free; it guarantees an SGPR pair for the "s" operands below (hipcc
+        // silently hands an "s" constraint a VGPR pair when it chose to keep the value in vector registers)
+        auto uni = [](const uint64_t v) {
+            return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        };
+        const int32_t* cols = grp_cols + cbeg;
+        const uint64_t cbase = uni(reinterpret_cast<uint64_t>(cols));
+        const uint64_t xbase = uni(reinterpret_cast<uint64_t>(X));
+        const int64_t v0 = grp_valptr[g];
+        const uint64_t vp = uni(reinterpret_cast<uint64_t>(grp_vals + v0 + r0));
+        const int ldx_i = (int)ldx;                                       // cols * ldx < 2^31 elements: checked by the launcher
+        const int vstep = rpad * 4;
+        constexpr int XD = 4;                                             // activation rows in flight
+        int col_nxt = 0;
+        auto fetch_x = [&](f32x4& xr, const int col) {
+            const uint64_t xaddr = xbase + 4 * (uint64_t)(uint32_t)(col * ldx_i);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
+        };
+        auto clampj = [&](const int j) { return j < ncol ? j : ncol - 1; };     // past the end: the last column again (results unused)
+        auto fetch_a = [&](vals_t& ar, const int j) {                     // values of column j, and the index of column j + XD - 1 (its row is requested after step j - 1)
+            const uint64_t va = vp + (uint64_t)(uint32_t)clampj(j) * (uint64_t)(uint32_t)vstep;
+            if constexpr (RBX == 16) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(ar) : "s"(va));
+            else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ar) : "s"(va));
+            const uint64_t caddr = cbase + 4 * (uint64_t)(uint32_t)clampj(j + XD);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(col_nxt) : "s"(caddr));
+        };
+        auto scalars_landed = [&](vals_t& ar) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ar), "+s"(col_nxt)); };
+        auto row_landed = [&](f32x4& xr, auto younger) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(decltype(younger)::value)); };
+        // acc[r] += x * a[r]: separate IEEE multiply and add; the packed multiply reads an aligned SGPR pair and broadcasts its low or high
+        // half with op_sel.  Order pinned (volatile asm): four multiplies of row pair k, then the four adds of pair k-1.
+        auto mul4 = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, f32x2 (&pr)[4]) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "s"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "s"(a2));
+        };
+        auto add4 = [&](int r, const f32x2 (&pr)[4]) {
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(pr[0]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(pr[1]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[2]));
+            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][1]) : "v"(pr[3]));
+        };
+        auto mac = [&](const f32x4& xv, const vals_t& av) {
+            const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+            f32x2 pa[4], pb[4];
+#pragma unroll
+            for (int r = 0; r < RBX; r += 4) {
+                mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, pa);
+                if (r > 0) add4(r - 2, pb);
+                mul4(xlo, xhi, f32x2{av[r + 2], av[r + 3]}, pb);
+                add4(r, pa);
+            }
+            add4(RBX - 2, pb);
+        };
+        f32x4 x0, x1, x2, x3;
+        vals_t a0, a1;
+        fetch_x(x0, __builtin_amdgcn_readfirstlane(cols[0]));
+        fetch_x(x1, __builtin_amdgcn_readfirstlane(cols[clampj(1)]));
+        fetch_x(x2, __builtin_amdgcn_readfirstlane(cols[clampj(2)]));
+        fetch_x(x3, __builtin_amdgcn_readfirstlane(cols[clampj(3)]));
+        fetch_a(a0, 0);
+        // one step: this step's scalars have landed -> request the next step's -> wait for this step's row (three younger rows stay in
+        // flight) -> arithmetic -> request the row four steps ahead into the register the arithmetic just released
+        auto step = [&](const int q, f32x4& xq, vals_t& aq, vals_t& an) {
+            scalars_landed(aq);
+            const int col_far = col_nxt;                                  // index of column q + XD
+            fetch_a(an, q + 1);
+            row_landed(xq, std::integral_constant<int, XD - 1>());
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < ncol) mac(xq, aq);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_x(xq, col_far);
+        };
+        for (int q = 0; q < ncol; q += 4) {
+            step(q, x0, a0, a1);
+            step(q + 1, x1, a1, a0);
+            step(q + 2, x2, a0, a1);
+            step(q + 3, x3, a1, a0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(a0), "+s"(col_nxt));
+    }
+    if (!active) return;
+#pragma unroll
+    for (int r = 0; r < RBX; r++) {
+        if (r0 + r < nmem) {
+            const int row = grp_rows[rbeg + r0 + r];
+            f32x4 t = {acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y};
+            if (relu) {
+                t.x = relu_f(t.x);
+                t.y = relu_f(t.y);
+                t.z = relu_f(t.z);
+                t.w = relu_f(t.w);
+            }
+            *reinterpret_cast<f32x4*>(Y + (int64_t)row * ldy + c) = t;
+        }
+    }
+}
+
 template <int VEC, int RBK>
 static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
@@ -704,6 +852,26 @@ static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_ve
         const int64_t grid = ((items + 7) / 8) * 8;
         hipLaunchKernelGGL(csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
                            y, ldy, n_vecs, relu, n_rb);
+    }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+// grouped rows through the software-pipelined kernel (RBX member rows per wavefront), loose rows as in launch_csr<4, .>
+template <int RBX>
+static int launch_csr_pipe(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    {
+        const int64_t n_rb = (A.n_work * (RB / RBX) + WAVES - 1) / WAVES;
+        const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
+        hipLaunchKernelGGL((csr_group_pipe_kernel<RBX>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
+    }
+    if (A.n_loose > 0) {
+        const int64_t n_rb = (A.n_loose + WAVES - 1) / WAVES;
+        const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
+        hipLaunchKernelGGL(csr_rows_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y, ldy,
+                           n_vecs, relu, n_rb);
     }
     KN_HIP(hipGetLastError());
     return KN_OK;
@@ -745,6 +913,13 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     constexpr int64_t ENOUGH = 2048;
 #define KN_TRY(V, R) \
     if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    // wide case: the software-pipelined grouped kernel, 16 member rows per wavefront when the groups fill such bundles, else 8
+    // (KN_NO_GROUP_PIPE = A/B switch, read per call)
+    if (A.n_work > 0 && aligned(4) && A.cols * ldx < ((int64_t)1 << 31) && getenv("KN_NO_GROUP_PIPE") == nullptr) {
+        const int64_t grouped_rows = A.rows - A.n_loose - A.n_long - A.n_big * 32;           // upper bound (a big group's last bundle may be partial)
+        if (waves(4, 16) >= ENOUGH && 10 * grouped_rows >= 7 * A.n_work * 16) return launch_csr_pipe<16>(A, x, ldx, n_vecs, y, ldy, relu, s);
+        if (waves(4, 8) >= ENOUGH) return launch_csr_pipe<8>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    }
     KN_TRY(4, 8)
     KN_TRY(2, 8)
     KN_TRY(4, 2)
