@@ -458,6 +458,43 @@ def test_csr_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(W.torchdot(Xt.t()).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('n_vecs,members', [(512, 16), (512, 6), (1024, 37), (768, 96)])
+def test_csr_grouped_pipeline_kernel_vs_oracle(n_vecs, members):
+    """Permutation-keyed-conv-shaped operators: many groups of `members` rows sharing one unsorted column sequence (1 .. 70 columns:
+    fewer than the four activation rows the kernel keeps in flight, not a multiple of four, duplicates), partial 16-row bundles,
+    loose rows in between, over a 4-column-per-lane batch -- the software-pipelined grouped kernel (csr_group_pipe_kernel, 16 or 8
+    rows per wavefront by bundle fill).  Bit-exact vs the oracle and bit-identical to the plain grouped kernel (KN_NO_GROUP_PIPE)."""
+    import os
+    rng = np.random.RandomState(n_vecs + members)
+    n = 900
+    n_groups = 2200 * 16 // max(members, 16)
+    rows = []
+    for g in range(n_groups):
+        ncol = 1 + (g * 7) % 70
+        pattern = rng.randint(0, n, ncol).astype(np.int32)
+        for _ in range(members):
+            rows.append(pattern)
+        if g % 5 == 0:
+            rows.append(rng.randint(0, n, rng.randint(0, 12)).astype(np.int32))       # loose row (sometimes empty)
+    m = len(rows)
+    indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+    indices = np.concatenate(rows)
+    data = rng.randn(len(indices)).astype(np.float32)
+    X = rng.randn(n, n_vecs).astype(np.float32)
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+    xd = torch.as_tensor(X).to(dev())
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu).cpu().numpy()
+        assert np.array_equal(y, np.maximum(ref, 0) if relu else ref), (n_vecs, members, relu)
+    os.environ['KN_NO_GROUP_PIPE'] = '1'
+    try:
+        y2 = W.torchdot(xd).cpu().numpy()
+    finally:
+        del os.environ['KN_NO_GROUP_PIPE']
+    assert np.array_equal(y2, ref)
+
+
 @pytest.mark.parametrize('n_vecs,window', [(128, None), (384, None), (128, 256), (128, 512)])
 def test_csr_short_rows_half_wave_path(n_vecs, window):
     """Keyed-pooling-shaped operators (thousands of loose rows, ~9 unsorted non-zeros each, a few empty or longer rows) over a batch
