@@ -74,9 +74,11 @@ def test_keyed_vgg16_equals_plain_network(vgg):
 
 
 def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
-    """KN_FLAG_EXACT on the real conv1_2 (3.2M x 3.2M, 1.84 G nnz) and conv4_2 (401k x 401k, 1.76 G nnz) operators: the
-    order-preserving kernel on the factored operator equals the CPU oracle (scipy csr_matvecs restated) bit for bit on
-    sampled output rows; the MFMA path agrees within 1e-5 of the activation scale."""
+    """KN_FLAG_EXACT on EVERY operator of the real key-net (conv1_1 ... fc8: up to 3.2M x 3.2M, 1.84 G nnz), chained layer to layer:
+    the order-preserving kernels (factored conv, expanded pooling tiles, keyed nn.Linear) equal the CPU oracle (scipy csr_matvecs
+    restated) bit for bit on sampled output rows of every layer -- three pixels x all output channels for the conv layers, 300 random
+    rows (plus the homogeneous row) for pooling and fc layers; on conv1_2 and conv4_2 the MFMA path additionally agrees within 1e-5 of
+    the activation scale."""
     import oracle
     (net, sensor, knet) = vgg
     dev = torch.device('cuda:0')
@@ -84,22 +86,38 @@ def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
     x = torch.randn(8, 3, 224, 224, generator=g)
     y = sensor.fromtensor(x.to(dev)).encrypt().astensor()
     rng = np.random.RandomState(1)
+    xin = y.t().contiguous()                                           # feature-major [D+1, 8]
+    checked = []
     for (name, c) in knet._keynet.named_children():
         if not isinstance(c, KeyedLayer):
             continue
-        if name in ('conv1_2', 'conv4_2'):
-            W = c.W
-            xin = y.t().contiguous()
-            ye = W.torchdot(xin, relu=True, exact=True)
-            ym = W.torchdot(xin, relu=True, exact=False)
+        relu = name.startswith(('conv', 'fc6', 'fc7'))
+        W = c.W
+        ye = W.torchdot(xin, relu=relu, exact=True)
+        xh = xin.cpu().numpy()
+        if isinstance(W, ksp.Conv2dTiledMatrix):
             (Cout, Hout, Wout) = W._outshape
-            pix = np.sort(rng.choice(Hout * Wout, size=6, replace=False))
+            pix = np.sort(rng.choice(Hout * Wout, size=3, replace=False))
             M = W.rows_csr(pix)
-            ref = np.maximum(oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), xin.cpu().numpy()), 0)
             rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
-            assert np.array_equal(ye.cpu().numpy()[rows], ref), name
+        else:
+            full = W.tocsr() if isinstance(W, ksp.TiledMatrix) else W._matrix.tocsr()
+            rows = np.unique(np.concatenate((rng.choice(full.shape[0] - 1, size=min(300, full.shape[0] - 1), replace=False), [full.shape[0] - 1])))
+            M = full[rows] if isinstance(W, ksp.TiledMatrix) else None
+            if M is None:                                               # stored (unsorted) order of the keyed nn.Linear rows, untouched
+                (ip, ix, dt) = (full.indptr, full.indices, full.data)
+                cnt = ip[rows + 1] - ip[rows]
+                sel = np.concatenate([np.arange(ip[r], ip[r + 1]) for r in rows])
+                import scipy.sparse
+                M = scipy.sparse.csr_matrix((dt[sel], ix[sel], np.concatenate(([0], np.cumsum(cnt)))), shape=(len(rows), full.shape[1]))
+        ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), xh)
+        if relu:
+            ref = np.maximum(ref, 0)
+        assert np.array_equal(ye.cpu().numpy()[rows], ref), name
+        checked.append(name)
+        if name in ('conv1_2', 'conv4_2'):
+            ym = W.torchdot(xin, relu=True, exact=False)
             scale = float(ye.abs().max())
             assert float((ye - ym).abs().max()) <= 1e-5 * max(1.0, scale), (name, float((ye - ym).abs().max()), scale)
-        y = c.forward(y, fuse_relu=True) if name.startswith(('conv', 'fc6', 'fc7')) else c.forward(y)
-        if name == 'conv4_2':
-            break
+        xin = ye
+    assert len(checked) == 21 and checked[0] == 'conv1_1' and checked[-1] == 'fc8'
