@@ -8,7 +8,9 @@ import ctypes
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, 'libkeynet_hip.so')
+# KEYNET_HIP_LIB: another BUILD of this same library (a diagnostic variant of the HIP kernels, e.g. tools/ablate_conv.sh's -DKN_ABLATION
+# build); there is no other implementation behind this binding
+LIBPATH = os.environ.get('KEYNET_HIP_LIB') or os.path.join(_HERE, 'libkeynet_hip.so')
 
 KN_OK = 0
 KN_FLAG_RELU = 1

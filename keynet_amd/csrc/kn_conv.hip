@@ -106,7 +106,18 @@ struct ConvArgs {
     int64_t* stamps;          // diagnostic build only (KN_STAMPS): per-workgroup {start, end} of s_memrealtime, XCC id, kind; null otherwise
     const int32_t* sk_desc;   // small-K pipeline: per-pixel descriptors in processing order (ConvTapsDev::sk_desc), or null
     int32_t sk_stride, sk_tab_rows;
+#ifdef KN_ABLATION
+    int32_t abl;           // diagnostic build only (tools/ablate_conv.sh): bit 0 no chunk barrier, 1 no LDS stores, 2 no global loads, 4 no pointer walk, 5 / 6 no tap / activation loads
+#endif
 };
+
+// Loop-piece ablation (timing only, results are garbage): compiled in with -DKN_ABLATION into a separate library by
+// tools/ablate_conv.sh; the shipped library has none of these tests in its loops.
+#ifdef KN_ABLATION
+#define KN_ABL(p, bit) (((p).abl >> (bit)) & 1)
+#else
+#define KN_ABL(p, bit) 0
+#endif
 
 // item -> (Cout tile, position in the pixel order, batch tile): the Cout tile is fastest (its workgroups share one gathered X tile),
 // the batch tile slowest (measured: batch tile inner, i.e. an XCD owning a pixel range for every batch tile, is neutral)
@@ -330,10 +341,15 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     }
     auto sptr_load = [&]() {                          // SPTR: the next chunk's tiles -> ra / rb, saddr form; then the scalar pointer walk
         if constexpr (SPTR) {
+            if (!KN_ABL(p, 5)) {
 #pragma unroll
-            for (int i = 0; i < AL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[i]) : "v"(a_voff), "s"(reinterpret_cast<uint64_t>(sa[i])));
+                for (int i = 0; i < AL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[i]) : "v"(a_voff), "s"(reinterpret_cast<uint64_t>(sa[i])));
+            }
+            if (!KN_ABL(p, 6)) {
 #pragma unroll
-            for (int i = 0; i < BL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[i]) : "v"(b_voff), "s"(reinterpret_cast<uint64_t>(sb[i])));
+                for (int i = 0; i < BL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[i]) : "v"(b_voff), "s"(reinterpret_cast<uint64_t>(sb[i])));
+            }
+            if (KN_ABL(p, 4)) return;
             const int64_t da = ((int64_t)__builtin_amdgcn_readlane(dtab_a_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_a_lo, g_slot);
             const int64_t db = ((int64_t)__builtin_amdgcn_readlane(dtab_b_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_b_lo, g_slot);
 #pragma unroll
@@ -451,8 +467,8 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
             const int cur = (kk >> 1) & 1;
-            if (kk == LS_AT && q + 1 < n_chunks) lstore(buf ^ 1);
-            if (kk == GL_AT && q + 2 < n_chunks) LOAD(q + 2);
+            if (kk == LS_AT && q + 1 < n_chunks && !KN_ABL(p, 1)) lstore(buf ^ 1);
+            if (kk == GL_AT && q + 2 < n_chunks && !KN_ABL(p, 2)) LOAD(q + 2);
             if (kk + 2 < KC) {
 #pragma unroll
                 for (int i = 0; i < TM; i++) af[cur ^ 1][i] = a[(kk + 2) * MT + i * AS];
@@ -468,7 +484,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!KN_ABL(p, 0)) __syncthreads();
     };
     {
         int q = 0;
@@ -1228,6 +1244,9 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.last_in_row = A.Cin * A.Hin * A.Win;
 
     a.stamps = nullptr;
+#ifdef KN_ABLATION
+    a.abl = getenv("KN_ABL") ? atoi(getenv("KN_ABL")) : 0;
+#endif
     a.sk_desc = A.sk_desc;
     a.sk_stride = (int32_t)A.sk_stride;
     a.sk_tab_rows = (int32_t)A.sk_tab_rows;
