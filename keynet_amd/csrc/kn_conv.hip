@@ -392,6 +392,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     }
     auto lstore = [&](int buf) {
         sptr_landed();
+        if (KN_ABL(p, 1)) return;                   // (the wait stays: loads in flight own their registers)
         float* a = As + buf * KC * MT;
         float* b = Bs + buf * KC * NB;
 #pragma unroll
@@ -467,7 +468,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
             const int cur = (kk >> 1) & 1;
-            if (kk == LS_AT && q + 1 < n_chunks && !KN_ABL(p, 1)) lstore(buf ^ 1);
+            if (kk == LS_AT && q + 1 < n_chunks) lstore(buf ^ 1);
             if (kk == GL_AT && q + 2 < n_chunks && !KN_ABL(p, 2)) LOAD(q + 2);
             if (kk + 2 < KC) {
 #pragma unroll
