@@ -307,6 +307,8 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     uint32_t a_voff = 0, b_voff = 0;
     int dtab_a_lo = 0, dtab_a_hi = 0, dtab_b_lo = 0, dtab_b_hi = 0;
     int g_slot = 0;
+    int st_slot = 0;                                  // slot of the chunk the next LDS store writes (non-unit coefficients)
+    float ctab = 1.0f;                                // lane s: coefficient of slot s
     const int n_slots_u = __builtin_amdgcn_readfirstlane(n_slots);
     auto uni64 = [](const char* q) {                 // readfirstlane on an already-scalar value is free; it keeps loop-carried pointers in SGPR pairs
         const uint64_t v = reinterpret_cast<uint64_t>(q);
@@ -327,6 +329,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             dtab_a_hi = (int)(d_a >> 32);
             dtab_b_lo = (int)(uint32_t)d_b;
             dtab_b_hi = (int)(d_b >> 32);
+            if (!p.unit_coef) ctab = p.slot_coef[s_beg + lane];
         }
         a_voff = 4u * (uint32_t)((tid / (MT / 4)) * p.cout_pad + (tid % (MT / 4)) * 4);
         b_voff = 4u * (uint32_t)((int64_t)(tid / (NB / 4)) * p.HiWi * p.ldx + (tid % (NB / 4)) * 4);      // < 2^31: checked by the launcher
@@ -393,6 +396,16 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     auto lstore = [&](int buf) {
         sptr_landed();
         if (KN_ABL(p, 1)) return;                   // (the wait stays: loads in flight own their registers)
+        if constexpr (SPTR) {
+            // float keys whose entries carry a coefficient (photometric gains: a_out[o] / a_in[i] per (output, input) pixel pair): the
+            // activation tile of the chunk is scaled by its slot's coefficient on the way to LDS, as the generic loader does per element
+            if (!p.unit_coef) {
+                const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), st_slot));
+#pragma unroll
+                for (int i = 0; i < BL; i++) rb[i] = rb[i] * cf;
+                st_slot = (st_slot + 1 == n_slots_u) ? 0 : st_slot + 1;
+            }
+        }
         float* a = As + buf * KC * MT;
         float* b = Bs + buf * KC * NB;
 #pragma unroll
@@ -1166,11 +1179,13 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  KN_NO_SPTR = A/B
     // switch (read per call).
     bool sptr = false;
-    if constexpr (KC == 16) sptr = fast && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && getenv("KN_NO_SPTR") == nullptr;
+    const bool fast_shape = a.vec_ok && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) && a.max_slots <= MAX_FAST_SLOTS &&
+                            (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
+    if constexpr (KC == 16) sptr = fast_shape && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && getenv("KN_NO_SPTR") == nullptr;
     a.tail_main = (int32_t)chunk;
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
         static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
-        if (fast && a.wide_store && !no_tail) {
+        if ((fast || sptr) && a.wide_store && !no_tail) {
             static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
             const int64_t slots = (pad > 0 && slots_free > 0) ? std::min<int64_t>(slots_free, (int64_t)occ_cap * 32) : slots_free;
             const int64_t rem = slots > 0 ? chunk % slots : 0;

@@ -458,6 +458,47 @@ def test_csr_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(W.torchdot(Xt.t()).cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('cin,cout,hw,n_vecs', [(32, 128, 12, 256), (16, 64, 10, 512), (48, 192, 8, 128)])
+def test_convtaps_fast_path_with_gain_coefficients(cin, cout, hw, n_vecs):
+    """A permutation + photometric-gain keyed 3x3 conv in factored form: every (output, input) pixel entry carries the coefficient
+    gain_out[o] / gain_in[i].  With whole 16-channel chunks the MFMA kernel takes its scalar-pointer fast path and scales each
+    activation tile by its slot's coefficient on the way to LDS.  Checked against the order-preserving path (itself bit-exact vs the
+    oracle on the expanded rows) within the float-key tolerance, and against the generic loader (KN_NO_SPTR)."""
+    import os
+    from keynet_amd import direct as kdirect
+    rng = np.random.RandomState(cin + cout + hw)
+    HW = hw * hw
+    w = (rng.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.randn(cout).astype(np.float32)
+    (pi, po) = (rng.permutation(HW), rng.permutation(HW))
+    (g_out, g_in) = ((rng.rand(HW) + 0.5).astype(np.float32), (rng.rand(HW) + 0.5).astype(np.float32))
+    (eo, ei, et, ec) = ([], [], [], [])
+    for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((hw, hw), 3, 1)):
+        S = S.tocoo()
+        eo.append(po[S.row]); ei.append(pi[S.col]); et.append(np.full(S.nnz, t)); ec.append((g_out[po[S.row]] / g_in[pi[S.col]]).astype(np.float32))
+    taps = np.stack([w[:, :, i, j] for i in range(3) for j in range(3)])
+    lastcol = np.concatenate((np.repeat(b, HW), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((cin, hw, hw), (cout, hw, hw), taps, np.concatenate(eo).astype(np.int32), np.concatenate(ei).astype(np.int32),
+                                       np.concatenate(et).astype(np.int32), np.concatenate(ec), lastcol)
+    X = np.vstack((rng.randn(cin * HW, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    xd = torch.as_tensor(X).to(dev())
+    M = W.rows_csr()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    ye = W.torchdot(xd, relu=False, exact=True).cpu().numpy()
+    assert np.array_equal(ye[:-1], ref[:cout * HW])
+    scale = float(np.abs(ref).max())
+    for relu in (False, True):
+        r = np.maximum(ref[:cout * HW], 0) if relu else ref[:cout * HW]
+        ym = W.torchdot(xd, relu=relu, exact=False).cpu().numpy()
+        assert float(np.abs(ym[:-1] - r).max()) <= 1e-5 * max(1.0, scale), float(np.abs(ym[:-1] - r).max())
+        os.environ['KN_NO_SPTR'] = '1'
+        try:
+            yg = W.torchdot(xd, relu=relu, exact=False).cpu().numpy()
+        finally:
+            del os.environ['KN_NO_SPTR']
+        assert float(np.abs(yg - ym).max()) <= 1e-5 * max(1.0, scale)
+
+
 @pytest.mark.parametrize('n_vecs,members', [(512, 16), (512, 6), (1024, 37), (768, 96)])
 def test_csr_grouped_pipeline_kernel_vs_oracle(n_vecs, members):
     """Permutation-keyed-conv-shaped operators: many groups of `members` rows sharing one unsorted column sequence (1 .. 70 columns:

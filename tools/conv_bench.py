@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--iters', type=int, default=7)
     ap.add_argument('--perm', action='store_true', help='block-permutation spatial key (tile = hw or 56)')
+    ap.add_argument('--gain', action='store_true', help='photometric (per-pixel gain) keys on top: non-unit per-entry coefficients')
     ap.add_argument('--exact', action='store_true', help='time the order-preserving path (KN_FLAG_EXACT) instead of the MFMA path')
     args = ap.parse_args()
     rng = np.random.RandomState(0)
@@ -32,7 +33,8 @@ def main():
     HW = H * H
     w = (rng.randn(Cout, Cin, 3, 3) / np.sqrt(9 * Cin)).astype(np.float32)
     b = rng.randn(Cout).astype(np.float32)
-    (eo, ei, et) = ([], [], [])
+    (eo, ei, et, ec) = ([], [], [], [])
+    (g_out, g_in) = ((rng.rand(HW) + 0.5).astype(np.float32), (rng.rand(HW) + 0.5).astype(np.float32))
     if args.perm:
         blk = min(H, 56) ** 2
         pi = np.concatenate([rng.permutation(blk) + k for k in range(0, HW, blk)])
@@ -42,9 +44,10 @@ def main():
     for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((H, H), 3, 1)):
         S = S.tocoo()
         eo.append(po[S.row]); ei.append(pi[S.col]); et.append(np.full(S.nnz, t))
+        ec.append((g_out[po[S.row]] / g_in[pi[S.col]]).astype(np.float32))
     taps = np.stack([w[:, :, i, j] for i in range(3) for j in range(3)])
     lastcol = np.concatenate((np.repeat(b, HW), [1.0])).astype(np.float32)
-    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), None, lastcol)
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec) if args.gain else None, lastcol)
     dev = torch.device('cuda:0')
     x = torch.randn((Cin * HW + 1, args.batch), device=dev)
     x[-1] = 1.0
@@ -71,7 +74,8 @@ def main():
     xh = x.cpu().numpy().astype(np.float64)
     ref = np.zeros((Cout, args.batch))
     for (ii, tt) in zip(ins, tps):
-        ref += taps[tt].astype(np.float64) @ xh[np.arange(Cin) * HW + ii]
+        cf = float(g_out[o] / g_in[ii]) if args.gain else 1.0
+        ref += cf * (taps[tt].astype(np.float64) @ xh[np.arange(Cin) * HW + ii])
     ref = np.maximum(ref + b[:, None].astype(np.float64), 0)
     got = y.cpu().numpy()[np.arange(Cout) * HW + o]
     err = float(np.abs(got - ref).max())
