@@ -121,3 +121,29 @@ def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
             assert float((ye - ym).abs().max()) <= 1e-5 * max(1.0, scale), (name, float((ye - ym).abs().max()), scale)
         xin = ye
     assert len(checked) == 21 and checked[0] == 'conv1_1' and checked[-1] == 'fc8'
+
+
+def test_float_key_vgg16_with_photometric_gain_equals_plain_network():
+    """The float-key variant that is constructible at full size: block permutation + block-local photometric gain (every keyed conv
+    entry carries the coefficient a_out[o] / a_in[i], so the MFMA kernel scales each activation tile by its slot's coefficient).
+    Keyed logits equal the source network's within the float-key tolerance; the encrypt/decrypt round trip is exact to rounding."""
+    torch.manual_seed(0)
+    net = VGG16(num_classes=2622).eval()
+    np.random.seed(0)
+    (sensor, knet) = ksys.Keynet((3, 224, 224), net, local_geometric='permutation', local_photometric='uniform_random_gain', beta=0.5,
+                                 tileshape=(64, 64), blocksize=64)
+    convs = [c for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer) and isinstance(c.W, ksp.Conv2dTiledMatrix)]
+    assert len(convs) == 13
+    coef = convs[3].W._taps['ent_coef']
+    assert coef is not None and float(np.abs(coef - 1.0).max()) > 0.05          # genuinely non-unit coefficients
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+    x256 = torch.cat([xc] * 64, dim=0).t().contiguous().t()                      # a full 256-image block: the fast MFMA instantiations
+    y = knet.forward_linear(x256)[:4, :-1].cpu().numpy()
+    with torch.no_grad():
+        yp = net(x).numpy()
+    assert np.abs(y - yp).max() <= 1e-5 * max(1.0, np.abs(yp).max()) + 1e-5, np.abs(y - yp).max()
+    back = sensor.fromtensor(x[:2].to(dev)).encrypt().decrypt().astensor().cpu().numpy()
+    assert np.allclose(back, x[:2].numpy(), rtol=1e-6, atol=1e-6)
