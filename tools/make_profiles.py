@@ -39,9 +39,10 @@ def per_kernel(d, counter):
 
 def main(R, tag, out='profiles', forwards=None):
     os.makedirs(out, exist_ok=True)
-    for f in glob.glob(out + '/%s_*' % tag):
-        os.remove(f)
     pre = '%s/%s_vgg16_b256_' % (out, tag)
+    for name in ('bench.json', 'bench_under_rocprof.json', 'kernel_stats.csv', 'layers.log', 'per_layer_pmc.csv', 'traffic.json'):     # only what this script writes
+        if os.path.exists(pre + name):
+            os.remove(pre + name)
     rows = list(csv.DictReader(open(glob.glob(R + '/stats/runc/*kernel_stats.csv')[0])))
     with open(pre + 'kernel_stats.csv', 'w') as f:
         w = csv.writer(f)
