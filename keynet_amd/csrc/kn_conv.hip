@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX>
+template <int RBX, bool COEF = false>
 __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
     const int64_t n_ct = (p.n_vecs + 255) / 256;
     const int64_t n_items = n_ct * n_rb;
@@ -991,9 +991,11 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     if (n_slots > 0) {
         // lane s: element offsets of slot s (32-bit: the launcher checks the ranges)
         int my_xoff = 0, my_aoff = 0;
+        float my_coef = 1.0f;                                     // COEF: lane s = coefficient of slot s
         if (lane < n_slots) {
             my_xoff = p.slot_in[s_beg + lane] * (int)p.ldx;
             my_aoff = p.slot_tap[s_beg + lane] * (p.cin_pad * p.cout_pad);
+            if constexpr (COEF) my_coef = p.slot_coef[s_beg + lane];
         }
         const int ch_x = __builtin_amdgcn_readfirstlane(p.HiWi * (int)p.ldx);      // one input channel of X
         const float* a_base = p.tapsT + co0;
@@ -1010,11 +1012,12 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
         };
-        auto fetch_a = [&](taps_t& ar) {
+        auto fetch_a = [&](taps_t& ar, float& cf) {
             const int ao = __builtin_amdgcn_readlane(my_aoff, s) + ci_a;
             const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
             if constexpr (RBX == 16) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
             else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
+            if constexpr (COEF) cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), s));
         };
         // Branch-free advance (selects on wave-uniform values, all on the scalar ALU).  Past the end the last step's operands are
         // fetched again: exactly one activation row stays in flight and the wait is a counted one.
@@ -1047,9 +1050,33 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[2]));
             asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][1]) : "v"(pr[3]));
         };
-        auto mac = [&](const f32x4& xv, const taps_t& av) {
+        // COEF (float keys whose entries carry a coefficient): the stored non-zero of the reference is fl(coef * tap) -- one more packed
+        // multiply per channel pair, tap pair (SGPR) x the step's coefficient (broadcast from a VGPR pair's low half), and the products
+        // are then formed from that VGPR pair.
+        auto mul4v = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, f32x2 (&pr)[4]) {
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "v"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "v"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "v"(a2));
+            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "v"(a2));
+        };
+        auto mac = [&](const f32x4& xv, const taps_t& av, const float cf) {
             const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
             f32x2 pa[4], pb[4];
+            if constexpr (COEF) {
+                const f32x2 cf2 = {cf, cf};
+                f32x2 sa, sb;
+#pragma unroll
+                for (int r = 0; r < RBX; r += 4) {
+                    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sa) : "s"(f32x2{av[r], av[r + 1]}), "v"(cf2));
+                    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sb) : "s"(f32x2{av[r + 2], av[r + 3]}), "v"(cf2));
+                    if (r > 0) add4(r - 2, pb);
+                    mul4v(xlo, xhi, sa, pa);
+                    mul4v(xlo, xhi, sb, pb);
+                    add4(r, pa);
+                }
+                add4(RBX - 2, pb);
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < RBX; r += 4) {
                 mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, pa);
@@ -1064,31 +1091,32 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         // 2*RBX packed multiplies / adds to land.  kn_order() keeps the compiler from moving the arithmetic across the fetches.
         f32x4 x0, x1;
         taps_t a0, a1;
+        float c0 = 1.0f, c1 = 1.0f;
         fetch_x(x0);
-        fetch_a(a0);
+        fetch_a(a0, c0);
         advance();
         int q = 0;
         for (; q + 1 < n_q; q += 2) {
             taps_landed(a0);
             fetch_x(x1);
-            fetch_a(a1);
+            fetch_a(a1, c1);
             advance();
             row_landed(x0, std::integral_constant<int, 1>());
             kn_order();
-            mac(x0, a0);
+            mac(x0, a0, c0);
             kn_order();
             taps_landed(a1);
             fetch_x(x0);
-            fetch_a(a0);
+            fetch_a(a0, c0);
             advance();
             row_landed(x1, std::integral_constant<int, 1>());
             kn_order();
-            mac(x1, a1);
+            mac(x1, a1, c1);
             kn_order();
         }
         taps_landed(a0);
         row_landed(x0, std::integral_constant<int, 0>());
-        if (q < n_q) mac(x0, a0);
+        if (q < n_q) mac(x0, a0, c0);
     }
     if (!active) return;
     const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
@@ -1271,15 +1299,17 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const bool v4 = a.vec_ok && n_vecs >= 256;
         const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
         static const int pipe_mode = getenv("KN_EXACT_PIPE") ? atoi(getenv("KN_EXACT_PIPE")) : 16;
-        const bool pipe = pipe_mode > 0 && v4 && A.unit_coef && !A.has_dups && A.max_slots <= 64 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0 &&
+        const bool pipe = pipe_mode > 0 && v4 && !A.has_dups && A.max_slots <= 64 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0 &&
                           (a.last_in_row + 1) * ldx < ((int64_t)1 << 31) && (int64_t)A.ntaps * A.cin_pad * A.cout_pad < ((int64_t)1 << 31);
         // 16 output channels per wavefront when that still leaves every SIMD several wavefronts, else 8
         const int rbx = (pipe && pipe_mode >= 16 && A.Cout % 16 == 0 && (int64_t)a.n_pix * (A.Cout / 16) * n_ct >= 4096) ? 16 : 8;
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16 && A.unit_coef) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && A.unit_coef) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {

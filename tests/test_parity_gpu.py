@@ -458,12 +458,13 @@ def test_csr_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(W.torchdot(Xt.t()).cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize('cin,cout,hw,n_vecs', [(32, 128, 12, 256), (16, 64, 10, 512), (48, 192, 8, 128)])
+@pytest.mark.parametrize('cin,cout,hw,n_vecs', [(32, 128, 12, 256), (16, 64, 10, 512), (48, 192, 8, 128), (32, 256, 16, 256)])
 def test_convtaps_fast_path_with_gain_coefficients(cin, cout, hw, n_vecs):
     """A permutation + photometric-gain keyed 3x3 conv in factored form: every (output, input) pixel entry carries the coefficient
     gain_out[o] / gain_in[i].  With whole 16-channel chunks the MFMA kernel takes its scalar-pointer fast path and scales each
-    activation tile by its slot's coefficient on the way to LDS.  Checked against the order-preserving path (itself bit-exact vs the
-    oracle on the expanded rows) within the float-key tolerance, and against the generic loader (KN_NO_SPTR)."""
+    activation tile by its slot's coefficient on the way to LDS.  Checked against the order-preserving path within the float-key
+    tolerance and against the generic loader (KN_NO_SPTR); the order-preserving path itself (the pipelined kernel's coefficient
+    instantiation at 256+ columns: stored value = fl(coef * tap), 8 or 16 channels per wave) is bit-exact vs the oracle on the expanded rows."""
     import os
     from keynet_amd import direct as kdirect
     rng = np.random.RandomState(cin + cout + hw)
