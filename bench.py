@@ -469,6 +469,48 @@ def float_key_parity(dev, batch=256):
             'logits_max_abs_err_mfma_vs_source_network': float((lm.cpu() - lp).abs().max()), 'seconds': time.time() - t0}
 
 
+def collective_record(knet, sensor, x_cipher, gathered, batch, world, rank, local_rank, dev, inshape, share):
+    """What the N>1 line says about itself (every rank takes part; rank 0 keeps the record): the ranks and devices that were really
+    there, the cost of the logits all-gather alone (HIP events on the launch stream), and two bit-level checks of the gathered block --
+    every rank's own shard against its local forward, and the LAST rank's shard recomputed on rank 0 from that rank's input seed
+    (weights are replicated and batch columns independent, so a single process must reproduce any shard bit for bit)."""
+    info = {'rank': rank, 'local_rank': local_rank, 'device_index': dev.index, 'device_name': torch.cuda.get_device_name(dev), 'pid': os.getpid()}
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+    yl = knet.forward_linear(x_cipher)[:, :-1].contiguous()
+    for _ in range(3):
+        kdist.gather_logits(yl, total=batch * world)
+    torch.cuda.synchronize()
+    dist.barrier()
+    n_calls = 20
+    (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n_calls):
+        g = kdist.gather_logits(yl, total=batch * world)
+    e1.record()
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / n_calls
+    ev_ms = e0.elapsed_time(e1) / n_calls
+    own = bool(torch.equal(g[rank * batch:(rank + 1) * batch], yl)) and bool(torch.equal(gathered[rank * batch:(rank + 1) * batch], yl))
+    flag = torch.tensor([1 if own else 0], dtype=torch.int32, device=torch.device('cpu') if share else dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    peer = world - 1
+    peer_equal = None
+    if rank == 0:
+        gp = torch.Generator(device=dev).manual_seed(1234 + peer)
+        xp = torch.randn((batch,) + tuple(inshape), generator=gp, device=dev)
+        yp = knet.forward_linear(sensor.fromtensor(xp).encrypt().astensor())[:, :-1]
+        peer_equal = bool(torch.equal(g[peer * batch:(peer + 1) * batch], yp))
+        del xp, yp
+    return {'backend': dist.get_backend(), 'ranks_seen': dist.get_world_size(), 'ranks': infos,
+            'op': 'all_gather_into_tensor of [%d, %d] f32 logits per rank' % (batch, yl.shape[1]), 'bytes_per_rank': int(yl.numel() * 4),
+            'ms_per_call': ev_ms, 'ms_per_call_wall': wall_ms, 'calls_timed': n_calls,
+            'every_rank_shard_bit_equal_to_its_local_forward': bool(flag.item() == 1), 'rank0_shard_bit_equal': own if rank == 0 else None,
+            'rank0_shard_sha256': hashlib.sha256(yl.cpu().numpy().tobytes()).hexdigest() if rank == 0 else None,
+            'peer_shard_recomputed_on_rank0': {'peer_rank': peer, 'bit_equal': peer_equal}}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (torch.distributed.run, one per GPU) from THIS
     process, which has not touched the GPU (no torch.cuda call above this point), and exit with their code."""
@@ -496,6 +538,9 @@ def main():
     ap.add_argument('--exact', action='store_true', help='bit-exact mode for the tiled key-nets as the MAIN measurement (order-preserving kernels everywhere)')
     ap.add_argument('--no-exact-leg', action='store_true', help='skip the additional bit-exact-mode measurement of the default vgg16 run')
     ap.add_argument('--graph', action='store_true', help='replay the forward from a captured HIP graph (launch-bound small nets)')
+    ap.add_argument('--dist', action='store_true', help='initialise the RCCL process group and all-gather the logits every step even with ONE rank '
+                                                        '(exercises the multi-GPU code path on a single-GPU box)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the LeNet / AllConvNet legs of the default run')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -527,8 +572,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if 'MASTER_PORT' not in os.environ:                  # --dist without a launcher: a rendezvous of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
         if share:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -553,24 +605,24 @@ def main():
 
     def step():
         yl = (replay(x_cipher) if replay is not None else knet.forward_linear(x_cipher))[:, :-1]
-        if world == 1:
+        if not use_dist:
             return yl
         return kdist.gather_logits(yl, total=batch * world)     # RCCL all-gather over xGMI (gloo rigs bounce through the host)
 
     def timed(n_warm, n_steps):
         for _ in range(n_warm):
             step()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_steps):
             out = step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cpu') if share else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -586,6 +638,9 @@ def main():
                   'ok': bool(err <= 1e-3)}
         if not parity['ok']:
             raise AssertionError('parity gate failed: %s' % json.dumps(parity))
+    collective = None
+    if use_dist:
+        collective = collective_record(knet, sensor, x_cipher, out, batch, world, rank, local_rank, dev, inshape, share)
     del out
 
     if rank == 0:
@@ -604,7 +659,9 @@ def main():
             'config': {'workload': desc, 'mode': mode, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
                        'parallelism': 'batch shards x%d, all_gather(logits)' % world if world > 1 else 'single GPU'},
             'achieved_hbm_gbs_algorithmic': total_bytes / (ms_per_step * 1e6), 'achieved_tflops_algorithmic': 2.0 * nnz_img * batch / (ms_per_step * 1e9),
-            'roofline': roof, 'parity': parity, 'cpu_baseline': cpu,
+            'roofline': roof, 'parity': parity,
+            'cpu_baseline': cpu if (cpu is not None or world == 1) else 'measured at N=1 only (the scipy baseline runs on rank 0 of a single-GPU run; see BENCH / profiles)',
+            'collective': collective,
             'layers_ms': {r['name']: round(r['ms'], 4) for r in table},
         }
         # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key")
@@ -634,7 +691,7 @@ def main():
             except Exception as e:      # a reported-only record must never break the bench line
                 res['float_key_parity'] = {'error': str(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,6 +7,8 @@
 #include <numeric>
 #include <unordered_map>
 
+extern "C" int kn_destroy(kn_handle_t h);
+
 namespace kn {
 
 static thread_local std::string g_err;
@@ -52,6 +54,11 @@ static void coo_to_csr(int64_t rows, std::vector<int64_t>& r, std::vector<int64_
     for (int64_t i = 0; i < rows; i++) indptr[(size_t)i + 1] += indptr[(size_t)i];
 }
 
+struct OperatorDeleter {
+    void operator()(kn_operator* h) const { (void)kn_destroy(h); }
+};
+typedef std::unique_ptr<kn_operator, OperatorDeleter> OperatorPtr;   // a create that fails or throws half way frees its device memory
+
 static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data,
                            kn_operator** out) {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
@@ -65,7 +72,7 @@ static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_
     int dev = 0;
     int rc = ensure_device(&dev);
     if (rc) return rc;
-    kn_operator* h = new kn_operator();
+    OperatorPtr h(new kn_operator());
     h->kind = KIND_CSR;
     h->device = dev;
     h->rows = rows;
@@ -76,12 +83,9 @@ static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_
     h->csr.cols = cols;
     h->csr.nnz = nnz;
     if ((rc = upload(&h->csr.indptr, indptr, (size_t)rows + 1)) || (rc = upload(&h->csr.indices, indices, (size_t)nnz)) ||
-        (rc = upload(&h->csr.data, data, (size_t)nnz)) || (rc = csr_build_groups(h, indptr, indices, data))) {
-        csr_free(h->csr);
-        delete h;
+        (rc = upload(&h->csr.data, data, (size_t)nnz)) || (rc = csr_build_groups(h.get(), indptr, indices, data)))
         return rc;
-    }
-    *out = h;
+    *out = h.release();
     return KN_OK;
 }
 
@@ -145,7 +149,7 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     int rc = ensure_device(&dev);
     if (rc) return rc;
 
-    kn_operator* h = new kn_operator();
+    OperatorPtr h(new kn_operator());
     h->kind = KIND_CONVTAPS;
     h->device = dev;
     h->rows = rows;
@@ -263,12 +267,9 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     if ((!sk_desc.empty() && (rc = upload(&c.sk_desc, sk_desc.data(), sk_desc.size()))) || (rc = upload(&c.tapsT, tapsT.data(), tapsT.size())) || (rc = upload(&c.pix_ptr, pix_ptr.data(), pix_ptr.size())) ||
         (rc = upload(&c.slot_in, slot_in.data(), slot_in.size())) || (rc = upload(&c.slot_tap, slot_tap.data(), slot_tap.size())) ||
         (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
-        (rc = upload(&c.lastcol, lastcol.data(), lastcol.size()))) {
-        convtaps_free(c);
-        delete h;
+        (rc = upload(&c.lastcol, lastcol.data(), lastcol.size())))
         return rc;
-    }
-    *out = h;
+    *out = h.release();
     return KN_OK;
 }
 
@@ -295,6 +296,7 @@ int kn_abi_version(void) { return KN_ABI_VERSION; }
 const char* kn_last_error(void) { return g_err.c_str(); }
 
 int kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len) {
+    return guarded([&]() -> int {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) n = 0;
@@ -311,14 +313,18 @@ int kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len) {
         }
     }
     return KN_OK;
+    });
 }
 
 int kn_csr_create(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data, kn_handle_t* out) {
+    return guarded([&]() -> int {
     return csr_create_impl(rows, cols, nnz, indptr, indices, data, out);
+    });
 }
 
 int kn_tiled_create(int64_t rows, int64_t cols, int64_t nblocks, const int64_t* blocks, int64_t ntiles, const int64_t* tile_ptr,
                     const int32_t* tile_row, const int32_t* tile_col, const float* tile_val, kn_handle_t* out) {
+    return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
     KN_REQUIRE(rows >= 0 && cols >= 0 && nblocks >= 0 && ntiles >= 0, KN_ERR_INVALID, "negative size");
@@ -343,11 +349,13 @@ int kn_tiled_create(int64_t rows, int64_t cols, int64_t nblocks, const int64_t* 
     int rc = csr_create_impl(rows, cols, (int64_t)ix.size(), ip.data(), ix.data(), dt.data(), out);
     if (rc == KN_OK) (*out)->nnz_stored = stored;
     return rc;
+    });
 }
 
 int kn_conv2dtiled_create(int64_t rows, int64_t cols, const int64_t inshape[3], const int64_t outshape[3], int64_t nblocks, const int64_t* blocks,
                           int64_t nent, const int64_t* tile_keys, const uint8_t* tile_isbias, const float* tile_chan, const float* tile_bias,
                           kn_handle_t* out) {
+    return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
     KN_REQUIRE(inshape && outshape && (nblocks == 0 || blocks) && (nent == 0 || (tile_keys && tile_isbias)), KN_ERR_INVALID, "NULL argument");
@@ -416,10 +424,12 @@ int kn_conv2dtiled_create(int64_t rows, int64_t cols, const int64_t inshape[3], 
         }
     }
     return convtaps_create_impl(b, out);
+    });
 }
 
 int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int64_t ntaps, const float* taps, int64_t nent, const int32_t* ent_out,
                        const int32_t* ent_in, const int32_t* ent_tap, const float* ent_coef, const float* lastcol, kn_handle_t* out) {
+    return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
     KN_REQUIRE(inshape && outshape && ntaps >= 0 && nent >= 0, KN_ERR_INVALID, "bad argument");
@@ -447,9 +457,11 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int6
             }
     }
     return convtaps_create_impl(b, out);
+    });
 }
 
 int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out) {
+    return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
     KN_REQUIRE(rows >= 2 && cols >= 2 && W != nullptr, KN_ERR_INVALID, "bad argument");
@@ -480,12 +492,13 @@ int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out
     kn_operator* sub = nullptr;
     int rc = convtaps_create_impl(b, &sub);
     if (rc) return rc;
-    kn_operator* h = new kn_operator();
+    OperatorPtr subp(sub);
+    OperatorPtr h(new kn_operator());
     h->kind = KIND_DENSE;
     h->device = sub->device;
     h->rows = rows;
     h->cols = cols;
-    h->dense_sub = sub;
+    h->dense_sub = subp.release();
     h->dense_splits = S;
     std::vector<float> lastcol((size_t)rows);
     int64_t nnz = 0;
@@ -495,48 +508,58 @@ int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out
     }
     h->nnz_stored = nnz;
     h->nnz_expanded = nnz;
-    if ((rc = upload(&h->dense_lastcol, lastcol.data(), lastcol.size()))) {
-        kn_destroy(h);
-        return rc;
-    }
-    *out = h;
+    if ((rc = upload(&h->dense_lastcol, lastcol.data(), lastcol.size()))) return rc;
+    *out = h.release();
     return KN_OK;
+    });
 }
 
 int kn_destroy(kn_handle_t h) {
+    return guarded([&]() -> int {
     if (!h) return KN_OK;
     if (h->exact) kn_destroy(h->exact);
     if (h->dense_sub) kn_destroy(h->dense_sub);
     if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
     for (auto& kv : h->dense_ws)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
-    for (float* q : h->dense_ws_retired) (void)hipFree(q);
+    for (auto& r : h->dense_ws_retired) {
+        if (r.done) (void)hipEventDestroy(r.done);
+        if (r.ptr) (void)hipFree(r.ptr);
+    }
     csr_free(h->csr);
     convtaps_free(h->ct);
     delete h;
     return KN_OK;
+    });
 }
 
 int kn_nnz(kn_handle_t h, int64_t* nnz) {
+    return guarded([&]() -> int {
     KN_REQUIRE(h && nnz, KN_ERR_INVALID, "NULL argument");
     *nnz = h->nnz_stored;
     return KN_OK;
+    });
 }
 
 int kn_nnz_expanded(kn_handle_t h, int64_t* nnz) {
+    return guarded([&]() -> int {
     KN_REQUIRE(h && nnz, KN_ERR_INVALID, "NULL argument");
     *nnz = h->nnz_expanded;
     return KN_OK;
+    });
 }
 
 int kn_shape(kn_handle_t h, int64_t* rows, int64_t* cols) {
+    return guarded([&]() -> int {
     KN_REQUIRE(h && rows && cols, KN_ERR_INVALID, "NULL argument");
     *rows = h->rows;
     *cols = h->cols;
     return KN_OK;
+    });
 }
 
 int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data) {
+    return guarded([&]() -> int {
     KN_REQUIRE(h && indptr, KN_ERR_INVALID, "NULL argument");
     if (h->kind == KIND_CSR) {
         KN_HIP(hipMemcpy(indptr, h->csr.indptr, sizeof(int32_t) * (size_t)(h->rows + 1), hipMemcpyDeviceToHost));
@@ -562,9 +585,11 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
         std::memcpy(data, dt.data(), sizeof(float) * dt.size());
     }
     return KN_OK;
+    });
 }
 
 int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, void* stream) {
+    return guarded([&]() -> int {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
     KN_REQUIRE(n_vecs >= 0, KN_ERR_INVALID, "negative n_vecs");
     if (n_vecs == 0 || h->rows == 0) return KN_OK;
@@ -590,10 +615,36 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
             std::lock_guard<std::mutex> g(h->lazy_mu);
             kn_operator::DenseWs& w = h->dense_ws[s];
             if (w.vecs < n_vecs) {
-                if (w.ptr) h->dense_ws_retired.push_back(w.ptr);   // launches already queued on `s` may still use it
+                // reap retired buffers whose last possible reader has finished, then retire this stream's outgrown one behind an event
+                for (size_t k = 0; k < h->dense_ws_retired.size();) {
+                    kn_operator::Retired& r = h->dense_ws_retired[k];
+                    if (r.done == nullptr || hipEventQuery(r.done) == hipSuccess) {
+                        if (r.done) (void)hipEventDestroy(r.done);
+                        (void)hipFree(r.ptr);
+                        h->dense_ws_retired.erase(h->dense_ws_retired.begin() + (long)k);
+                    } else {
+                        k++;
+                    }
+                }
+                (void)hipGetLastError();                            // hipEventQuery's hipErrorNotReady is not an error of this call
+                if (w.ptr) {
+                    kn_operator::Retired r;
+                    r.ptr = w.ptr;                                  // launches already queued on `s` may still use it
+                    if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, s) != hipSuccess) {
+                        if (r.done) (void)hipEventDestroy(r.done);
+                        r.done = nullptr;
+                        (void)hipStreamSynchronize(s);              // no event: wait for the stream, then the buffer is free at the next reap
+                    }
+                    h->dense_ws_retired.push_back(r);
+                }
                 w.ptr = nullptr;
                 w.vecs = 0;
-                KN_HIP(hipMalloc((void**)&w.ptr, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs));
+                hipError_t e = hipMalloc((void**)&w.ptr, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs);
+                if (e != hipSuccess) {
+                    w.ptr = nullptr;
+                    return fail(e == hipErrorOutOfMemory ? KN_ERR_NOMEM : KN_ERR_HIP, std::string("dense workspace hipMalloc: ") + hipGetErrorString(e) +
+                                " (during a HIP-graph capture: run one eager kn_spmm on the capture stream first, or call kn_reserve_workspace)");
+                }
                 w.vecs = n_vecs;
             }
             ws = w.ptr;
@@ -604,26 +655,33 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
     }
     // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
     return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    });
 }
 
 int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream) {
+    return guarded([&]() -> int {
     KN_REQUIRE(y_dev || rows * n_vecs == 0, KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ld >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
     return relu_inplace(y_dev, rows, ld, n_vecs, reinterpret_cast<hipStream_t>(stream));
+    });
 }
 
 int kn_affine_to_linear(const float* x_dev, int64_t n, int64_t d, float* out_dev, int64_t ldo, void* stream) {
+    return guarded([&]() -> int {
     KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE((x_dev || n * d == 0) && (out_dev || n == 0), KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ldo >= n, KN_ERR_SHAPE, "leading dimension smaller than n");
     return affine_to_linear(x_dev, n, d, out_dev, ldo, reinterpret_cast<hipStream_t>(stream));
+    });
 }
 
 int kn_linear_to_affine(const float* y_dev, int64_t ldy, int64_t n, int64_t d, float* out_dev, float* maxdev_dev, void* stream) {
+    return guarded([&]() -> int {
     KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE((y_dev || n == 0) && (out_dev || n * d == 0), KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ldy >= n, KN_ERR_SHAPE, "leading dimension smaller than n");
     return linear_to_affine(y_dev, ldy, n, d, out_dev, maxdev_dev, reinterpret_cast<hipStream_t>(stream));
+    });
 }
 
 }  // extern "C"

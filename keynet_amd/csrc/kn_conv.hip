@@ -575,11 +575,13 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
     int mt, pi, bt;
     decode_conv_item(p, item, mt, pi, bt);
     const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
+#ifdef KN_ABLATION
     if (p.stamps && threadIdx.x == 0) {
         p.stamps[4 * (int64_t)blockIdx.x + 0] = (int64_t)__builtin_amdgcn_s_memrealtime();
         p.stamps[4 * (int64_t)blockIdx.x + 2] = (int64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
         p.stamps[4 * (int64_t)blockIdx.x + 3] = quad;
     }
+#endif
     bool done = false;
     if constexpr (TAIL) {
         if (quad >= 0) {
@@ -588,7 +590,9 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
         }
     }
     if (!done) convtaps_mfma_tile<MT, NB, KC, WM, WN, FAST>(p, o, mt * MT, bt * NB, lds);
+#ifdef KN_ABLATION
     if (p.stamps && threadIdx.x == 0) p.stamps[4 * (int64_t)blockIdx.x + 1] = (int64_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---- one-shot small-K path -----------------------------------------------------------------------------------------------
@@ -1214,13 +1218,19 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
         static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
         if ((fast || sptr) && a.wide_store && !no_tail) {
-            static const int64_t slots_free = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
+            // resident workgroups per XCD of the instantiation that is actually launched (the two loader modes may differ in registers)
+            static const int64_t slots_free_1 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
+            static const int64_t slots_free_2 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>);
+            const int64_t slots_free = sptr ? slots_free_2 : slots_free_1;
             const int64_t slots = (pad > 0 && slots_free > 0) ? std::min<int64_t>(slots_free, (int64_t)occ_cap * 32) : slots_free;
             const int64_t rem = slots > 0 ? chunk % slots : 0;
             if (rem > 0) {   // the last, partial round of resident workgroups (measured: pays even when it fills half the machine)
                 a.tail_main = (int32_t)(chunk - rem);
                 const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
-                if (const char* path = getenv("KN_STAMPS")) {       // DIAGNOSTIC: per-workgroup time stamps of this launch, appended to a file
+#ifdef KN_ABLATION
+                // DIAGNOSTIC BUILD ONLY (tools/ablate_conv.sh): per-workgroup time stamps of this launch, appended to a file.  Synchronises the
+                // stream and uses one process-wide device buffer: not thread-safe, not capturable, never compiled into the product library.
+                if (const char* path = getenv("KN_STAMPS")) {
                     static int64_t* dbuf = nullptr;
                     static int seq = 0;
                     const size_t cap = (size_t)1 << 22;
@@ -1228,7 +1238,8 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
                     if (dbuf && (size_t)grid <= cap) {
                         (void)hipMemsetAsync(dbuf, 0, (size_t)grid * 4 * sizeof(int64_t), s);
                         a.stamps = dbuf;
-                        hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                        if (sptr) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                        else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                         (void)hipStreamSynchronize(s);
                         std::vector<int64_t> h((size_t)grid * 4);
                         (void)hipMemcpy(h.data(), dbuf, h.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
@@ -1241,6 +1252,7 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
                         return;
                     }
                 }
+#endif
                 if (sptr) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 return;

@@ -6,6 +6,9 @@
 #include <vector>
 #include <mutex>
 #include <map>
+#include <new>
+#include <stdexcept>
+#include <memory>
 #include "../../include/keynet_hip.h"
 
 namespace kn {
@@ -25,6 +28,23 @@ int fail(int code, const std::string& msg);
     do {                                                                                               \
         if (!(cond)) return kn::fail((code), std::string(msg) + " [" #cond "]");                       \
     } while (0)
+
+// Every extern "C" body runs inside guarded(): the create functions do std::vector work on caller-sized inputs, and no C++ exception
+// may unwind through the C ABI into ctypes / cgo / JNI (include/keynet_hip.h: "no C++ exception crosses the boundary").
+template <typename F>
+static inline int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { return fail(KN_ERR_NOMEM, "host allocation failed (std::bad_alloc)"); } catch (...) { return KN_ERR_NOMEM; }
+    } catch (const std::length_error& e) {
+        try { return fail(KN_ERR_NOMEM, std::string("host allocation of an impossible size (std::length_error: ") + e.what() + ")"); } catch (...) { return KN_ERR_NOMEM; }
+    } catch (const std::exception& e) {
+        try { return fail(KN_ERR_INVALID, std::string("C++ exception: ") + e.what()); } catch (...) { return KN_ERR_INVALID; }
+    } catch (...) {
+        try { return fail(KN_ERR_INVALID, "unknown C++ exception"); } catch (...) { return KN_ERR_INVALID; }
+    }
+}
 
 enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2 };
 
@@ -103,14 +123,19 @@ struct kn_operator {
     int64_t dense_splits = 0;
     float* dense_lastcol = nullptr;   // [rows] bias column incl. the homogeneous 1
     // split-K partial sums [(rows-1) * splits, vecs]: ONE workspace PER STREAM (launches on one stream are ordered, launches on
-    // different streams get different buffers, so concurrent kn_spmm calls on one handle never share partial sums).  A buffer
-    // that is outgrown is retired, not freed: an earlier launch may still be reading it; kn_destroy frees everything.
+    // different streams get different buffers, so concurrent kn_spmm calls on one handle never share partial sums).
     struct DenseWs {
         float* ptr = nullptr;
         int64_t vecs = 0;
     };
     std::map<hipStream_t, DenseWs> dense_ws;
-    std::vector<float*> dense_ws_retired;
+    // an outgrown buffer is retired with an event recorded on its stream at that moment and freed by a later call once the event has
+    // completed (every launch that could read it was queued before the event); kn_destroy frees what is left
+    struct Retired {
+        float* ptr = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Retired> dense_ws_retired;
 };
 
 namespace kn {

@@ -33,8 +33,10 @@ def gather_logits(local_logits, total=None):
 
     Uneven shards (total % world != 0) are padded to the largest shard for the collective and trimmed afterwards."""
     (rank, ws) = world()
-    if ws == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_logits
+    # an initialised group of ONE rank still runs the collective: `bench.py --gpus 1 --dist` and tests/test_rccl_gpu.py drive RCCL's
+    # communicator set-up and the device all_gather_into_tensor on a single-GPU box that way (a few microseconds)
     if local_logits.is_cuda and dist.get_backend() == 'gloo':
         # gloo has no device collectives: bounce through the host (single-GPU test rigs; the production backend is RCCL)
         return gather_logits(local_logits.cpu(), total=total).to(local_logits.device)

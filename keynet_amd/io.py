@@ -10,7 +10,8 @@ Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_gold
     conv2dtiled:  shape, inshape, outshape, tileshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias
     convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol [, tileshape]
     L.<name>.exact                   (save_keynet only) the layer's arithmetic contract: True = the reference's accumulation order and
-                                     rounding, False = float-key tolerance on the matrix cores; absent (golden files) = the default
+                                     rounding, False = matrix cores, 'auto' = decided at the first forward (float-key tolerance 1e-5);
+                                     absent (golden files) = the default
     outshape                         (C,1,1) of the logits
     sensor.*                         (optional) the image key pair as stored-order CSR + 'sensor.inshape'
 
@@ -105,7 +106,9 @@ def keynet_from_arrays(z):
         if str(z[p + 'kind']) == 'relu':
             layers[name] = nn.ReLU()
         else:
-            exact = bool(z[p + 'exact']) if (p + 'exact') in z.files else None
+            exact = None
+            if (p + 'exact') in z.files:
+                exact = 'auto' if z[p + 'exact'].dtype.kind in 'US' else bool(z[p + 'exact'])
             layers[name] = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']), exact=exact)
     last = [l for l in layers.values() if isinstance(l, KeyedLayer)][-1]
     outshape = tuple(int(v) for v in z['outshape']) if 'outshape' in z.files else (last.W.shape[0] - 1, 1, 1)
@@ -128,7 +131,8 @@ def save_keynet(knet, filename, sensor=None):
         if isinstance(c, KeyedLayer):
             operator_to_arrays(c.W, p, out)
             out[p + 'layertype'] = np.array(c._layertype)
-            out[p + 'exact'] = np.array(bool(getattr(c, '_exact', True)))
+            decl = getattr(c, '_exact_decl', getattr(c, '_exact', True))          # the declared contract ('auto' stays 'auto': re-decided where it is loaded)
+            out[p + 'exact'] = np.array('auto') if decl == 'auto' else np.array(bool(decl))
         else:
             out[p + 'kind'] = np.array('relu')
     if sensor is not None:

@@ -151,6 +151,13 @@ class SparseMatrix(object):
         assert isinstance(x_numpy, np.ndarray)
         return self.torchdot(torch.as_tensor(np.asarray(x_numpy))).cpu().numpy()
 
+    def max_abs_rowsum(self):
+        """max_i sum_j |W_ij| (host, float64): the operator-side factor of the float-key error bound (KeyedLayer._calibrate)."""
+        M = self._matrix
+        if is_scipy_sparse(M):
+            return float(abs(M).sum(axis=1).max()) if M.nnz else 0.0
+        return float(np.abs(np.asarray(M, dtype=np.float64)).sum(axis=1).max()) if M.size else 0.0
+
     # -- structure (host)
     def new(self):
         return SparseMatrix()
@@ -261,6 +268,10 @@ class TiledMatrix(SparseMatrix):
     def dot(self, x):
         assert isinstance(x, np.ndarray)
         return self.torchdot(torch.as_tensor(x)).cpu().numpy()
+
+    def max_abs_rowsum(self):
+        M = self.tosparse('csr')
+        return float(abs(M).sum(axis=1).max()) if M.nnz else 0.0
 
     def copy(self, blocks, tiles):
         (self._blocks, self._tiles, self._op) = (blocks, tiles, None)
@@ -600,6 +611,23 @@ class Conv2dTiledMatrix(TiledMatrix):
         pixel selected this is the whole operator incl. its homogeneous row."""
         assert self._taps is not None, 'rows_csr needs the factored form (fromtaps / direct keying)'
         return self._expand_taps_host(pixels, channels)
+
+    def max_abs_rowsum(self):
+        """max over output rows (co, o) of sum |W| along the row, from the factored form without expanding it: for row (co, o) it is
+        sum over the pixel's entries of |coef| * sum_ci |taps[tap][co][ci]|  (+ |last column|) -- one [HoWo x ntaps] sparse product."""
+        if self._taps is None:
+            M = self.tosparse('csr')
+            return float(abs(M).sum(axis=1).max()) if M.nnz else 0.0
+        t = self._taps
+        (Cout, Hout, Wout) = self._outshape
+        HoWo = Hout * Wout
+        tap_abs = np.abs(t['taps'].astype(np.float64)).sum(axis=2)                     # [ntaps, Cout]
+        coef = np.ones(len(t['ent_out'])) if t['ent_coef'] is None else np.abs(t['ent_coef'].astype(np.float64))
+        S = scipy.sparse.csr_matrix((coef, (t['ent_out'].astype(np.int64), t['ent_tap'].astype(np.int64))), shape=(HoWo, tap_abs.shape[0]))
+        rs = S.dot(tap_abs)                                                            # [HoWo, Cout]
+        if t['lastcol'] is not None:
+            rs = rs + np.abs(t['lastcol'][:Cout * HoWo].astype(np.float64)).reshape(Cout, HoWo).T
+        return float(rs.max()) if rs.size else 0.0
 
     def nnz(self):
         """Stored parameters: sum of tile sizes (keynet/sparse.py:778) -- or, for a factored operator, taps + entries +

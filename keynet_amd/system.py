@@ -130,10 +130,15 @@ class KeyedModel(object):
         """[N, D0+1] -> [N, classes+1]: the nn.Sequential of keynet/system.py:132 with the unkeyed ReLUs fused into the
         producing layer's kernel epilogue.  Stream-ordered on torch's current HIP stream; no host sync.
         `overlap`: run the batch as two half-batch column windows on two side streams, one kernel apart (see _forward_overlapped);
-        None = automatically for device-resident feature-major batches that are a multiple of 256 images, False = never."""
+        None = automatically for device-resident feature-major batches that are a multiple of 256 images, False = never.
+        Memory: the overlapped forward keeps two ping-pong workspaces of max_rows x N floats per (device, N) plan (VGG-16 at N = 256:
+        2 x 3.3 GB) plus two side streams; at most OVERLAP_PLANS_KEPT plans are cached (least recently used dropped),
+        release_workspace() drops them all."""
         forced = overlap is True
         if overlap is None and os.environ.get('KN_NO_OVERLAP') == '1':      # A/B switch
             overlap = False
+        if any(getattr(c, '_exact', True) == 'auto' for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer)):
+            overlap = False        # first forward of an 'auto' key-net: the layers calibrate their contract one by one (KeyedLayer._calibrate)
         if overlap is None:
             overlap = (img_cipher.is_cuda and img_cipher.dtype == torch.float32 and img_cipher.dim() == 2 and img_cipher.shape[0] >= 256 and
                        img_cipher.shape[0] % 256 == 0 and img_cipher.t().is_contiguous() and not torch.cuda.is_current_stream_capturing())
@@ -159,15 +164,20 @@ class KeyedModel(object):
 
     # -- overlapped forward: two half-batch column windows on two HIP streams, one kernel apart ---------------------------------
     OVERLAP_MIN_MACS = 2e11      # below this much work per forward the launches are too short for the overlap to pay (LeNet: launch-bound)
+    OVERLAP_PLANS_KEPT = 2       # least-recently-used plans beyond this are dropped (a service that sees many batch sizes must not pile up workspaces)
 
     def _overlap_plan(self, device, batch, force=False):
         """Launch list + segments for the overlapped forward, or None when this key-net / batch does not qualify.  A layer is run
         per half only if the half batch keeps it on the same kernel instantiation as the whole batch (conv tiles are 128 or 256
         batch columns wide) and it is a matrix-core conv layer; see the segment rule below."""
         key = (device.index, batch, bool(force))
-        plans = self.__dict__.setdefault('_overlap_plans', {})
-        if key in plans:
-            return plans[key]
+        plans = self.__dict__.setdefault('_overlap_plans', OrderedDict())
+        # a plan caches operator handles and flags: it is only valid for the layers' current (operator, contract) identities
+        sig = tuple((id(c.W), getattr(c, '_exact', True)) for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer))
+        if key in plans and plans[key][0] == sig:
+            plans.move_to_end(key)
+            return plans[key][1]
+        plans.pop(key, None)
         plan = None
         half = batch // 2
         children = list(self._keynet.children())
@@ -181,7 +191,7 @@ class KeyedModel(object):
                     steps = None                                   # a ReLU that could not be fused into a producer: simple path
                     break
                 fuse = (i + 1 < len(children)) and isinstance(children[i + 1], nn.ReLU)
-                exact = bool(getattr(c, '_exact', True))
+                exact = getattr(c, '_exact', True) is not False
                 W = c.W
                 relu = fuse or c.iskeyedrelu()
                 if type(W) is ksp.SparseMatrix and not exact and W._dense_device_op(device) is not None:
@@ -218,7 +228,9 @@ class KeyedModel(object):
                     plan = dict(steps=steps, segments=segs,
                                 bufs=[torch.empty(rows_max * batch, dtype=torch.float32, device=device) for _ in range(2)],
                                 streams=[torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)])
-        plans[key] = plan
+        plans[key] = (sig, plan)
+        while len(plans) > self.OVERLAP_PLANS_KEPT:      # each plan holds two workspaces of max_rows x batch floats (VGG-16 at 256 images: 2 x 3.3 GB)
+            plans.popitem(last=False)
         return plan
 
     def _macs_per_image(self):
@@ -285,17 +297,29 @@ class KeyedModel(object):
         return out.t()
 
     def exact_mode(self, flag):
-        """Switch every keyed layer between the two arithmetic contracts WITHOUT re-keying: True = the reference's accumulation
+        """Switch every keyed layer between the arithmetic contracts WITHOUT re-keying: True = the reference's accumulation
         order and mul-then-add rounding in every layer (bit-exact with scipy: order-preserving kernels, no MFMA); False =
-        float-key tolerance (1e-5: conv-taps and large dense operators on the matrix cores); None = back to the per-layer
-        setting the key-net was built with.  Returns self."""
+        matrix cores wherever an operator has such a path (conv-taps, large dense operators), whatever the error; 'auto' = per layer,
+        decided at the next forward so that the float-key tolerance 1e-5 holds against the reference's arithmetic (KeyedLayer._calibrate;
+        see contract_report()); None = back to the per-layer setting the key-net was built with (tiled key-nets: 'auto').  Returns self."""
         for c in self._keynet.children():
             if isinstance(c, klayer.KeyedLayer):
                 if not hasattr(c, '_exact_built'):
-                    c._exact_built = getattr(c, '_exact', True)
-                c._exact = c._exact_built if flag is None else bool(flag)
+                    c._exact_built = getattr(c, '_exact_decl', getattr(c, '_exact', True))
+                c._exact = c._exact_built if flag is None else klayer._contract(flag, True)
+                c.__dict__.pop('_contract_record', None)
         self.__dict__.pop('_overlap_plans', None)                  # the launch lists depend on the layers' contracts
         return self
+
+    def contract_report(self):
+        """Per keyed layer: the contract in force (True / False / 'auto' = not decided yet) and, for layers decided by calibration, the
+        record of that decision (bound, measured difference, tolerance).  `switched` lists the layers calibration moved off the matrix cores."""
+        rows = []
+        for (n, c) in self._keynet.named_children():
+            if isinstance(c, klayer.KeyedLayer):
+                rows.append(dict(name=n, exact=getattr(c, '_exact', True), calibration=getattr(c, '_contract_record', None)))
+        return dict(layers=rows, switched=[r['name'] for r in rows if r['calibration'] is not None and r['calibration'].get('decided') == 'exact' and 'bound' in r['calibration']],
+                    undecided=[r['name'] for r in rows if r['exact'] == 'auto'])
 
     def capture(self, img_cipher):
         """Capture forward_linear for this input shape into a HIP graph (torch.cuda.CUDAGraph on ROCm) and return a callable
@@ -315,7 +339,9 @@ class KeyedModel(object):
             self.forward_linear(static_in, overlap=False)   # warm-up on the capture stream
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # capture ON THE WARMED STREAM: per-stream state of the operators (the split-K workspace of a dense layer, kn_api.hip) was sized
+        # by the warm-up forward above; torch's default capture stream would be a fresh one, and a hipMalloc inside a capture is refused
+        with torch.cuda.graph(graph, stream=side):
             static_out = self.forward_linear(static_in, overlap=False)
 
         def replay(x):
@@ -478,8 +504,8 @@ def layergen(module, inshape, outshape, A, Ainv, tileshape=None, backend='hip', 
     """The plug-in seam of the reference (keynet/system.py:303-314): snaps the requested tile to divisors of the
     layer's spatial sizes, then dispatches on `backend`.  The reference accepts only 'scipy'; this build registers
     'hip'.  Anything else raises ValueError('invalid backend ...') exactly like the reference."""
-    if exact is None:
-        exact = tileshape is None       # untiled key-nets: bit-exact; tiled key-nets: float-key tolerance (MFMA)
+    # exact=None: untiled key-nets bit-exact; tiled key-nets 'auto' (matrix cores wherever the 1e-5 float-key contract holds, decided per
+    # layer at the first forward: KeyedLayer._calibrate)
     if tileshape is not None:
         tileshape = (find_closest_positive_divisor(outshape[1], tileshape[0]), find_closest_positive_divisor(inshape[1], tileshape[1]))
     if backend == 'hip':

@@ -48,25 +48,38 @@ def make_case(kind, n):
     return (knet, x.to('cuda:0'))
 
 
-def worker(rank, world_size, port, kind, n, q):
+def worker(rank, world_size, port, kind, n, q, backend='gloo'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend == 'nccl':                                      # RCCL: one rank per GPU, the communicator bound to the device up front
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world_size, device_id=torch.device('cuda', rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
     try:
+        calls = []
+        real = dist.all_gather_into_tensor
+
+        def counted(out, inp, *a, **k):
+            calls.append((str(inp.device), tuple(inp.shape)))
+            return real(out, inp, *a, **k)
+        dist.all_gather_into_tensor = counted
         (knet, x) = make_case(kind, n)
         y = kdist.sharded_forward(knet, x)                     # this rank's shard through the real path + all-gather
         ref = knet.forward_linear(x)[:, :-1]                   # the single-process result of the SAME batch
         (lo, hi) = kdist.shard_bounds(n, rank, world_size)
-        q.put((rank, bool(torch.equal(y, ref)), (lo, hi), tuple(y.shape), str(y.device)))
+        q.put((rank, bool(torch.equal(y, ref)), (lo, hi), tuple(y.shape), str(y.device), dist.get_backend(), calls))
     finally:
+        dist.all_gather_into_tensor = real
         dist.destroy_process_group()
 
 
-def run(kind, n, world_size=2, timeout=300):
+def run(kind, n, world_size=2, timeout=300, backend='gloo'):
     ctx = mp.get_context('spawn')        # fresh processes: a forked child must never inherit an initialised GPU runtime
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world_size, port, kind, n, q)) for r in range(world_size)]
+    procs = [ctx.Process(target=worker, args=(r, world_size, port, kind, n, q, backend)) for r in range(world_size)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=timeout) for _ in procs])

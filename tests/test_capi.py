@@ -67,3 +67,35 @@ def test_integration_md_stub_is_real_code():
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'check_integration_stub.py')],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'STUB OK' in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])
+
+
+def test_no_cpp_exception_crosses_the_c_abi():
+    """include/keynet_hip.h promises integer codes only.  Sizes that cannot be allocated (a host std::vector of 2^60 elements throws
+    std::length_error / std::bad_alloc inside the create function) and sizes that contradict the arrays must come back as codes with a
+    message -- a C++ exception unwinding into ctypes would abort the interpreter, so surviving this test IS the assertion."""
+    import numpy as np
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    ip = np.array([0, 1, 2], dtype=np.int32)
+    ix = np.array([0, 1], dtype=np.int32)
+    dt = np.array([1.0, 2.0], dtype=np.float32)
+    vp = (lambda a: a.ctypes.data_as(ctypes.c_void_p))
+    # absurd nnz with valid small arrays
+    for nnz in (1 << 60, (1 << 31) + 5, -3):
+        rc = L.kn_csr_create(2, 2, nnz, vp(ip), vp(ix), vp(dt), ctypes.byref(h))
+        assert rc in (1, 6) and h.value is None and len(L.kn_last_error()) > 0
+    # 2^60 tile entries: the per-entry tables are host vectors sized by `nent` before any entry is read
+    shp = np.array([1, 2, 2], dtype=np.int64)
+    blocks = np.zeros((1, 3), dtype=np.int64)
+    keys = np.zeros((1, 3), dtype=np.int64)
+    isb = np.zeros(1, dtype=np.uint8)
+    chan = np.ones((1, 1, 1), dtype=np.float32)
+    bias = np.zeros(1, dtype=np.float32)
+    rc = L.kn_conv2dtiled_create(4, 4, vp(shp), vp(shp), 1, vp(blocks), 1 << 60, vp(keys), vp(isb), vp(chan), vp(bias), ctypes.byref(h))
+    assert rc == 4 and h.value is None, (rc, L.kn_last_error())          # KN_ERR_NOMEM
+    assert b'alloc' in L.kn_last_error()
+    # a well-formed call still works as before on this box (no device: KN_ERR_NODEVICE; with a device: a handle)
+    rc = L.kn_csr_create(2, 2, 2, vp(ip), vp(ix), vp(dt), ctypes.byref(h))
+    assert rc in (0, 5)
+    if rc == 0:
+        assert L.kn_destroy(h) == 0
