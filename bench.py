@@ -77,6 +77,19 @@ def build_workload(name, rank, exact=None):
         (sensor, knet) = ksys.Keynet((3, 224, 224), net, local_geometric='permutation', local_photometric='uniform_random_gain', beta=0.5,
                                      tileshape=(64, 64), blocksize=64, exact=exact)
         (inshape, batch, desc) = ((3, 224, 224), 256, 'Keynet(permutation + uniform_random_gain, tile=64) VGG16(2622) 3x224x224: float keys')
+    elif name == 'vgg16-givens':
+        # the reference's OWN float-key VGG-16 configuration (test/test_keynet.py:133-151, test_vgg16_orthogonal): block-local Givens rotations
+        # (alpha = 2) + block-local affine photometric keys (beta = gamma = 1), tile = blocksize = 224 // 16 = 14, channel memory order.
+        # Keyed directly in factored form (the reference route cannot build it: 15 G non-zeros); fill-in: ~9.0-9.3 slots per output pixel
+        # on average, up to 19, every entry carries a coefficient.
+        torch.manual_seed(0)
+        net = VGG16(num_classes=2622).eval()
+        np.random.seed(0)
+        (sensor, knet) = ksys.Keynet((3, 224, 224), net, tileshape=(224 // 16, 224 // 16), global_geometric='identity', hierarchical_blockshape=(2, 2),
+                                     hierarchical_permute_at_level=(0, 1, 2), local_geometric='givens_orthogonal', alpha=2.0, blocksize=224 // 16,
+                                     local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='channel', exact=exact)
+        (inshape, batch, desc) = ((3, 224, 224), 256, 'Keynet(givens_orthogonal alpha=2 + uniform_random_affine beta=gamma=1, tile=blocksize=14) VGG16(2622) 3x224x224: '
+                                                       'the float-key configuration of test/test_keynet.py:133-151')
     elif name == 'lenet':
         torch.manual_seed(0)
         net = LeNet_AvgPool().eval()
@@ -283,7 +296,7 @@ def layer_table(knet, batch):
     for (i, (name, c)) in enumerate(children):
         if not isinstance(c, KeyedLayer):
             continue
-        exact = bool(getattr(c, '_exact', True))
+        exact = getattr(c, '_exact', True) is not False
         if type(c.W) is ksp.SparseMatrix and not exact and c.W._dense_device_op() is not None:
             kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
             (r, cdim) = c.W.shape
@@ -301,8 +314,9 @@ def layer_table(knet, batch):
             nnz_exp = op.nnz_expanded()
             kind = 'csr'
             wbytes = 8 * nnz_exp               # (col,val) per non-zero
+        flags = (1 if ((i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)) or c.iskeyedrelu() else 0) | (2 if (exact and kind != 'dense') else 0)
         rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch,
-                         bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c,
+                         bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c, plan=(c.W._dense_device_op() if kind == 'dense' else op).plan(batch, flags),
                          fuse=(i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)))
     return rows
 
@@ -427,10 +441,12 @@ def exact_parity(knet, x_cipher, n_img=8, n_pix=4):
 
 def float_key_parity(dev, batch=256):
     """Float-key family on a VGG-16 slice (the same 21-layer topology at width 8 on 32x32 inputs, keyed by TiledOrthogonalKeynet:
-    hierarchical permutation + block Givens rotations + affine photometric keys, gamma = 100): how far the matrix-core path is from
-    the order-preserving path, which is bit-exact with the reference's scipy arithmetic (tests/test_parity_gpu.py).  Per conv layer
-    both paths get the SAME input (the exact path's previous output); reported: the worst absolute difference and the worst
-    difference in units of eps32 * sum|a.x| (the rounding-noise scale of any f32 evaluation of that sum)."""
+    hierarchical permutation + block Givens rotations + affine photometric keys, gamma = 100).  The order-preserving path is bit-exact
+    with the reference's scipy arithmetic (tests/test_parity_gpu.py), so it stands in for the reference here.  Two records:
+      contract   the key-net under its DEFAULT contract ('auto'): per conv layer, the shipped forward's output against the exact path on
+                 the same input -- `ok` = every layer within 1e-5 * max(1, |y|), unconditioned; `layers_switched_to_exact` = the layers the
+                 calibration moved off the matrix cores to get there;
+      forced_mfma  the same layers forced onto the matrix cores (exact_mode(False)): how far a re-ordered f32 evaluation lands."""
     import warnings
     t0 = time.time()
     torch.manual_seed(0)
@@ -441,32 +457,130 @@ def float_key_parity(dev, batch=256):
         (sensor, knet) = ksys.TiledOrthogonalKeynet((3, 32, 32), net, 8)
     g = torch.Generator(device=dev).manual_seed(77)
     x = torch.randn((batch, 3, 32, 32), generator=g, device=dev)
-    y = sensor.fromtensor(x).encrypt().astensor()
-    rows = []
-    children = list(knet._keynet.named_children())
-    for (i, (name, c)) in enumerate(children):
-        if not isinstance(c, KeyedLayer):
-            continue
-        fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
-        if isinstance(c.W, ksp.Conv2dTiledMatrix):
-            xt = y.t()
-            ye = c.W.torchdot(xt, relu=fuse, exact=True)
-            ym = c.W.torchdot(xt, relu=fuse, exact=False)
-            rows.append({'layer': name, 'max_abs_diff': float((ye - ym).abs().max()), 'max_abs_out': float(ye.abs().max())})
-            y = ye.t()
-        else:
-            y = c.forward(y, fuse_relu=fuse)
+    xc = sensor.fromtensor(x).encrypt().astensor()
+    import logging
+    logging.getLogger('keynet_amd').setLevel(logging.ERROR)          # the switches are reported below, not as log lines
+    la = knet.forward_linear(xc)[:, :-1]                              # calibrates every layer
+    logging.getLogger('keynet_amd').setLevel(logging.WARNING)
+    rep = knet.contract_report()
+
+    def per_layer(force_mfma):
+        rows = []
+        y = xc
+        children = list(knet._keynet.named_children())
+        for (i, (name, c)) in enumerate(children):
+            if not isinstance(c, KeyedLayer):
+                continue
+            fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+            if isinstance(c.W, ksp.Conv2dTiledMatrix):
+                xt = y.t()
+                ye = c.W.torchdot(xt, relu=fuse, exact=True)
+                ys = c.W.torchdot(xt, relu=fuse, exact=False) if force_mfma else c.forward(y, fuse_relu=fuse).t()
+                (d, m) = (float((ye - ys).abs().max()), float(ye.abs().max()))
+                rows.append({'layer': name, 'max_abs_diff': d, 'max_abs_out': m, 'within_1e-5': bool(d <= 1e-5 * max(1.0, m)), 'ran': 'mfma' if (force_mfma or c._exact is False) else 'exact'})
+                y = ye.t()
+            else:
+                y = c.forward(y, fuse_relu=fuse)
+        return rows
+    rows_auto = per_layer(False)
+    rows_mfma = per_layer(True)
     knet.exact_mode(True)
-    le = knet.forward_linear(sensor.fromtensor(x).encrypt().astensor())[:, :-1]
+    le = knet.forward_linear(xc)[:, :-1]
     knet.exact_mode(False)
-    lm = knet.forward_linear(sensor.fromtensor(x).encrypt().astensor())[:, :-1]
+    lm = knet.forward_linear(xc)[:, :-1]
     with torch.no_grad():
         lp = net(x.cpu()).reshape(batch, -1)
-    return {'net': 'TiledOrthogonalKeynet VGG16 slice (width 8, 3x32x32, tile 8), %d images' % batch, 'layers': rows,
-            'worst_layer_abs_diff_mfma_vs_exact': max(r['max_abs_diff'] for r in rows),
-            'logits_max_abs_diff_mfma_vs_exact': float((le - lm).abs().max()), 'logits_max_abs': float(le.abs().max()),
+    return {'net': 'TiledOrthogonalKeynet VGG16 slice (width 8, 3x32x32, tile 8), %d images' % batch,
+            'contract': {'tolerance': 1e-5, 'layers': rows_auto, 'ok': bool(all(r['within_1e-5'] for r in rows_auto)), 'layers_switched_to_exact': rep['switched'],
+                         'worst_layer_abs_diff': max(r['max_abs_diff'] for r in rows_auto),
+                         'logits_max_abs_diff_vs_exact': float((le - la).abs().max())},
+            'ok': bool(all(r['within_1e-5'] for r in rows_auto)), 'layers_switched_to_exact': rep['switched'],
+            'forced_mfma': {'layers': rows_mfma, 'worst_layer_abs_diff_mfma_vs_exact': max(r['max_abs_diff'] for r in rows_mfma),
+                            'logits_max_abs_diff_mfma_vs_exact': float((le - lm).abs().max())},
+            'logits_max_abs': float(le.abs().max()),
             'logits_max_abs_err_exact_vs_source_network': float((le.cpu() - lp).abs().max()),
             'logits_max_abs_err_mfma_vs_source_network': float((lm.cpu() - lp).abs().max()), 'seconds': time.time() - t0}
+
+
+def oracle_parity_csr(knet, x_cipher, logits, n_img=8):
+    """Checker for the untiled (permutation) key-nets: the CPU oracle (oracle/: scipy csr_matvecs restated) recomputes the first images
+    through EVERY layer of the same stored-order operators; the device logits of the timed batch must equal them bit for bit."""
+    import oracle
+    t0 = time.time()
+    yo = np.ascontiguousarray(x_cipher[:n_img].cpu().numpy().T)                     # [D0+1, n] feature-major
+    children = list(knet._keynet.named_children())
+    i = 0
+    while i < len(children):
+        (name, c) = children[i]
+        if not isinstance(c, KeyedLayer) or type(c.W) is not ksp.SparseMatrix:
+            return {'check': 'CPU oracle on every layer', 'ok': None, 'skipped': 'layer %s is not a plain stored-order CSR operator' % name}
+        fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+        (ip, ix, dt) = ksp._stored_order_csr(c.W._matrix)
+        yo = oracle.csr_matvecs(c.W.shape, ip, ix, dt, yo)
+        if fuse or c.iskeyedrelu():
+            yo = np.maximum(yo, 0)
+        i += 2 if fuse else 1
+    got = logits[:n_img].contiguous().cpu().numpy()
+    eq = bool(np.array_equal(got, yo.T[:, :-1]))
+    return {'check': 'logits of the timed batch vs the CPU oracle (scipy csr_matvecs restated) run through every layer on the first %d images' % n_img,
+            'bit_equal': eq, 'ok': eq, 'images': n_img, 'seconds': time.time() - t0}
+
+
+def run_secondary(args):
+    """BASELINE configs[1] and [2] in the driver's line: LeNet_AvgPool B=1024 and AllConvNet B=4096 each run as a CHILD process of this
+    bench (its own host phase, scipy baseline, device phase, oracle parity) BEFORE this process touches the GPU; the child's JSON line is
+    condensed into `secondary`.  (A child process, not an exec: the parent goes on to the VGG legs.)"""
+    out = {}
+    for (wl, steps, extra) in (('lenet', max(args.steps, 200), ['--graph-leg']), ('allconv', max(args.steps, 10), [])):
+        t0 = time.time()
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', str(steps), '--warmup', str(max(args.warmup, 3)), '--layer-iters', '3',
+               '--no-secondary', '--cpu-budget', '8'] + extra
+        env = dict(os.environ)
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+            env.pop(k, None)
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+            for l in p.stderr.splitlines():
+                if l.startswith('[bench'):
+                    log('  [%s] %s' % (wl, l))
+            if p.returncode != 0 or len(lines) != 1:
+                out[wl] = {'error': 'child exited with %d' % p.returncode, 'stderr_tail': p.stderr[-800:]}
+                continue
+            r = json.loads(lines[0])
+            cpu = r.get('cpu_baseline') or {}
+            out[wl] = {'workload': r['config']['workload'], 'images_per_gpu': r['config']['images_per_gpu'], 'images_per_s': r['value'], 'ms_per_step': r['ms_per_step'],
+                       'steps': r['steps'], 'warmup': r['warmup'], 'roofline': r['roofline'], 'whole_net': {k: r.get(k) for k in ('achieved_hbm_gbs_algorithmic', 'achieved_tflops_algorithmic')},
+                       'parity': r.get('oracle_parity'), 'parity_vs_source_network': r.get('parity'), 'graph': r.get('graph'), 'layers_ms': r.get('layers_ms'), 'plans': r.get('plans'),
+                       'cpu_baseline': {k: cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'engine', 'sample', 'all_cores')}, 'child_wall_s': time.time() - t0}
+        except Exception as e:      # a reported-only section must never break the headline
+            out[wl] = {'error': str(e)}
+    return out
+
+
+def end_to_end(sensor, knet, x_plain, steps, warmup):
+    """Plaintext -> logits (keynet/system.py:250-255 + 130-133): sensor.fromtensor(x).encrypt() -- homogenise on the device
+    (kn_affine_to_linear) and apply the image key (the same SpMM primitive) -- inside the timed loop, then the keyed forward."""
+    def step():
+        return knet.forward_linear(sensor.fromtensor(x_plain).encrypt().astensor())
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        y = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    e0.record()
+    for _ in range(5):
+        xc = sensor.fromtensor(x_plain).encrypt().astensor()
+    e1.record()
+    torch.cuda.synchronize()
+    del y, xc
+    n = x_plain.shape[0]
+    return {'images_per_s': n * steps / el, 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'encrypt_ms': e0.elapsed_time(e1) / 5,
+            'what': 'sensor.fromtensor(x_plain).encrypt() + forward_linear per step, plaintext batch resident in HBM'}
 
 
 def collective_record(knet, sensor, x_cipher, gathered, batch, world, rank, local_rank, dev, inshape, share):
@@ -531,7 +645,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'lenet', 'allconv'])
+    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=5)
@@ -541,14 +655,24 @@ def main():
     ap.add_argument('--dist', action='store_true', help='initialise the RCCL process group and all-gather the logits every step even with ONE rank '
                                                         '(exercises the multi-GPU code path on a single-GPU box)')
     ap.add_argument('--no-secondary', action='store_true', help='skip the LeNet / AllConvNet legs of the default run')
+    ap.add_argument('--graph-leg', action='store_true', help='additionally time the forward replayed from a captured HIP graph (reported as `graph`)')
+    ap.add_argument('--cpu-budget', type=float, default=24.0, help='seconds of scipy work for the CPU baseline sample')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))                       # before ANY GPU call in this process
+    # stdout carries exactly ONE line, the JSON record: native libraries (RCCL prints a version banner to fd 1) go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     assert args.gpus == world, '--gpus %d but WORLD_SIZE=%d' % (args.gpus, world)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    secondary = None
+    if args.workload == 'vgg16' and world == 1 and not args.no_secondary and not args.exact and not args.dist and args.batch is None:
+        secondary = run_secondary(args)                   # children own the GPU one after the other; this process has not touched it yet
 
     # ---- host phase: keying and the CPU baseline, nothing below touches the GPU until "device phase" ----------------------
     (sensor, knet, inshape, batch, desc, net) = build_workload(args.workload, rank, exact=True if args.exact else None)
@@ -557,9 +681,9 @@ def main():
         desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
     batch = args.batch if args.batch is not None else batch
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and args.workload != 'vgg16-gain':      # (the scipy baseline is measured on the headline workload)
+    if world == 1 and not args.no_cpu_baseline and args.workload not in ('vgg16-gain', 'vgg16-givens'):      # (the scipy baseline is measured on the headline workload)
         t0 = time.time()
-        cpu = cpu_baseline(knet, args.workload)
+        cpu = cpu_baseline(knet, args.workload, budget_s=args.cpu_budget)
         log('[bench cpu] baseline section took %.1f s' % (time.time() - t0))
 
     # ---- device phase --------------------------------------------------------------------------------------------------------
@@ -595,6 +719,7 @@ def main():
     n_gate = min(4, batch)
     with torch.no_grad():
         y_plain = net(x[:n_gate].cpu()).reshape(n_gate, -1) if rank == 0 else None
+    x_plain = x if (rank == 0 and world == 1) else None
     del x
     t0 = time.time()
     y = knet.forward_linear(x_cipher)                            # first call uploads the operators
@@ -641,6 +766,11 @@ def main():
     collective = None
     if use_dist:
         collective = collective_record(knet, sensor, x_cipher, out, batch, world, rank, local_rank, dev, inshape, share)
+    oracle_par = None
+    if rank == 0 and not args.workload.startswith('vgg16'):
+        oracle_par = oracle_parity_csr(knet, x_cipher, out[:batch])
+        if oracle_par.get('ok') is False:
+            raise AssertionError('oracle parity failed: %s' % json.dumps(oracle_par))
     del out
 
     if rank == 0:
@@ -653,7 +783,7 @@ def main():
         total_bytes = sum(r['bytes'] for r in table)
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
-            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
+            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
             'value': batch * world * args.steps / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'mode': mode, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
@@ -663,7 +793,45 @@ def main():
             'cpu_baseline': cpu if (cpu is not None or world == 1) else 'measured at N=1 only (the scipy baseline runs on rank 0 of a single-GPU run; see BENCH / profiles)',
             'collective': collective,
             'layers_ms': {r['name']: round(r['ms'], 4) for r in table},
+            'plans': {r['name']: r['plan'] for r in table},        # kn_spmm_plan: the kernels (tile shape, loader) each layer really takes at this batch
         }
+        if oracle_par is not None:
+            res['oracle_parity'] = oracle_par
+        rep = knet.contract_report()
+        if any(r['calibration'] is not None for r in rep['layers']):
+            # float-key contract (KeyedLayer._calibrate): which layers the first forward left on the matrix cores, which it moved to the
+            # order-preserving kernels so that |y - y_reference| <= 1e-5 max(1, |y|) holds, and the evidence per layer
+            res['contract'] = {'tolerance': 1e-5, 'layers_switched_to_exact': rep['switched'],
+                               'layers': {r['name']: ({k: r['calibration'].get(k) for k in ('decided', 'bound', 'measured_mfma_vs_exact', 'tol', 'max_abs_rowsum', 'max_abs_x', 'max_abs_y')}
+                                                      if r['calibration'] is not None else {'decided': 'exact' if r['exact'] else 'mfma', 'declared': True}) for r in rep['layers']}}
+        if args.workload.startswith('vgg16'):
+            convs = [(r['name'], r['layer'].W) for r in table if isinstance(r['layer'].W, ksp.Conv2dTiledMatrix) and r['layer'].W._taps is not None]
+            res['config']['slots_per_output_pixel'] = {n: {'mean': round(float(len(W._taps['ent_out'])) / (W._outshape[1] * W._outshape[2]), 3),
+                                                           'max': int(np.bincount(W._taps['ent_out']).max())} for (n, W) in convs}
+            res['config']['entries_carry_coefficients'] = bool(any(W._taps['ent_coef'] is not None for (n, W) in convs))
+        if world == 1 and x_plain is not None and replay is None:
+            try:
+                res['end_to_end'] = end_to_end(sensor, knet, x_plain, args.steps, 1)
+            except Exception as e:
+                res['end_to_end'] = {'error': str(e)}
+        if args.graph_leg and replay is None and world == 1:
+            try:
+                rp = knet.capture(x_cipher)
+                for _ in range(3):
+                    rp(x_cipher)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    og = rp(x_cipher)
+                torch.cuda.synchronize()
+                el_g = time.perf_counter() - t0
+                res['graph'] = {'images_per_s': batch * args.steps / el_g, 'ms_per_step': 1e3 * el_g / args.steps,
+                                'bit_equal_to_eager': bool(torch.equal(og, knet.forward_linear(x_cipher))), 'what': 'the same forward replayed from ONE captured HIP graph (KeyedModel.capture)'}
+                del rp, og
+            except Exception as e:
+                res['graph'] = {'error': str(e)}
+        if secondary is not None:
+            res['secondary'] = secondary
         # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key")
         if args.workload == 'vgg16' and world == 1 and not args.exact and not args.no_exact_leg and replay is None:
             knet.exact_mode(True)
@@ -690,7 +858,7 @@ def main():
                 res['float_key_parity'] = float_key_parity(dev)
             except Exception as e:      # a reported-only record must never break the bench line
                 res['float_key_parity'] = {'error': str(e)}
-        print(json.dumps(res), flush=True)
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

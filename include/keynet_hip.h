@@ -127,6 +127,12 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
 int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
             float* y_dev, int64_t ldy, uint32_t flags, void* stream);
 
+/* Introspection: which kernels kn_spmm would launch for this operator, batch width, leading dimensions (16-byte aligned activations
+ * assumed) and flags -- the SAME dispatch code runs, every launch site describes itself instead of launching.  No reference
+ * counterpart (scipy has one kernel); it exists so that measurements can state which loader / tile shape produced them
+ * ("choices evidenced").  Writes a NUL-terminated, ';'-separated list into buf. */
+int kn_spmm_plan(kn_handle_t h, int64_t n_vecs, int64_t ldx, int64_t ldy, uint32_t flags, char* buf, int64_t buf_len);
+
 /* unkeyed nn.ReLU on a whole activation block (keynet/system.py:92) when it could not be fused */
 int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream);
 

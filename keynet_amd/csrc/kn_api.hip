@@ -12,6 +12,8 @@ extern "C" int kn_destroy(kn_handle_t h);
 namespace kn {
 
 static thread_local std::string g_err;
+static thread_local PlanSink* g_plan = nullptr;
+PlanSink*& plan_sink() { return g_plan; }
 void set_error(const std::string& msg) { g_err = msg; }
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -609,7 +611,7 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
         KN_REQUIRE(!(flags & KN_FLAG_EXACT), KN_ERR_UNSUPPORTED, "KN_FLAG_EXACT on a dense (MFMA) operator: create it with kn_csr_create instead");
         const int64_t outs = h->rows - 1, S = h->dense_splits;
         float* ws = nullptr;
-        {
+        if (plan_sink() == nullptr) {
             // partial-sum workspace of THIS stream, grown on demand (the growing call is not capturable in a HIP graph: run one
             // eager forward per stream and batch size first, as KeyedModel.capture does)
             std::lock_guard<std::mutex> g(h->lazy_mu);
@@ -655,6 +657,22 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
     }
     // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
     return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    });
+}
+
+int kn_spmm_plan(kn_handle_t h, int64_t n_vecs, int64_t ldx, int64_t ldy, uint32_t flags, char* buf, int64_t buf_len) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(buf != nullptr && buf_len > 0, KN_ERR_INVALID, "NULL buffer");
+    buf[0] = 0;
+    PlanSink sink;
+    plan_sink() = &sink;
+    // 16-byte aligned stand-ins for the activation pointers: the dispatch logic looks at their alignment only, and nothing is launched
+    const int rc = kn_spmm(h, reinterpret_cast<const float*>((uintptr_t)4096), ldx, n_vecs, reinterpret_cast<float*>((uintptr_t)8192), ldy, flags, nullptr);
+    plan_sink() = nullptr;
+    if (rc) return rc;
+    std::strncpy(buf, sink.text.c_str(), (size_t)buf_len - 1);
+    buf[buf_len - 1] = 0;
+    return KN_OK;
     });
 }
 

@@ -1206,6 +1206,12 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
         if (r4 < 4.0 && f4 > 0.0 && f3 < f4) occ_cap = 3;
     }
     const unsigned pad = lds_pad_for_occupancy(static_lds, occ_cap);
+    auto D = [&](const char* loader, bool tail) {        // evaluated only by kn_spmm_plan
+        char b[200];
+        snprintf(b, sizeof(b), "convtaps_mfma_kernel<MT=%d,NB=%d,KC=%d> loader=%s%s%s occ_cap=%d", MT, NB, KC, loader, a.unit_coef ? "" : "+coef",
+                 tail ? " tail_split" : "", occ_cap);
+        return std::string(b);
+    };
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  KN_NO_SPTR = A/B
@@ -1253,8 +1259,8 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
                     }
                 }
 #endif
-                if (sptr) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
-                else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                if (sptr) KN_LAUNCH(D("sptr(wave-uniform pointers)", true), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
+                else KN_LAUNCH(D("fast(per-thread pointers)", true), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>), dim3((unsigned)grid), dim3(256), pad, s, a);
                 return;
             }
         }
@@ -1262,12 +1268,12 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     const int64_t grid = 8 * chunk;
     if constexpr (KC == 16) {
         if (sptr) {
-            hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+            KN_LAUNCH(D("sptr(wave-uniform pointers)", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
             return;
         }
     }
-    if (fast) hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
-    else hipLaunchKernelGGL((convtaps_mfma_kernel<MT, NB, KC, WM, WN, 0, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+    if (fast) KN_LAUNCH(D("fast(per-thread pointers)", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+    else KN_LAUNCH(D("generic", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 0, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
@@ -1318,15 +1324,15 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        if (pipe && rbx == 16 && A.unit_coef) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe && rbx == 16) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe && A.unit_coef) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (pipe) hipLaunchKernelGGL((convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else if (v4) hipLaunchKernelGGL(convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
-        else hipLaunchKernelGGL(convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16>", (convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef>", (convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef>", (convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (v4) KN_LAUNCH("convtaps_exact_kernel<vec=4>", convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else KN_LAUNCH("convtaps_exact_kernel<vec=1>", convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
-            hipLaunchKernelGGL(conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
+            KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
                                x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
         }
         KN_HIP(hipGetLastError());
@@ -1347,9 +1353,9 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         if (a.sk_desc && a.n_mt == 1 && !no_pipe) {
             static const int64_t slots = xcd_slots(convtaps_smallk_pipe_kernel);
             const int64_t per_xcd = std::min<int64_t>(std::max<int64_t>(slots, 32), (items + 7) / 8);
-            hipLaunchKernelGGL(convtaps_smallk_pipe_kernel, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, s, a);
+            KN_LAUNCH("convtaps_smallk_pipe_kernel", convtaps_smallk_pipe_kernel, dim3((unsigned)(8 * per_xcd)), dim3(256), 0, s, a);
         } else {
-            hipLaunchKernelGGL(convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
+            KN_LAUNCH("convtaps_smallk_kernel", convtaps_smallk_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, a);
         }
     } else if (big_m) {
         a.n_mt = (int32_t)(A.cout_pad / 128);
@@ -1364,7 +1370,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     }
     if (A.has_last) {
         const int64_t out_last = A.Cout * A.Hout * A.Wout;
-        hipLaunchKernelGGL(conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
+        KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
                            x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
     }
     KN_HIP(hipGetLastError());

@@ -843,14 +843,14 @@ static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_ve
         const int64_t n_rb = (A.n_work * (RB / RBK) + WAVES - 1) / WAVES;
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
-        hipLaunchKernelGGL((csr_group_kernel<VEC, RBK>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+        KN_LAUNCH("csr_group_kernel<vec=" + std::to_string(VEC) + ",rows=" + std::to_string(RBK) + ">", (csr_group_kernel<VEC, RBK>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
                            A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
     }
     if (A.n_loose > 0) {
         const int64_t n_rb = (A.n_loose + WAVES - 1) / WAVES;
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
-        hipLaunchKernelGGL(csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
+        KN_LAUNCH("csr_rows_kernel<vec=" + std::to_string(VEC) + ">", csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
                            y, ldy, n_vecs, relu, n_rb);
     }
     KN_HIP(hipGetLastError());
@@ -864,13 +864,13 @@ static int launch_csr_pipe(const CsrDev& A, const float* x, int64_t ldx, int64_t
     {
         const int64_t n_rb = (A.n_work * (RB / RBX) + WAVES - 1) / WAVES;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        hipLaunchKernelGGL((csr_group_pipe_kernel<RBX>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+        KN_LAUNCH("csr_group_pipe_kernel<rows=" + std::to_string(RBX) + ">", (csr_group_pipe_kernel<RBX>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
                            A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
     }
     if (A.n_loose > 0) {
         const int64_t n_rb = (A.n_loose + WAVES - 1) / WAVES;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
-        hipLaunchKernelGGL(csr_rows_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y, ldy,
+        KN_LAUNCH("csr_rows_kernel<vec=4>", csr_rows_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y, ldy,
                            n_vecs, relu, n_rb);
     }
     KN_HIP(hipGetLastError());
@@ -893,7 +893,7 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
         const int64_t n_ct = (n_vecs + 63) / 64;
         const int64_t grid_big = ((n_ct * A.n_big + 7) / 8) * 8;
         const int64_t grid_long = A.n_long * ((n_ct + 3) / 4);
-        hipLaunchKernelGGL(csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
+        KN_LAUNCH("csr_big_group_kernel", csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
                            A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, grid_big, A.long_rows, A.n_long, A.indptr, A.indices, A.data);
         KN_HIP(hipGetLastError());
         if (A.n_work == 0 && A.n_loose == 0) return KN_OK;
@@ -903,7 +903,7 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
         (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0)) {
         const int64_t n_rb = (A.n_loose + 2 * WAVES - 1) / (2 * WAVES);
         const int64_t items = ((n_vecs + 127) / 128) * n_rb;
-        hipLaunchKernelGGL(csr_rows_pair_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y,
+        KN_LAUNCH("csr_rows_pair_kernel", csr_rows_pair_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y,
                            ldy, n_vecs, relu, n_rb);
         KN_HIP(hipGetLastError());
         return KN_OK;

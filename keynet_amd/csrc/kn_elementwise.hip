@@ -88,7 +88,7 @@ int dense_reduce(const float* z, int64_t ldz, int64_t outs, int64_t splits, cons
                  int relu, hipStream_t s) {
     const int64_t total = (outs + 1) * n_vecs;
     const int64_t grid = std::min<int64_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(dense_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, z, ldz, outs, (int)splits, lastcol, xlast, y, ldy, n_vecs, relu);
+    KN_LAUNCH("dense_reduce_kernel", dense_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, s, z, ldz, outs, (int)splits, lastcol, xlast, y, ldy, n_vecs, relu);
     KN_HIP(hipGetLastError());
     return KN_OK;
 }

@@ -46,6 +46,25 @@ static inline int guarded(F&& body) noexcept {
     }
 }
 
+// kn_spmm_plan: the dispatch logic runs exactly as in kn_spmm, but every launch site describes itself into the sink instead of launching.
+struct PlanSink {
+    std::string text;
+    int launches = 0;
+};
+PlanSink*& plan_sink();   // thread-local; null outside kn_spmm_plan
+
+#define KN_LAUNCH(desc, kernel, grid, block, lds, stream, ...)                                                   \
+    do {                                                                                                         \
+        if (kn::PlanSink* _ps = kn::plan_sink()) {                                                               \
+            if (_ps->launches) _ps->text += "; ";                                                                \
+            _ps->text += (desc);                                                                                 \
+            _ps->text += " grid=" + std::to_string((unsigned long long)(grid).x);                                \
+            _ps->launches++;                                                                                     \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+        }                                                                                                        \
+    } while (0)
+
 enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2 };
 
 // Order-preserving CSR resident in HBM.
