@@ -107,6 +107,15 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3],
  * multiple of 256 (use kn_csr_create then).  KN_FLAG_EXACT is refused on such a handle. */
 int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out);
 
+/* Replaces the nn.Sequential walk of KeyedModel.forward (keynet/system.py:130-133, `self._keynet.forward(x)`) for a key-net whose
+ * operators are all CSR handles (kn_csr_create / kn_tiled_create: the permutation key-nets) and whose activations are small enough
+ * to stay on chip: kn_spmm on the returned handle applies ops[0] ... ops[n_ops-1] back to back in ONE launch, the activations of
+ * four batch columns resident in LDS, ReLU after operator l when flags[l] & KN_FLAG_RELU (flags may be NULL).  Same arithmetic as
+ * n_ops kn_spmm calls with KN_FLAG_EXACT (stored order, f32 multiply then add): bit-identical results.  The handle keeps its own
+ * copy of the operators (ops may be destroyed afterwards).  X is [ops[0].cols, n_vecs], Y is [ops[n_ops-1].rows, n_vecs].
+ * KN_ERR_UNSUPPORTED when an operator is not a CSR handle, n_ops > 12, or (max features in + out of a layer) * 16 B > 160 KiB. */
+int kn_chain_create(int64_t n_ops, const kn_handle_t* ops, const uint32_t* flags, kn_handle_t* out);
+
 int kn_destroy(kn_handle_t h);
 
 /* SparseMatrix.nnz / TiledMatrix.nnz / Conv2dTiledMatrix.nnz (keynet/sparse.py:494,649,778): stored parameters. */

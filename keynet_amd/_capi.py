@@ -19,7 +19,7 @@ KN_ABI_VERSION = 1
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_dense_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_plan', 'kn_relu',
+           'kn_convtaps_create', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -54,6 +54,7 @@ def lib():
         L.kn_conv2dtiled_create.argtypes = [i64, i64, p, p, i64, p, i64, p, p, p, p, p]
         L.kn_convtaps_create.argtypes = [p, p, i64, p, i64, p, p, p, p, p, p]
         L.kn_dense_create.argtypes = [i64, i64, p, p]
+        L.kn_chain_create.argtypes = [i64, p, p, p]
         L.kn_destroy.argtypes = [p]
         L.kn_nnz.argtypes = [p, p]
         L.kn_nnz_expanded.argtypes = [p, p]
@@ -171,6 +172,16 @@ class Operator(object):
         assert w.ndim == 2
         h = ctypes.c_void_p()
         check(lib().kn_dense_create(int(w.shape[0]), int(w.shape[1]), wp, ctypes.byref(h)))
+        return Operator(h)
+
+    @staticmethod
+    def chain(operators, flags):
+        """kn_chain_create: the operators (CSR handles, in application order) as ONE launch; flags[l] & KN_FLAG_RELU = ReLU after operator l."""
+        n = len(operators)
+        hs = (ctypes.c_void_p * n)(*[op.handle for op in operators])
+        fl = (ctypes.c_uint32 * n)(*[int(f) for f in flags])
+        h = ctypes.c_void_p()
+        check(lib().kn_chain_create(n, hs, fl, ctypes.byref(h)))
         return Operator(h)
 
     def nnz(self):

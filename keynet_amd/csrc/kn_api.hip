@@ -516,9 +516,31 @@ int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out
     });
 }
 
+int kn_chain_create(int64_t n_ops, const kn_handle_t* ops, const uint32_t* flags, kn_handle_t* out) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
+    *out = nullptr;
+    KN_REQUIRE(ops != nullptr && n_ops >= 1, KN_ERR_INVALID, "no operators");
+    int cur = -1;
+    KN_HIP(hipGetDevice(&cur));
+    KN_REQUIRE(ops[0] != nullptr && cur == ops[0]->device, KN_ERR_INVALID, "create the chain under the device its operators live on");
+    OperatorPtr h(new kn_operator());
+    h->kind = KIND_CHAIN;
+    h->device = cur;
+    int64_t nnz = 0;
+    int rc = chain_create(n_ops, ops, flags, &h->chain, &h->rows, &h->cols, &nnz);
+    if (rc) return rc;
+    h->nnz_stored = nnz;
+    h->nnz_expanded = nnz;
+    *out = h.release();
+    return KN_OK;
+    });
+}
+
 int kn_destroy(kn_handle_t h) {
     return guarded([&]() -> int {
     if (!h) return KN_OK;
+    if (h->chain) chain_free(h->chain);
     if (h->exact) kn_destroy(h->exact);
     if (h->dense_sub) kn_destroy(h->dense_sub);
     if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
@@ -572,7 +594,7 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
         }
         return KN_OK;
     }
-    KN_REQUIRE(h->kind == KIND_CONVTAPS, KN_ERR_UNSUPPORTED, "kn_export_csr: dense operators are exported by their creator (the host keeps the matrix)");
+    KN_REQUIRE(h->kind == KIND_CONVTAPS, KN_ERR_UNSUPPORTED, "kn_export_csr: dense operators and chains are exported by their creator (the host keeps the matrices)");
     std::vector<int32_t> ip, ix;
     std::vector<float> dt;
     std::vector<int64_t> lr;
@@ -607,6 +629,7 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
         KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one (create it under the device of x)");
     }
     if (h->kind == KIND_CSR) return csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    if (h->kind == KIND_CHAIN) return chain_forward(h->chain, x_dev, ldx, n_vecs, y_dev, ldy, s);   // order-preserving by construction; ReLU flags were fixed at create
     if (h->kind == KIND_DENSE) {
         KN_REQUIRE(!(flags & KN_FLAG_EXACT), KN_ERR_UNSUPPORTED, "KN_FLAG_EXACT on a dense (MFMA) operator: create it with kn_csr_create instead");
         const int64_t outs = h->rows - 1, S = h->dense_splits;

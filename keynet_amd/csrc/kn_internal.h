@@ -65,7 +65,8 @@ PlanSink*& plan_sink();   // thread-local; null outside kn_spmm_plan
         }                                                                                                        \
     } while (0)
 
-enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2 };
+enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2, KIND_CHAIN = 3 };
+struct ChainDev;   // kn_chain.hip
 
 // Order-preserving CSR resident in HBM.
 struct CsrDev {
@@ -155,6 +156,8 @@ struct kn_operator {
         hipEvent_t done = nullptr;
     };
     std::vector<Retired> dense_ws_retired;
+    // a whole key-net of CSR operators as one launch (kn_chain.hip)
+    kn::ChainDev* chain = nullptr;
 };
 
 namespace kn {
@@ -172,6 +175,9 @@ int linear_to_affine(const float* y, int64_t ldy, int64_t n, int64_t d, float* o
 // a global breadth-first sweep.  Columns referenced by more than `max_degree` of the rows (a bias column) do not link rows.
 std::vector<int32_t> locality_order(const std::vector<int32_t>& row_ids, const int32_t* indptr, const int32_t* indices, int64_t n_cols, int patch,
                                     int max_degree);
+int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, ChainDev** out, int64_t* rows_out, int64_t* cols_out, int64_t* nnz_out);
+int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, hipStream_t s);
+void chain_free(ChainDev* c);
 void csr_free(CsrDev& c);
 void convtaps_free(ConvTapsDev& c);
 

@@ -142,6 +142,10 @@ class KeyedModel(object):
         if overlap is None:
             overlap = (img_cipher.is_cuda and img_cipher.dtype == torch.float32 and img_cipher.dim() == 2 and img_cipher.shape[0] >= 256 and
                        img_cipher.shape[0] % 256 == 0 and img_cipher.t().is_contiguous() and not torch.cuda.is_current_stream_capturing())
+        if not forced and img_cipher.is_cuda and img_cipher.dim() == 2:
+            chain = self._chain_op(img_cipher.device)
+            if chain is not None:
+                return self._forward_chain(img_cipher, chain)
         if overlap:
             plan = self._overlap_plan(img_cipher.device, img_cipher.shape[0], force=forced)
             if plan is not None and img_cipher.is_cuda and img_cipher.dtype == torch.float32 and img_cipher.t().is_contiguous():
@@ -161,6 +165,63 @@ class KeyedModel(object):
             else:
                 raise ValueError('unsupported module in a key-net: %s' % str(type(c)))
         return y
+
+    # -- whole-net kernel: every operator of a small untiled key-net in ONE launch, activations in LDS (csrc/kn_chain.hip) --------
+    CHAIN_LDS_BYTES = 160 * 1024
+    CHAIN_MAX_OPS = 12
+
+    def _chain_op(self, device):
+        """kn_chain_create handle for this key-net on `device`, or None when it does not qualify: every layer a keyed layer under the
+        bit-exact contract whose operator is a plain / tiled CSR container, every ReLU fusable into its producer, at most 12 operators,
+        and the activations of four batch columns of any two consecutive layers within the CU's 160 KiB of LDS (LeNet_AvgPool: 92 KB).
+        KN_NO_CHAIN=1 (A/B switch, read per call) selects the launch-per-layer forward instead."""
+        if os.environ.get('KN_NO_CHAIN') == '1':
+            return None
+        children = list(self._keynet.children())
+        sig = tuple((id(c.W), getattr(c, '_exact', True)) if isinstance(c, klayer.KeyedLayer) else None for c in children)
+        cache = self.__dict__.setdefault('_chain_ops', {})
+        hit = cache.get(device.index)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        if torch.cuda.is_current_stream_capturing():
+            return None                  # building the chain allocates: not inside a HIP-graph capture (KeyedModel.capture runs an eager forward first)
+        op = None
+        steps = []
+        i = 0
+        ok = 0 < len(children)
+        while ok and i < len(children):
+            c = children[i]
+            if not isinstance(c, klayer.KeyedLayer) or getattr(c, '_exact', True) is not True or isinstance(c.W, ksp.Conv2dTiledMatrix) or not isinstance(c.W, ksp.SparseMatrix):
+                ok = False
+                break
+            fuse = (i + 1 < len(children)) and isinstance(children[i + 1], nn.ReLU)
+            steps.append((c.W, _capi.KN_FLAG_RELU if (fuse or c.iskeyedrelu()) else 0))
+            i += 2 if fuse else 1
+        if ok and len(steps) <= self.CHAIN_MAX_OPS:
+            feat = [0, 0]
+            for (l, (W, _)) in enumerate(steps):
+                feat[l & 1] = max(feat[l & 1], int(W.shape[1]))
+                feat[(l & 1) ^ 1] = max(feat[(l & 1) ^ 1], int(W.shape[0]))
+            if (feat[0] + feat[1]) * 16 <= self.CHAIN_LDS_BYTES and all(steps[l][0].shape[1] == steps[l - 1][0].shape[0] for l in range(1, len(steps))):
+                with torch.cuda.device(device):
+                    op = _capi.Operator.chain([W._device_op(device) for (W, _) in steps], [f for (_, f) in steps])
+        cache[device.index] = (sig, op)
+        return op
+
+    def _forward_chain(self, x, chain):
+        """[N, D0+1] -> [N, classes+1] through the whole-net kernel; stream-ordered on torch's current HIP stream."""
+        (rows, cols) = chain.shape()
+        assert x.shape[1] == cols, 'Non-conformal shape for the key-net input: %s' % str(tuple(x.shape))
+        xt = x.detach().t()
+        if xt.dtype != torch.float32:
+            xt = xt.float()
+        if not xt.is_contiguous():
+            xt = xt.contiguous()
+        n = xt.shape[1]
+        y = torch.empty((rows, n), dtype=torch.float32, device=xt.device)
+        with torch.cuda.device(xt.device):
+            chain.spmm(xt.data_ptr(), n, n, y.data_ptr(), n, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        return y.t()
 
     # -- overlapped forward: two half-batch column windows on two HIP streams, one kernel apart ---------------------------------
     OVERLAP_MIN_MACS = 2e11      # below this much work per forward the launches are too short for the overlap to pay (LeNet: launch-bound)
@@ -248,6 +309,7 @@ class KeyedModel(object):
     def release_workspace(self):
         """Drop the activation workspaces and side streams of the overlapped forward (two ping-pong blocks per batch size)."""
         self.__dict__.pop('_overlap_plans', None)
+        self.__dict__.pop('_chain_ops', None)
 
     def _forward_overlapped(self, x, plan):
         """x: [N, D0+1] whose transpose is a contiguous feature-major block.  Layers ping-pong between two flat workspaces with the
@@ -309,6 +371,7 @@ class KeyedModel(object):
                 c._exact = c._exact_built if flag is None else klayer._contract(flag, True)
                 c.__dict__.pop('_contract_record', None)
         self.__dict__.pop('_overlap_plans', None)                  # the launch lists depend on the layers' contracts
+        self.__dict__.pop('_chain_ops', None)
         return self
 
     def contract_report(self):

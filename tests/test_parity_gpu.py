@@ -744,6 +744,84 @@ def test_hip_graph_capture_with_dense_linear():
         assert np.allclose(eager[:, :-1], net(x).reshape(256, -1).numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize('n_vecs', [1, 3, 4, 10, 64, 1027])
+def test_whole_net_kernel_vs_oracle_random(n_vecs):
+    """kn_chain_create / the whole-net kernel on random non-canonical operators that exercise every layout case: rows of unequal length
+    inside one wavefront slice, empty rows, duplicate columns, groups of rows sharing one unsorted column sequence (shared column copy),
+    unrelated rows (per-lane columns), thin layers (1, 2 and 4 batch columns per lane), ReLU on and off, ragged batches -- bit-equal to
+    the CPU oracle applied operator by operator, and to the launch-per-layer kernels."""
+    rng = np.random.RandomState(100 + n_vecs)
+
+    def rand_csr(rows, cols, kind):
+        (ip, ix, dt) = ([0], [], [])
+        shared = None
+        for r in range(rows):
+            if kind == 'grouped':
+                if r % 7 == 0:
+                    shared = rng.randint(0, cols, size=rng.randint(1, 40))
+                c = shared
+            elif kind == 'dense':
+                if shared is None:
+                    shared = rng.permutation(cols)
+                c = shared if r % 11 else shared[:-1]                   # one row in eleven lost an entry: its own pattern
+            else:
+                c = rng.randint(0, cols, size=(0 if r % 13 == 5 else rng.randint(1, 14)))
+            ix.extend(int(v) for v in c)
+            dt.extend(rng.randn(len(c)).astype(np.float32))
+            ip.append(len(ix))
+        return (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+    shapes = [(301, 97, 'grouped', 1), (150, 301, 'loose', 0), (70, 150, 'dense', 1), (33, 70, 'dense', 1), (9, 33, 'dense', 0)]
+    ops = []
+    mats = []
+    for (r, c, kind, relu) in shapes:
+        (ip, ix, dt) = rand_csr(r, c, kind)
+        mats.append(((r, c), ip, ix, dt, relu))
+        ops.append(_capi.Operator.csr((r, c), ip, ix, dt))
+    chain = _capi.Operator.chain(ops, [m[4] for m in mats])
+    assert chain.shape() == (9, 97) and 'chain_kernel' in chain.plan(n_vecs)
+    X = rng.randn(97, n_vecs).astype(np.float32)
+    ld = n_vecs + 5                                                         # a column window of a wider block, unaligned
+    xd = torch.zeros((97, ld), device=dev())
+    xd[:, :n_vecs] = torch.as_tensor(X).to(dev())
+    yd = torch.full((9, ld), 7.0, device=dev())
+    chain.spmm(xd.data_ptr(), ld, n_vecs, yd.data_ptr(), ld, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+    ref = X
+    per = torch.as_tensor(X).to(dev())
+    for ((shape, ip, ix, dt, relu), op) in zip(mats, ops):
+        ref = oracle.csr_matvecs(shape, ip, ix, dt, ref)
+        if relu:
+            ref = np.maximum(ref, 0)
+        nxt = torch.empty((shape[0], n_vecs), device=dev())
+        op.spmm(per.data_ptr(), n_vecs, n_vecs, nxt.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT | (_capi.KN_FLAG_RELU if relu else 0), torch.cuda.current_stream().cuda_stream)
+        per = nxt
+    got = yd.cpu().numpy()
+    assert np.array_equal(got[:, :n_vecs], ref)
+    assert np.array_equal(got[:, n_vecs:], np.full((9, 5), 7.0, np.float32))        # nothing written beyond the batch window
+    assert np.array_equal(per.cpu().numpy(), ref)
+
+
+def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
+    """LeNet_AvgPool (BASELINE configs[0]-[1]) takes the whole-net kernel by default; KN_NO_CHAIN=1 selects the launch-per-layer forward;
+    both equal the reference's vectors bit for bit, for the golden batch, a ragged one and 1024 images."""
+    z = golden('lenet_perm.npz')
+    knet = kio.keynet_from_arrays(z)
+    xc = torch.as_tensor(z['x_cipher']).to(dev())
+    chain = knet._chain_op(xc.device)
+    assert chain is not None and chain.shape() == (11, 785)
+    last = 'Y.%s' % [str(n) for n in z['layer_names']][-1]
+    assert np.array_equal(knet.forward_linear(xc).cpu().numpy(), z[last])
+    assert np.array_equal(knet.forward_linear(xc[:5]).cpu().numpy(), z[last][:5])
+    big = torch.cat([xc] * 128, dim=0)
+    yb = knet.forward_linear(big)
+    monkeypatch.setenv('KN_NO_CHAIN', '1')
+    assert knet._chain_op(xc.device) is None
+    assert torch.equal(yb, knet.forward_linear(big))
+    assert np.array_equal(knet.forward_linear(xc).cpu().numpy(), z[last])
+    monkeypatch.delenv('KN_NO_CHAIN')
+    # a tiled key-net (matrix-core conv layers) and a key-net too wide for LDS do not qualify
+    assert kio.keynet_from_arrays(golden('mini_tiled_permutation.npz'))._chain_op(xc.device) is None
+
+
 def test_output_encryption_roundtrip(golden):
     """do_output_encryption=True (keynet/system.py:48-50,135-137; the reference's decrypt call is broken, the intent is one more
     torchdot with the embedding key): logits come back decrypted and equal the plain net."""
