@@ -202,7 +202,7 @@ class KeyedModel(object):
             for (l, (W, _)) in enumerate(steps):
                 feat[l & 1] = max(feat[l & 1], int(W.shape[1]))
                 feat[(l & 1) ^ 1] = max(feat[(l & 1) ^ 1], int(W.shape[0]))
-            if (feat[0] + feat[1]) * 16 <= self.CHAIN_LDS_BYTES and all(steps[l][0].shape[1] == steps[l - 1][0].shape[0] for l in range(1, len(steps))):
+            if (feat[0] + feat[1] + 1) * 16 <= self.CHAIN_LDS_BYTES and all(steps[l][0].shape[1] == steps[l - 1][0].shape[0] for l in range(1, len(steps))):
                 with torch.cuda.device(device):
                     op = _capi.Operator.chain([W._device_op(device) for (W, _) in steps], [f for (_, f) in steps])
         cache[device.index] = (sig, op)
