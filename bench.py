@@ -781,6 +781,26 @@ def main():
                 (r['name'], r['kind'], r['rows'], r['nnz'], r['ms'], r['flops'] / r['ms'] / 1e9, r['bytes'] / r['ms'] / 1e6))
         roof = roofline_of(table, args.workload, batch, mode)
         total_bytes = sum(r['bytes'] for r in table)
+        chain = knet._chain_op(dev) if hasattr(knet, '_chain_op') else None
+        if chain is not None:
+            # the forward of this key-net is ONE launch of the whole-net kernel (csrc/kn_chain.hip): that launch is the dominant kernel.
+            # Algorithmic bytes: every operator once (8 B per stored non-zero) + activations in and out of every layer.
+            for _ in range(5):
+                knet.forward_linear(x_cipher)
+            (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                knet.forward_linear(x_cipher)
+            e1.record()
+            torch.cuda.synchronize()
+            ch_ms = e0.elapsed_time(e1) / 50
+            ach = total_bytes / ch_ms / 1e6
+            roof = dict(bound='hbm', kernel=chain.plan(batch), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                        algorithmic_bytes=total_bytes, algorithmic_macs=float(sum(r['nnz'] for r in table)) * batch, ms_per_forward=ch_ms,
+                        t_mac_per_s=float(sum(r['nnz'] for r in table)) * batch / ch_ms / 1e9,
+                        launch_per_layer_ms={r['name']: round(r['ms'], 4) for r in table},
+                        note='one launch for the whole key-net, activations in LDS; launch_per_layer_ms = the seven separate kernels it replaces (KN_NO_CHAIN=1)')
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
             'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
