@@ -657,6 +657,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the LeNet / AllConvNet legs of the default run')
     ap.add_argument('--graph-leg', action='store_true', help='additionally time the forward replayed from a captured HIP graph (reported as `graph`)')
     ap.add_argument('--cpu-budget', type=float, default=24.0, help='seconds of scipy work for the CPU baseline sample')
+    ap.add_argument('--trace-layers', default=None, metavar='FILE', help='profiling aid (run under rocprofv3 --kernel-trace): after the first forward, launch every layer '
+                                                                          '8 times back to back with a marker kernel between layers, write the layer list (name, kind, flops, bytes) to FILE and exit; '
+                                                                          'tools/trace_layers.py joins it with the kernel trace into a per-layer table')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -725,6 +728,23 @@ def main():
     y = knet.forward_linear(x_cipher)                            # first call uploads the operators
     torch.cuda.synchronize()
     log('[bench rank %d] operators resident + first forward in %.1f s; logits %s' % (rank, time.time() - t0, tuple(y.shape)))
+
+    if args.trace_layers:
+        table = layer_table(knet, batch)
+        marker = torch.zeros(1031, device=dev)
+        yin = x_cipher
+        for row in table:
+            c = row['layer']
+            marker.add_(1.0)                                   # one torch elementwise kernel = the separator tools/trace_layers.py splits on
+            for _ in range(8):
+                out = c.forward(yin, fuse_relu=row['fuse'])
+            yin = out
+        marker.add_(1.0)
+        torch.cuda.synchronize()
+        json.dump({'workload': desc, 'batch': batch, 'launches_per_layer': 8, 'csrc_sha256': kernel_sources_sha(),
+                   'layers': [{k: r[k] for k in ('name', 'kind', 'rows', 'cols', 'nnz', 'flops', 'bytes', 'plan')} for r in table]}, open(args.trace_layers, 'w'), indent=1)
+        log('[bench] layer list written to %s' % args.trace_layers)
+        return
 
     replay = knet.capture(x_cipher) if args.graph else None
 
