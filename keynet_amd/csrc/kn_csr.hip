@@ -889,15 +889,30 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     // wavefronts; operators with few rows (a 121-row Linear, a dense Linear at n_vecs = 256) fall through to thinner
     // bundles / narrower vectors -- the walk over a row's columns is serial by contract, so parallelism can only come
     // from rows and batch columns.
-    if (A.n_big > 0 || A.n_long > 0) {
+    // Long loose rows (>= 1024 stored entries: a row of a keyed Linear, or of a wide permutation-keyed conv, whose pattern lost an entry to
+    // an exact zero).  The deep-queue role of the big-group launch (one wave per row and 64 batch columns, 4 bytes per lane) exists for
+    // NARROW batches, where such a row would otherwise be walked by a single wave; with a wide batch there are enough (row, 256-column
+    // tile) pairs to fill the chip with the plain row kernel at 16 bytes per lane (AllConvNet conv5 at 4 096 images: 752 such rows took
+    // 1.80 ms in the deep-queue role -- 15 % of the layer -- against ~0.2 ms this way).
+    const bool long_as_rows = A.n_long > 0 && (n_vecs % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0) &&
+                              A.n_long * ((n_vecs + 255) / 256) >= 1024;
+    const int64_t n_long_deep = long_as_rows ? 0 : A.n_long;
+    if (long_as_rows) {
+        const int64_t n_ct4 = (n_vecs + 255) / 256;
+        const int64_t n_rb = (A.n_long + WAVES - 1) / WAVES;
+        KN_LAUNCH("csr_rows_kernel<vec=4> (long rows)", csr_rows_kernel<4>, dim3((unsigned)(((n_ct4 * n_rb + 7) / 8) * 8)), dim3(256), 0, s, A.long_rows, A.n_long, A.indptr, A.indices,
+                  A.data, x, ldx, y, ldy, n_vecs, relu, n_rb);
+        KN_HIP(hipGetLastError());
+    }
+    if (A.n_big > 0 || n_long_deep > 0) {
         const int64_t n_ct = (n_vecs + 63) / 64;
         const int64_t grid_big = ((n_ct * A.n_big + 7) / 8) * 8;
-        const int64_t grid_long = A.n_long * ((n_ct + 3) / 4);
+        const int64_t grid_long = n_long_deep * ((n_ct + 3) / 4);
         KN_LAUNCH("csr_big_group_kernel", csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
-                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, grid_big, A.long_rows, A.n_long, A.indptr, A.indices, A.data);
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, grid_big, A.long_rows, n_long_deep, A.indptr, A.indices, A.data);
         KN_HIP(hipGetLastError());
-        if (A.n_work == 0 && A.n_loose == 0) return KN_OK;
     }
+    if ((A.n_big > 0 || A.n_long > 0) && A.n_work == 0 && A.n_loose == 0) return KN_OK;
     // short loose rows over a batch window that fills only half of a 256-column wave tile: one row per half wavefront
     if (A.n_work == 0 && A.n_loose >= 4096 && A.nnz <= 32 * A.n_loose && n_vecs % 128 == 0 && (n_vecs / 128) % 2 == 1 && (ldx % 4 == 0) && (ldy % 4 == 0) &&
         (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0)) {
