@@ -296,7 +296,8 @@ def layer_table(knet, batch):
     for (i, (name, c)) in enumerate(children):
         if not isinstance(c, KeyedLayer):
             continue
-        exact = getattr(c, '_exact', True) is not False
+        contract = getattr(c, '_exact', True)
+        exact = contract is True or contract == 'auto'
         if type(c.W) is ksp.SparseMatrix and not exact and c.W._dense_device_op() is not None:
             kind = 'dense'                     # keyed nn.Linear on the split-K MFMA path (tolerance mode)
             (r, cdim) = c.W.shape
@@ -314,9 +315,12 @@ def layer_table(knet, batch):
             nnz_exp = op.nnz_expanded()
             kind = 'csr'
             wbytes = 8 * nnz_exp               # (col,val) per non-zero
-        flags = (1 if ((i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)) or c.iskeyedrelu() else 0) | (2 if (exact and kind != 'dense') else 0)
+        flags = (1 if ((i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)) or c.iskeyedrelu() else 0) | (2 if (exact and kind != 'dense') else 0) | (4 if contract == 'bf16x3' else 0)
+        plan = (c.W._dense_device_op() if kind == 'dense' else op).plan(batch, flags)
+        if 'bf16x3' in plan:
+            kind = 'convbf16x3'
         rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch,
-                         bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c, plan=(c.W._dense_device_op() if kind == 'dense' else op).plan(batch, flags),
+                         bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c, plan=plan,
                          fuse=(i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)))
     return rows
 
@@ -388,6 +392,12 @@ def roofline_of(table, workload, batch, mode):
     by_ms = sorted(kinds.items(), key=lambda kv: -sum(r['ms'] for r in kv[1]))
     (kind, dom) = by_ms[0]
     dom_ms = sum(r['ms'] for r in dom)
+    if kind == 'convbf16x3':
+        peak = PEAK_F32_MFMA_TFLOPS * 16.0 / 6.0
+        ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
+        return dict(bound='mfma', kernel='convtaps_bf16x3_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=peak, unit='TFLOP/s (f32-equivalent)', frac=ach / peak, traffic=None,
+                    algorithmic_flops=sum(r['flops'] for r in dom), algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
+                    note='peak = six v_mfma_f32_32x32x16_bf16 per f32 product block at 16x the f32-input MFMA rate: 157.3 * 16 / 6')
     if kind in ('convtaps', 'dense'):
         dom = kinds.get('convtaps', []) or dom
         dom_ms = sum(r['ms'] for r in dom)
@@ -893,6 +903,32 @@ def main():
                             'mode': 'KeyedModel.exact_mode(True): every layer in the reference\'s accumulation order and rounding (no FMA, no MFMA)',
                             'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
                             'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
+            knet.exact_mode(None)
+            # EXPERIMENTAL (never the headline): the same key-net with the bf16x3 kernel as the first candidate of the float-key contract.
+            # Each conv layer keeps it only if its result, measured against the order-preserving kernel on the calibration batch, has 4x
+            # headroom under 1e-5 * max(1, |y|).
+            try:
+                knet.exact_mode('auto-bf16x3')
+                knet.forward_linear(x_cipher)
+                torch.cuda.synchronize()
+                (el_b, out_b) = timed(1, args.steps)
+                err_b = float((out_b[:n_gate].contiguous().cpu() - y_plain).abs().max())
+                del out_b
+                table_b = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
+                rep_b = knet.contract_report()
+                res['experimental'] = {'bf16x3': {
+                    'what': 'KeyedModel.exact_mode(\'auto-bf16x3\'): f32 products emulated on the bf16 matrix pipe (three-way split of both operands, six of the nine '
+                            'cross products, f32 accumulate: KN_FLAG_BF16X3) in every conv layer whose calibration measured 4x headroom under the 1e-5 tolerance',
+                    'dtype': 'f32 emulated (3 x bf16 split, 6 of 9 cross products, f32 accumulate)',
+                    'images_per_s': batch * args.steps / el_b, 'ms_per_step': 1e3 * el_b / args.steps, 'steps': args.steps,
+                    'parity': {'vs_source_network_max_abs_err': err_b, 'ok': bool(err_b <= 1e-3),
+                               'per_layer_vs_order_preserving_kernel': {r['name']: {k: r['calibration'].get(k) for k in ('decided', 'measured_bf16x3_vs_exact', 'measured_mfma_vs_exact', 'tol')}
+                                                                        for r in rep_b['layers'] if r['calibration'] is not None and 'tol' in r['calibration']}},
+                    'layers_on_bf16x3': [r['name'] for r in rep_b['layers'] if r['exact'] == 'bf16x3'],
+                    'roofline': roofline_of(table_b, args.workload, batch, 'tolerance'),
+                    'layers_ms': {r['name']: round(r['ms'], 4) for r in table_b}}}
+            except Exception as e:
+                res['experimental'] = {'bf16x3': {'error': str(e)}}
             knet.exact_mode(None)
             try:
                 res['float_key_parity'] = float_key_parity(dev)

@@ -45,6 +45,12 @@ enum kn_status {
                               MFMA kernel to an order-preserving VALU kernel that walks the factored operator in the
                               expansion's column order (no CSR is materialised: works at VGG-16 scale) */
 
+#define KN_FLAG_BF16X3 4u  /* allow a conv-taps operator to form its f32 products on the bf16 matrix pipe: operands split exactly into three
+                              bf16 parts, six of the nine cross products kept (the dropped ones are <= 2^-23 of a product), f32 accumulate.
+                              ~1 ulp per term away from the f32-MFMA result; never bit-exact; ignored with KN_FLAG_EXACT and by operators /
+                              operands that do not qualify (Cin % 16, Cout > 64, n_vecs % 128).  No reference counterpart: the Python host
+                              sets it only for layers whose calibration measured the result inside the float-key tolerance. */
+
 typedef struct kn_operator* kn_handle_t;   /* opaque keyed operator resident in HBM */
 
 int         kn_abi_version(void);

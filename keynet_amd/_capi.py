@@ -15,6 +15,7 @@ LIBPATH = os.environ.get('KEYNET_HIP_LIB') or os.path.join(_HERE, 'libkeynet_hip
 KN_OK = 0
 KN_FLAG_RELU = 1
 KN_FLAG_EXACT = 2
+KN_FLAG_BF16X3 = 4
 KN_ABI_VERSION = 1
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)

@@ -25,6 +25,7 @@
 #include "kn_internal.h"
 #include <type_traits>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace kn {
@@ -106,6 +107,8 @@ struct ConvArgs {
     int64_t* stamps;          // diagnostic build only (KN_STAMPS): per-workgroup {start, end} of s_memrealtime, XCC id, kind; null otherwise
     const int32_t* sk_desc;   // small-K pipeline: per-pixel descriptors in processing order (ConvTapsDev::sk_desc), or null
     int32_t sk_stride, sk_tab_rows;
+    const uint16_t* tapsB;    // bf16x3 path: taps split into three bf16 planes (ConvTapsDev::tapsB), or null
+    int64_t tapsB_plane;      // bytes between planes
 #ifdef KN_ABLATION
     int32_t abl;           // diagnostic build only (tools/ablate_conv.sh): bit 0 no chunk barrier, 1 no LDS stores, 2 no global loads, 4 no pointer walk, 5 / 6 no tap / activation loads
 #endif
@@ -593,6 +596,221 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
 #ifdef KN_ABLATION
     if (p.stamps && threadIdx.x == 0) p.stamps[4 * (int64_t)blockIdx.x + 1] = (int64_t)__builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ---- f32 products on the bf16 matrix pipe: three-way split, six of nine cross products (KN_FLAG_BF16X3) ---------------------------------
+// An f32 value is the sum of three bf16 values to within 2^-27 of itself (round-to-nearest at each step, residuals exact):
+// x = xh + xm + xl, a = ah + am + al with |xm| <= 2^-9 |x|, |xl| <= 2^-18 |x|.  Their product needs nine bf16 x bf16 terms; the three
+// smallest (am*xl, al*xm, al*xl: <= 2^-26 of the product together, a quarter of one f32 rounding, of either sign) are dropped, the other six are each exact in f32 and are accumulated in f32 by v_mfma_f32_32x32x16_bf16, which runs at 16x
+// the rate of the f32-input MFMA: 6/16 of the matrix time of convtaps_mfma_kernel for a result that differs from it by ~1 ulp per term.
+// This is NOT bit-exact with anything and is only ever selected by the float-key contract (KeyedLayer._calibrate: measured against the
+// order-preserving kernel on the layer's own input, 1e-5 * max(1, |y|) with 4x headroom) or asked for explicitly.
+// Tile 128 x 128, K chunk = 16 channels of one slot = ONE MFMA k-step.  Taps are split once at create time into three bf16 planes laid out
+// [plane][tap][channel chunk][cout][16 k] so that a chunk's 128 x 16 tile is one contiguous 4 KiB piece per plane, already in its LDS
+// image; activations are loaded k-major (8 dwords per thread: one batch column, 8 channels), split in registers (4 VALU per element +
+// packing) and written as 3 x 16 bytes.  LDS rows are 32 bytes (16 k); the two 16-byte halves of a row are swapped on rows with bit 3
+// set, which makes every ds_read_b128 fragment read (lane = row, lanes 0-31 / 32-63 = k half) conflict-free.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+template <bool COEF>
+__global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
+    constexpr int MT = 128, NB = 128, TM = 2, TN = 2, WN = 2;
+    constexpr int PLANE = MT * 32;                   // bytes of one 128 x 16 bf16 tile
+    constexpr int STAGE = 6 * PLANE;                 // A planes 0-2, B planes 0-2
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE + 2 * MAX_FAST_SLOTS * 8 + 2 * (MT + NB) * 4];
+    int64_t* s_da = reinterpret_cast<int64_t*>(lds + 2 * STAGE);
+    int64_t* s_db = s_da + MAX_FAST_SLOTS;
+    float* bias_a = reinterpret_cast<float*>(s_db + MAX_FAST_SLOTS);      // [2][MT]
+    float* bias_b = bias_a + 2 * MT;                                      // [2][NB]
+
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t item = xl * chunk + (blockIdx.x >> 3);
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    int mt, pi, bt;
+    decode_conv_item(p, item, mt, pi, bt);
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
+    const int m0 = mt * MT, b0 = bt * NB;
+    const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
+    const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
+    const int cpk = p.cin_pad / 16;
+    const int n_chunks = n_slots * cpk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // per-slot byte deltas to the next chunk's tiles (channel chunk OUTER, slot INNER, like convtaps_mfma_tile)
+    const int64_t a_chunk = (int64_t)p.cout_pad * 32;                    // one channel chunk of one tap, one plane
+    const int64_t a_tap = (int64_t)cpk * a_chunk;
+    const int64_t b_chunk = (int64_t)16 * p.HiWi * p.ldx * 4;
+    if (tid < n_slots) {
+        const int nxt = (tid + 1 < n_slots) ? tid + 1 : 0;
+        const bool wrap = tid + 1 >= n_slots;
+        s_da[tid] = (int64_t)(p.slot_tap[s_beg + nxt] - p.slot_tap[s_beg + tid]) * a_tap + (wrap ? a_chunk : 0);
+        s_db[tid] = (int64_t)(p.slot_in[s_beg + nxt] - p.slot_in[s_beg + tid]) * p.ldx * 4 + (wrap ? b_chunk : 0);
+    }
+    // this thread's pieces: A = 16 bytes at tile offset tid * 16 of each plane; B = batch column n, channels 8 * kh .. 8 * kh + 7
+    // adjacent lanes hold the two k halves of one batch column: the eight lanes of a ds_write_b128 group then cover four rows x two halves
+    // = 32 distinct banks (writes bank modulo 32; with a wave on one k half, rows n and n + 4 collided: SQ_LDS_BANK_CONFLICT 7.5 % of the
+    // launch), and a wave's global load is still two full 128-byte segments
+    const int bn = tid >> 1, kh = tid & 1;
+    const char* pa = nullptr;
+    const char* pb = nullptr;
+    if (n_slots > 0) {
+        pa = reinterpret_cast<const char*>(p.tapsB) + (int64_t)p.slot_tap[s_beg] * a_tap + (int64_t)m0 * 32 + tid * 16;
+        pb = reinterpret_cast<const char*>(p.X + b0 + bn + ((int64_t)(8 * kh) * p.HiWi + p.slot_in[s_beg]) * p.ldx);
+    }
+    const int64_t plane_b = p.tapsB_plane;                               // bytes between planes
+    const int64_t row_b = (int64_t)p.HiWi * p.ldx * 4;                   // bytes between channels of X
+    const int b_lds = bn * 32 + ((kh ^ ((bn >> 3) & 1)) * 16);           // (the A image is pre-swizzled in memory)
+    __syncthreads();
+    int64_t da = 0, db = 0;
+    int f_slot = 0, st_slot = 0;
+    if (n_slots > 0) {
+        da = s_da[0];
+        db = s_db[0];
+    }
+    u32x4 ra[3];
+    float rb[8];
+    auto gload = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) ra[pl] = *reinterpret_cast<const u32x4*>(pa + pl * plane_b);
+#pragma unroll
+        for (int j = 0; j < 8; j++) rb[j] = *reinterpret_cast<const float*>(pb + j * row_b);
+        pa += da;
+        pb += db;
+        f_slot = __builtin_amdgcn_readfirstlane((f_slot + 1 == n_slots) ? 0 : f_slot + 1);
+        da = s_da[f_slot];
+        db = s_db[f_slot];
+    };
+    // registers -> LDS in pieces that sit between the MFMA groups of a chunk (the matrix pipe must not wait for one lump of ~70 vector
+    // instructions): piece 0 = the three tap planes (plain copies), pieces 1-4 = split of one pair of activations each, piece 5 = the
+    // three activation planes.  Round-to-nearest split, two elements at a time (v_cvt_pk_bf16_f32 packs the pair): h = bf16(x),
+    // r1 = x - h (exact), m = bf16(r1), r2 = r1 - m (exact), l = bf16(r2): x = h + m + l up to 2^-27 |x|, every part signed and unbiased.
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    u32x4 sh, sm, sl;
+    float cf = 1.0f;
+    auto store_taps = [&](const int buf) {
+        char* A = lds + buf * STAGE;
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) *reinterpret_cast<u32x4*>(A + pl * PLANE + tid * 16) = ra[pl];
+        if constexpr (COEF) {
+            cf = p.slot_coef[s_beg + st_slot];
+            st_slot = (st_slot + 1 == n_slots) ? 0 : st_slot + 1;
+        }
+    };
+    auto split_pair = [&](const int jj) {                     // elements 2 jj, 2 jj + 1 (plain scalar arithmetic: packed f32 VALU beside MFMAs is slow)
+        float x0 = rb[2 * jj], x1 = rb[2 * jj + 1];
+        if constexpr (COEF) {
+            x0 = x0 * cf;
+            x1 = x1 * cf;
+        }
+        const unsigned int hp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{x0, x1}, bf16x2));
+        const float r0 = x0 - __builtin_bit_cast(float, hp << 16), r1 = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+        const unsigned int mp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{r0, r1}, bf16x2));
+        const float q0 = r0 - __builtin_bit_cast(float, mp << 16), q1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+        sh[jj] = hp;
+        sm[jj] = mp;
+        sl[jj] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{q0, q1}, bf16x2));
+    };
+    auto store_acts = [&](const int buf) {
+        char* B = lds + buf * STAGE + 3 * PLANE;
+        *reinterpret_cast<u32x4*>(B + 0 * PLANE + b_lds) = sh;
+        *reinterpret_cast<u32x4*>(B + 1 * PLANE + b_lds) = sm;
+        *reinterpret_cast<u32x4*>(B + 2 * PLANE + b_lds) = sl;
+    };
+    auto lstore = [&](const int buf) {
+        store_taps(buf);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) split_pair(jj);
+        store_acts(buf);
+    };
+    if (n_chunks > 0) {
+        gload();
+        lstore(0);
+    }
+    if (n_chunks > 1) gload();
+    if (p.lastcol) {
+        const float* xlast = p.X + p.last_in_row * p.ldx;
+        for (int t = tid; t < MT + NB; t += 256) {
+            if (t < MT) {
+                const int m = m0 + t;
+                bias_a[t] = (m < p.Cout) ? p.lastcol[(int64_t)m * p.HoWo + o] : 0.0f;
+                bias_a[MT + t] = 0.0f;
+            } else {
+                const int n = b0 + (t - MT);
+                bias_b[t - MT] = (n < p.n_vecs) ? xlast[n] : 0.0f;
+                bias_b[NB + (t - MT)] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // fragment addresses: row = wave tile origin + 32 * sub-tile + (lane & 31), k half = lane >> 5 (swapped on rows with bit 3 set)
+    const int lr = lane & 31, lh = lane >> 5;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int r = wm * 64 + i * 32 + lr;
+        a_off[i] = r * 32 + ((lh ^ ((r >> 3) & 1)) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int r = wn * 64 + j * 32 + lr;
+        b_off[j] = 3 * PLANE + r * 32 + ((lh ^ ((r >> 3) & 1)) * 16);
+    }
+    auto chunk_fn = [&](const int q, const int buf) {
+        const char* base = lds + buf * STAGE;
+        bf16x8 af[3][TM], bf[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + a_off[i]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[pl][j] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + b_off[j]);
+        }
+        // six products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); four independent accumulators between dependent MFMAs
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        const bool more = q + 1 < n_chunks;                   // wave-uniform
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+            if (more) {
+                if (t == 0) store_taps(buf ^ 1);
+                if (t >= 1 && t <= 4) split_pair(t - 1);
+                if (t == 5) store_acts(buf ^ 1);
+            }
+            if (t == 5 && q + 2 < n_chunks) gload();
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+    for (int q = 0; q < n_chunks; q++) chunk_fn(q, q & 1);
+
+    // bias column x homogeneous coordinate: one exact f32 MFMA k-step, last (as in convtaps_mfma_tile)
+    if (p.lastcol) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[lh * MT + wm * 64 + i * 32 + lr], bias_b[lh * NB + wn * 64 + j * 32 + lr], acc[i][j], 0, 0, 0);
+    }
+    const int m_first = m0 + wm * 64;
+    constexpr int COLS = TN * 32, LPR = COLS / 4;
+    float* stage = reinterpret_cast<float*>(lds) + wave * (8 * COLS);
+    float* yp = p.Y + ((int64_t)(m_first + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wn * COLS + (lane % LPR) * 4);
+    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu);
 }
 
 // ---- one-shot small-K path -----------------------------------------------------------------------------------------------
@@ -1161,7 +1379,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();
@@ -1276,6 +1494,55 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     else KN_LAUNCH(D("generic", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 0, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
 }
 
+// Can this operator / operand take convtaps_bf16x3_kernel?  (The planes must exist: convtaps_build_bf16 at first use, kn_api.hip.)
+bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy) {
+    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && A.cout_pad % 128 == 0 && A.Cout > 64 && n_vecs > 0 && n_vecs % 128 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
+           ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && A.max_slots <= MAX_FAST_SLOTS && !A.has_dups;
+}
+
+// Three bf16 planes of the taps, laid out as the kernel's LDS image: [plane][tap][channel chunk of 16][cout_pad][16 k], the two 8-k halves of
+// a row swapped on rows (cout) with bit 3 set.  Truncation split: w = h + m + l exactly.
+int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps /* [ntaps][Cout][Cin] */) {
+    if (A.tapsB) return KN_OK;
+    if (A.Cin % 16 != 0 || A.cin_pad != A.Cin || A.cout_pad % 128 != 0) return KN_OK;      // not eligible: nothing to build
+    const int64_t cpk = A.cin_pad / 16;
+    const size_t plane = (size_t)(A.ntaps * cpk * A.cout_pad * 16);
+    std::vector<uint16_t> hb(3 * plane, 0);
+    for (int64_t t = 0; t < A.ntaps; t++)
+        for (int64_t co = 0; co < A.Cout; co++)
+            for (int64_t ci = 0; ci < A.Cin; ci++) {
+                const float w = taps[(size_t)((t * A.Cout + co) * A.Cin + ci)];
+                auto rne = [](float v) -> uint32_t {                       // f32 -> bf16 bits in the upper half, round to nearest even
+                    uint32_t b;
+                    std::memcpy(&b, &v, 4);
+                    if ((b & 0x7f800000u) == 0x7f800000u) return b & 0xffff0000u;   // inf / nan unchanged (taps are finite)
+                    b += 0x7fffu + ((b >> 16) & 1u);
+                    return b & 0xffff0000u;
+                };
+                auto asf = [](uint32_t b) {
+                    float f;
+                    std::memcpy(&f, &b, 4);
+                    return f;
+                };
+                const uint32_t h = rne(w);
+                const float r1 = w - asf(h);
+                const uint32_t m = rne(r1);
+                const float r2 = r1 - asf(m);
+                const uint32_t l = rne(r2);
+                const int64_t k = ci % 16, half = k / 8;
+                const int64_t pos = ((t * cpk + ci / 16) * A.cout_pad + co) * 16 + ((half ^ ((co >> 3) & 1)) * 8) + (k % 8);
+                hb[(size_t)pos] = (uint16_t)(h >> 16);
+                hb[plane + (size_t)pos] = (uint16_t)(m >> 16);
+                hb[2 * plane + (size_t)pos] = (uint16_t)(l >> 16);
+            }
+    uint16_t* d = nullptr;
+    int rc = upload(&d, hb.data(), hb.size());
+    if (rc) return rc;
+    A.tapsB = d;
+    A.tapsB_plane = (int64_t)plane * 2;
+    return KN_OK;
+}
+
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
                   uint32_t flags, hipStream_t s) {
     (void)rows;
@@ -1342,6 +1609,23 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.max_slots = A.max_slots;
     a.ntaps = (int32_t)A.ntaps;
     a.last_in_row = A.Cin * A.Hin * A.Win;
+    a.tapsB = A.tapsB;
+    a.tapsB_plane = A.tapsB_plane;
+    if ((flags & KN_FLAG_BF16X3) && convtaps_bf16x3_ok(A, x, ldx, n_vecs, y, ldy)) {
+        a.n_mt = (int32_t)(A.cout_pad / 128);
+        a.n_bt = (int32_t)(n_vecs / 128);
+        const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
+        const int64_t grid = 8 * ((items + 7) / 8);
+        if (A.unit_coef) KN_LAUNCH("convtaps_bf16x3_kernel<128x128, 3-way bf16 split, 6 products>", (convtaps_bf16x3_kernel<false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else KN_LAUNCH("convtaps_bf16x3_kernel<128x128, 3-way bf16 split, 6 products>+coef", (convtaps_bf16x3_kernel<true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        if (A.has_last) {
+            const int64_t out_last = A.Cout * A.Hout * A.Wout;
+            KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
+                      x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+        }
+        KN_HIP(hipGetLastError());
+        return KN_OK;
+    }
     const bool big_m = A.cout_pad % 128 == 0 && A.Cout > 64;
     const bool k16 = A.cin_pad % 16 == 0;
     static const bool no_smallk = getenv("KN_NO_SMALLK") != nullptr;

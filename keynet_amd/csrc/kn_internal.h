@@ -121,6 +121,9 @@ struct ConvTapsDev {
     // processing order, or null when the operator is not eligible
     int32_t* sk_desc = nullptr;
     int64_t sk_stride = 0, sk_tab_rows = 0;
+    // bf16x3 path (kn_conv.hip, convtaps_bf16x3_kernel): the taps as three bf16 planes, built at the first kn_spmm that asks for them
+    uint16_t* tapsB = nullptr;
+    int64_t tapsB_plane = 0;
 };
 
 }  // namespace kn
@@ -178,6 +181,8 @@ std::vector<int32_t> locality_order(const std::vector<int32_t>& row_ids, const i
 int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, ChainDev** out, int64_t* rows_out, int64_t* cols_out, int64_t* nnz_out);
 int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, hipStream_t s);
 void chain_free(ChainDev* c);
+int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps);
+bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy);
 void csr_free(CsrDev& c);
 void convtaps_free(ConvTapsDev& c);
 

@@ -14,6 +14,7 @@ from .globals import verbose
 from . import sparse as ksp
 from . import direct as kdirect
 from .sparse import SparseMatrix, sparse_toeplitz_conv2d, sparse_toeplitz_avgpool2d
+from . import _capi
 from .torch import affine_to_linear_matrix
 
 
@@ -73,8 +74,8 @@ def _contract(exact, bit_exact_default):
     if exact is None:
         return True if bit_exact_default else 'auto'
     if isinstance(exact, str):
-        assert exact == 'auto', "exact must be True, False, None or 'auto'"
-        return 'auto'
+        assert exact in ('auto', 'bf16x3'), "exact must be True, False, None, 'auto' or 'bf16x3'"
+        return exact
     return bool(exact)
 
 
@@ -177,6 +178,21 @@ class KeyedLayer(nn.Module):
             self._exact = True
             self._contract_record = rec
             return W.torchdot(xt, relu=relu, exact=True).t()
+        # opt-in first candidate (KeyedModel.exact_mode('auto-bf16x3')): f32 products emulated on the bf16 matrix pipe (KN_FLAG_BF16X3).
+        # It is taken only with 4x headroom under the tolerance on this batch; otherwise the decision below is made as usual.
+        if getattr(self, '_allow_bf16x3', False) and isinstance(W, ksp.Conv2dTiledMatrix):
+            cols = min(int(xt.shape[1]), 256)
+            xs = xt[:, :cols] if cols % 128 == 0 else None
+            if xs is not None and 'bf16x3' in W._device_op(dev).plan(cols, _capi.KN_FLAG_BF16X3 | (_capi.KN_FLAG_RELU if relu else 0)):
+                yb = W.torchdot(xs, relu=relu, exact='bf16x3')
+                ye = W.torchdot(xs, relu=relu, exact=True)
+                (meas, ymax_b) = (float((ye - yb).abs().max()), float(ye.abs().max()))
+                tol_b = FLOAT_KEY_TOL * max(1.0, ymax_b)
+                del yb, ye
+                if meas <= 0.25 * tol_b:
+                    self._exact = 'bf16x3'
+                    self._contract_record = dict(layer=self._repr, decided='bf16x3', measured_bf16x3_vs_exact=meas, tol=tol_b, max_abs_y=ymax_b, measured_on_columns=cols)
+                    return W.torchdot(xt, relu=relu, exact='bf16x3').t()
         y = W.torchdot(xt, relu=relu, exact=False)
         asum = getattr(self, '_abs_rowsum', None)
         if asum is None:

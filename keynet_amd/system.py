@@ -252,7 +252,8 @@ class KeyedModel(object):
                     steps = None                                   # a ReLU that could not be fused into a producer: simple path
                     break
                 fuse = (i + 1 < len(children)) and isinstance(children[i + 1], nn.ReLU)
-                exact = getattr(c, '_exact', True) is not False
+                contract = getattr(c, '_exact', True)
+                exact = contract is True or contract == 'auto'
                 W = c.W
                 relu = fuse or c.iskeyedrelu()
                 if type(W) is ksp.SparseMatrix and not exact and W._dense_device_op(device) is not None:
@@ -261,9 +262,11 @@ class KeyedModel(object):
                     (op, ex) = (W._device_op(device), exact)
                     # order-preserving conv kernels work on 256-column tiles; MFMA tiles are 128 (Cout > 64) or 256 columns wide
                     ok = (half % 256 == 0) if exact else (half % (128 if W._outshape[0] > 64 else 256) == 0)
+                    if contract == 'bf16x3' and 'bf16x3' in op.plan(batch, _capi.KN_FLAG_BF16X3) and 'bf16x3' not in op.plan(half, _capi.KN_FLAG_BF16X3):
+                        ok = False     # (cannot happen with 128-column tiles; kept as a guard: a half batch must keep the kernel family)
                 else:
                     (op, ex, ok) = (W._device_op(device), True, True)
-                flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if ex else 0)
+                flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if ex else 0) | (_capi.KN_FLAG_BF16X3 if (contract == 'bf16x3' and not ex) else 0)
                 steps.append((op, int(W.shape[0]), int(W.shape[1]), flags, ok, 'Linear' in c._layertype, isinstance(W, ksp.Conv2dTiledMatrix)))
                 i += 2 if fuse else 1
             if steps:
@@ -363,12 +366,19 @@ class KeyedModel(object):
         order and mul-then-add rounding in every layer (bit-exact with scipy: order-preserving kernels, no MFMA); False =
         matrix cores wherever an operator has such a path (conv-taps, large dense operators), whatever the error; 'auto' = per layer,
         decided at the next forward so that the float-key tolerance 1e-5 holds against the reference's arithmetic (KeyedLayer._calibrate;
-        see contract_report()); None = back to the per-layer setting the key-net was built with (tiled key-nets: 'auto').  Returns self."""
+        see contract_report()); 'auto-bf16x3' = like 'auto', but a conv layer first tries the kernel that emulates f32 products on the bf16
+        matrix pipe (three-way split, six of nine cross products: KN_FLAG_BF16X3) and keeps it when its result, measured against the
+        order-preserving kernel on the calibration batch, has 4x headroom under the tolerance (EXPERIMENTAL, opt-in); 'bf16x3' forces that
+        kernel wherever it applies; None = back to the per-layer setting the key-net was built with (tiled key-nets: 'auto').  Returns self."""
         for c in self._keynet.children():
             if isinstance(c, klayer.KeyedLayer):
                 if not hasattr(c, '_exact_built'):
                     c._exact_built = getattr(c, '_exact_decl', getattr(c, '_exact', True))
-                c._exact = c._exact_built if flag is None else klayer._contract(flag, True)
+                if flag == 'auto-bf16x3':        # 'auto' with the bf16x3 kernel as the first candidate (opt-in: never chosen by default)
+                    (c._exact, c._allow_bf16x3) = ('auto', True)
+                else:
+                    c._exact = c._exact_built if flag is None else klayer._contract(flag, True)
+                    c._allow_bf16x3 = False
                 c.__dict__.pop('_contract_record', None)
         self.__dict__.pop('_overlap_plans', None)                  # the launch lists depend on the layers' contracts
         self.__dict__.pop('_chain_ops', None)
