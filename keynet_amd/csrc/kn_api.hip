@@ -679,7 +679,7 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
         return dense_reduce(ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
     }
     // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
-    if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr && plan_sink() == nullptr) {
+    if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr) {        // (also under kn_spmm_plan: the plan must say what a launch would do)
         std::lock_guard<std::mutex> g(h->lazy_mu);           // bf16 planes of the taps, once (not capturable: like any first use)
         int rc = convtaps_build_bf16(h->ct, h->h_taps);
         if (rc) return rc;
