@@ -744,6 +744,91 @@ def test_hip_graph_capture_with_dense_linear():
         assert np.allclose(eager[:, :-1], net(x).reshape(256, -1).numpy(), atol=1e-4)
 
 
+@pytest.mark.parametrize('cin,cout,hw,n_vecs,gain', [(32, 128, 12, 256, False), (48, 192, 8, 128, True), (16, 256, 10, 384, False), (64, 128, 9, 256, True)])
+def test_convtaps_bf16x3_kernel_vs_oracle(cin, cout, hw, n_vecs, gain):
+    """EXPERIMENTAL path (KN_FLAG_BF16X3): f32 products emulated on the bf16 matrix pipe -- both operands split into three bf16 parts,
+    six of the nine cross products, f32 accumulate.  A permutation (+ photometric gain) keyed 3x3 conv in factored form, every layout case of
+    the kernel (Cout that does not fill the 128-row tile, one to three batch tiles, 1-4 channel chunks, coefficients, bias column, ReLU):
+    within the float-key tolerance of the CPU oracle on the expanded operator (measured: a few 1e-7 on unit-scale data), its homogeneous row
+    exact; operands that do not qualify (batch not a multiple of 128) take the f32 kernel bit for bit."""
+    from keynet_amd import direct as kdirect
+    rng = np.random.RandomState(cin + cout + hw + n_vecs)
+    HW = hw * hw
+    w = (rng.randn(cout, cin, 3, 3) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.randn(cout).astype(np.float32)
+    (pi, po) = (rng.permutation(HW), rng.permutation(HW))
+    (g_out, g_in) = ((rng.rand(HW) + 0.5).astype(np.float32), (rng.rand(HW) + 0.5).astype(np.float32))
+    (eo, ei, et, ec) = ([], [], [], [])
+    for (t, ((i, j), S)) in enumerate(kdirect.shift_matrices((hw, hw), 3, 1)):
+        S = S.tocoo()
+        eo.append(po[S.row]); ei.append(pi[S.col]); et.append(np.full(S.nnz, t)); ec.append((g_out[po[S.row]] / g_in[pi[S.col]]).astype(np.float32))
+    taps = np.stack([w[:, :, i, j] for i in range(3) for j in range(3)])
+    lastcol = np.concatenate((np.repeat(b, HW), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((cin, hw, hw), (cout, hw, hw), taps, np.concatenate(eo).astype(np.int32), np.concatenate(ei).astype(np.int32),
+                                       np.concatenate(et).astype(np.int32), np.concatenate(ec) if gain else None, lastcol)
+    X = np.vstack((rng.randn(cin * HW, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    xd = torch.as_tensor(X).to(dev())
+    M = W.rows_csr()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    scale = float(np.abs(ref).max())
+    assert 'convtaps_bf16x3_kernel' in W._device_op().plan(n_vecs, _capi.KN_FLAG_BF16X3)
+    for relu in (False, True):
+        r = np.maximum(ref, 0) if relu else ref
+        yb = W.torchdot(xd, relu=relu, exact='bf16x3').cpu().numpy()
+        err = float(np.abs(yb - r).max())
+        assert err <= 1e-5 * max(1.0, scale), (err, scale)
+        assert np.array_equal(yb[-1], r[-1])                                     # homogeneous row
+    # not a multiple of 128 columns: the flag is ignored, the f32 MFMA kernel runs
+    n2 = n_vecs - 28
+    assert 'bf16x3' not in W._device_op().plan(n2, _capi.KN_FLAG_BF16X3)
+    x2 = xd[:, :n2].contiguous()
+    assert torch.equal(W.torchdot(x2, exact='bf16x3'), W.torchdot(x2, exact=False))
+    # KN_FLAG_EXACT wins over the flag
+    op = W._device_op()
+    y1 = torch.empty((W.shape[0], n_vecs), device=dev())
+    op.spmm(xd.data_ptr(), n_vecs, n_vecs, y1.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT | _capi.KN_FLAG_BF16X3, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(y1.cpu().numpy(), ref)
+
+
+def test_contract_with_bf16x3_candidate():
+    """KeyedModel.exact_mode('auto-bf16x3') (opt-in): conv layers that qualify try the bf16x3 kernel first and keep it only with 4x headroom under
+    the tolerance on the calibration batch; the default contract never selects it; whatever is selected, every layer stays within 1e-5 of the
+    order-preserving path and the logits equal the source network."""
+    class Net(_Chain):
+        flatten_before = 'fc1'
+
+        def __init__(self):
+            super(Net, self).__init__()
+            self.conv1 = nn.Conv2d(16, 128, 3, padding=1)
+            self.relu1 = nn.ReLU()
+            self.conv2 = nn.Conv2d(128, 128, 3, padding=1)
+            self.relu2 = nn.ReLU()
+            self.pool2 = nn.AvgPool2d(3, stride=2, padding=1)
+            self.fc1 = nn.Linear(128 * 4 * 4, 10)
+    torch.manual_seed(11)
+    net = Net().eval()
+    np.random.seed(11)
+    (sensor, knet) = ksys.TiledPermutationKeynet((16, 8, 8), net, 4)
+    x = torch.randn(256, 16, 8, 8, generator=torch.Generator().manual_seed(3))
+    xc = sensor.fromtensor(x.to(dev())).encrypt().astensor()
+    y_auto = knet.forward_linear(xc)
+    assert all(c._exact in (True, False) for c in knet._keynet.children() if isinstance(c, KeyedLayer))      # default: never bf16x3
+    knet.exact_mode(True)
+    y_exact = knet.forward_linear(xc)
+    knet.exact_mode('auto-bf16x3')
+    y_b = knet.forward_linear(xc)
+    assert knet.conv1._exact == 'bf16x3' and knet.conv2._exact == 'bf16x3', knet.contract_report()
+    rec = knet.conv2._contract_record
+    assert rec['decided'] == 'bf16x3' and rec['measured_bf16x3_vs_exact'] <= 0.25 * rec['tol']
+    scale = max(1.0, float(y_exact.abs().max()))
+    assert float((y_b - y_exact).abs().max()) <= 2e-5 * scale and float((y_auto - y_exact).abs().max()) <= 2e-5 * scale
+    with torch.no_grad():
+        assert np.allclose(y_b[:, :-1].cpu().numpy(), net(x).reshape(256, -1).numpy(), atol=1e-4)
+    assert torch.equal(y_b, knet.forward_linear(xc))                               # decided: repeatable
+    knet.exact_mode(None)
+    assert knet.conv1._exact == 'auto' and not knet.conv1._allow_bf16x3
+
+
 @pytest.mark.parametrize('n_vecs', [1, 3, 4, 10, 64, 1027])
 def test_whole_net_kernel_vs_oracle_random(n_vecs):
     """kn_chain_create / the whole-net kernel on random non-canonical operators that exercise every layout case: rows of unequal length
