@@ -601,24 +601,37 @@ __global__ __launch_bounds__(256, 2) void convtaps_mfma_kernel(ConvArgs p) {
 // ---- f32 products on the bf16 matrix pipe: three-way split, six of nine cross products (KN_FLAG_BF16X3) ---------------------------------
 // An f32 value is the sum of three bf16 values to within 2^-27 of itself (round-to-nearest at each step, residuals exact):
 // x = xh + xm + xl, a = ah + am + al with |xm| <= 2^-9 |x|, |xl| <= 2^-18 |x|.  Their product needs nine bf16 x bf16 terms; the three
-// smallest (am*xl, al*xm, al*xl: <= 2^-26 of the product together, a quarter of one f32 rounding, of either sign) are dropped, the other six are each exact in f32 and are accumulated in f32 by v_mfma_f32_32x32x16_bf16, which runs at 16x
-// the rate of the f32-input MFMA: 6/16 of the matrix time of convtaps_mfma_kernel for a result that differs from it by ~1 ulp per term.
-// This is NOT bit-exact with anything and is only ever selected by the float-key contract (KeyedLayer._calibrate: measured against the
-// order-preserving kernel on the layer's own input, 1e-5 * max(1, |y|) with 4x headroom) or asked for explicitly.
-// Tile 128 x 128, K chunk = 16 channels of one slot = ONE MFMA k-step.  Taps are split once at create time into three bf16 planes laid out
-// [plane][tap][channel chunk][cout][16 k] so that a chunk's 128 x 16 tile is one contiguous 4 KiB piece per plane, already in its LDS
-// image; activations are loaded k-major (8 dwords per thread: one batch column, 8 channels), split in registers (4 VALU per element +
-// packing) and written as 3 x 16 bytes.  LDS rows are 32 bytes (16 k); the two 16-byte halves of a row are swapped on rows with bit 3
-// set, which makes every ds_read_b128 fragment read (lane = row, lanes 0-31 / 32-63 = k half) conflict-free.
+// smallest (am*xl, al*xm, al*xl: <= 2^-26 of the product together, a quarter of one f32 rounding, of either sign) are dropped, the other six
+// are each exact in f32 and are accumulated in f32 by v_mfma_f32_32x32x16_bf16, which runs at 16x the rate of the f32-input MFMA: 6/16 of
+// the matrix time of convtaps_mfma_kernel for a result that differs from it by ~1 ulp per term (measured: 2-3x the f32 kernel's own
+// distance from the order-preserving result).  This is NOT bit-exact with anything and is only ever selected by the float-key contract
+// (KeyedLayer._calibrate: measured against the order-preserving kernel on the layer's own input, 1e-5 * max(1, |y|) with 4x headroom) when
+// the caller opted in, or asked for explicitly.
+// Tile MT x NB (128 x 128, or 64 x 256 for 64-channel layers), four wavefronts of 64 x 64, K chunk = 16 channels of one slot = ONE MFMA
+// k-step.  Taps are split once at create time into three bf16 planes laid out [plane][tap][channel chunk][cout][16 k] so that a chunk's
+// MT x 16 tile is one contiguous piece per plane, already in its LDS image (32-byte rows, the two halves swapped on rows with bit 3 set:
+// conflict-free ds_read_b128 fragments).  Activations arrive as 16-byte row pieces (k-major, the same two or four loads per thread as the
+// f32 kernel: every register-destination load costs the matrix pipe ~29 cycles, eight dword loads per chunk cost a quarter of the launch),
+// are split in registers (v_cvt_pk_bf16_f32) and stored k-major too; the MFMA's k-contiguous B fragments come out of LDS through the
+// hardware transpose read ds_read_b64_tr_b16 (image (b) of the programming guide: 256-byte rows, 16-byte chunks XORed with the row bits).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
-template <bool COEF>
+template <int MT, int NB, int WM, int WN, bool COEF>
 __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
-    constexpr int MT = 128, NB = 128, TM = 2, TN = 2, WN = 2;
-    constexpr int PLANE = MT * 32;                   // bytes of one 128 x 16 bf16 tile
-    constexpr int STAGE = 6 * PLANE;                 // A planes 0-2, B planes 0-2
+    constexpr int TM = 2, TN = 2;
+    static_assert(MT == WM * 64 && NB == WN * 64 && WM * WN == 4, "four wavefronts of 64 x 64");
+    constexpr int A_PLANE = MT * 32;                 // bytes: MT rows x 16 bf16
+    constexpr int B_PLANE = 16 * NB * 2;             // bytes: NB / 128 images of 16 rows x 256 bytes
+    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
+    constexpr int A16 = A_PLANE / 16;                // 16-byte pieces of one tap plane (threads tid < A16 load them)
+    constexpr int TPR = NB / 4;                      // threads per activation row
+    constexpr int RPP = 256 / TPR;                   // rows per load pass
+    constexpr int BL = 16 / RPP;                     // load passes (dwordx4 per thread) per chunk
     __shared__ __attribute__((aligned(16))) char lds[2 * STAGE + 2 * MAX_FAST_SLOTS * 8 + 2 * (MT + NB) * 4];
     int64_t* s_da = reinterpret_cast<int64_t*>(lds + 2 * STAGE);
     int64_t* s_db = s_da + MAX_FAST_SLOTS;
@@ -659,20 +672,24 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
         s_da[tid] = (int64_t)(p.slot_tap[s_beg + nxt] - p.slot_tap[s_beg + tid]) * a_tap + (wrap ? a_chunk : 0);
         s_db[tid] = (int64_t)(p.slot_in[s_beg + nxt] - p.slot_in[s_beg + tid]) * p.ldx * 4 + (wrap ? b_chunk : 0);
     }
-    // this thread's pieces: A = 16 bytes at tile offset tid * 16 of each plane; B = batch column n, channels 8 * kh .. 8 * kh + 7
-    // adjacent lanes hold the two k halves of one batch column: the eight lanes of a ds_write_b128 group then cover four rows x two halves
-    // = 32 distinct banks (writes bank modulo 32; with a wave on one k half, rows n and n + 4 collided: SQ_LDS_BANK_CONFLICT 7.5 % of the
-    // launch), and a wave's global load is still two full 128-byte segments
-    const int bn = tid >> 1, kh = tid & 1;
+    // this thread's pieces: A = 16 bytes at tile offset tid * 16 of each plane (tid < A16); B = channel row r0 (+ RPP per pass), 4 batch columns
+    const int c4 = tid % TPR, r0 = tid / TPR;
     const char* pa = nullptr;
     const char* pb = nullptr;
     if (n_slots > 0) {
-        pa = reinterpret_cast<const char*>(p.tapsB) + (int64_t)p.slot_tap[s_beg] * a_tap + (int64_t)m0 * 32 + tid * 16;
-        pb = reinterpret_cast<const char*>(p.X + b0 + bn + ((int64_t)(8 * kh) * p.HiWi + p.slot_in[s_beg]) * p.ldx);
+        pa = reinterpret_cast<const char*>(p.tapsB) + (int64_t)p.slot_tap[s_beg] * a_tap + (int64_t)m0 * 32 + (tid < A16 ? tid : 0) * 16;
+        pb = reinterpret_cast<const char*>(p.X + b0 + 4 * c4 + ((int64_t)r0 * p.HiWi + p.slot_in[s_beg]) * p.ldx);
     }
-    const int64_t plane_b = p.tapsB_plane;                               // bytes between planes
-    const int64_t row_b = (int64_t)p.HiWi * p.ldx * 4;                   // bytes between channels of X
-    const int b_lds = bn * 32 + ((kh ^ ((bn >> 3) & 1)) * 16);           // (the A image is pre-swizzled in memory)
+    const int64_t plane_b = p.tapsB_plane;                               // bytes between tap planes
+    const int64_t pass_b = (int64_t)RPP * p.HiWi * p.ldx * 4;            // bytes between a thread's activation rows
+    // LDS image of an activation plane: per 128 columns 16 rows of 256 bytes, 16-byte chunk ch of row k at 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3)))
+    auto b_img = [](const int k, const int n) {                          // byte offset of element (k, n), n a multiple of 4
+        const int nn = n & 127, ch = nn >> 3;
+        return (n >> 7) * 4096 + 256 * k + 16 * (ch ^ (((k & 3) << 2) | ((k >> 2) & 3))) + 8 * ((nn >> 2) & 1);
+    };
+    int b_lds[BL];
+#pragma unroll
+    for (int i = 0; i < BL; i++) b_lds[i] = 3 * A_PLANE + b_img(r0 + i * RPP, 4 * c4);
     __syncthreads();
     int64_t da = 0, db = 0;
     int f_slot = 0, st_slot = 0;
@@ -681,63 +698,64 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
         db = s_db[0];
     }
     u32x4 ra[3];
-    float rb[8];
+    f32x4 rb[BL];
     auto gload = [&]() {
+        if (tid < A16) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) ra[pl] = *reinterpret_cast<const u32x4*>(pa + pl * plane_b);
+            for (int pl = 0; pl < 3; pl++) ra[pl] = *reinterpret_cast<const u32x4*>(pa + pl * plane_b);
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j++) rb[j] = *reinterpret_cast<const float*>(pb + j * row_b);
+        for (int i = 0; i < BL; i++) rb[i] = *reinterpret_cast<const f32x4*>(pb + i * pass_b);
         pa += da;
         pb += db;
         f_slot = __builtin_amdgcn_readfirstlane((f_slot + 1 == n_slots) ? 0 : f_slot + 1);
         da = s_da[f_slot];
         db = s_db[f_slot];
     };
-    // registers -> LDS in pieces that sit between the MFMA groups of a chunk (the matrix pipe must not wait for one lump of ~70 vector
-    // instructions): piece 0 = the three tap planes (plain copies), pieces 1-4 = split of one pair of activations each, piece 5 = the
-    // three activation planes.  Round-to-nearest split, two elements at a time (v_cvt_pk_bf16_f32 packs the pair): h = bf16(x),
-    // r1 = x - h (exact), m = bf16(r1), r2 = r1 - m (exact), l = bf16(r2): x = h + m + l up to 2^-27 |x|, every part signed and unbiased.
+    // registers -> LDS in pieces that sit between the MFMA groups of a chunk: the three tap planes (plain copies), then one activation row piece
+    // per call: round-to-nearest split, two elements at a time (v_cvt_pk_bf16_f32 packs the pair): h = bf16(x), r1 = x - h (exact), m = bf16(r1),
+    // r2 = r1 - m (exact), l = bf16(r2): x = h + m + l up to 2^-27 |x|, every part signed and unbiased.  (A truncation split is exact but
+    // one-sided: the dropped cross terms then all carry the sign of the product and add up.)
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    u32x4 sh, sm, sl;
     float cf = 1.0f;
     auto store_taps = [&](const int buf) {
         char* A = lds + buf * STAGE;
+        if (tid < A16) {
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) *reinterpret_cast<u32x4*>(A + pl * PLANE + tid * 16) = ra[pl];
+            for (int pl = 0; pl < 3; pl++) *reinterpret_cast<u32x4*>(A + pl * A_PLANE + tid * 16) = ra[pl];
+        }
         if constexpr (COEF) {
             cf = p.slot_coef[s_beg + st_slot];
             st_slot = (st_slot + 1 == n_slots) ? 0 : st_slot + 1;
         }
     };
-    auto split_pair = [&](const int jj) {                     // elements 2 jj, 2 jj + 1 (plain scalar arithmetic: packed f32 VALU beside MFMAs is slow)
-        float x0 = rb[2 * jj], x1 = rb[2 * jj + 1];
-        if constexpr (COEF) {
-            x0 = x0 * cf;
-            x1 = x1 * cf;
-        }
-        const unsigned int hp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{x0, x1}, bf16x2));
-        const float r0 = x0 - __builtin_bit_cast(float, hp << 16), r1 = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
-        const unsigned int mp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{r0, r1}, bf16x2));
-        const float q0 = r0 - __builtin_bit_cast(float, mp << 16), q1 = r1 - __builtin_bit_cast(float, mp & 0xffff0000u);
-        sh[jj] = hp;
-        sm[jj] = mp;
-        sl[jj] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{q0, q1}, bf16x2));
-    };
-    auto store_acts = [&](const int buf) {
-        char* B = lds + buf * STAGE + 3 * PLANE;
-        *reinterpret_cast<u32x4*>(B + 0 * PLANE + b_lds) = sh;
-        *reinterpret_cast<u32x4*>(B + 1 * PLANE + b_lds) = sm;
-        *reinterpret_cast<u32x4*>(B + 2 * PLANE + b_lds) = sl;
-    };
-    auto lstore = [&](const int buf) {
-        store_taps(buf);
+    auto split_row = [&](const int i, const int buf) {         // (plain scalar arithmetic: packed f32 VALU beside MFMAs is slow)
+        u32x2 sh, sm, sl;
 #pragma unroll
-        for (int jj = 0; jj < 4; jj++) split_pair(jj);
-        store_acts(buf);
+        for (int e = 0; e < 2; e++) {
+            float x0 = rb[i][2 * e], x1 = rb[i][2 * e + 1];
+            if constexpr (COEF) {
+                x0 = x0 * cf;
+                x1 = x1 * cf;
+            }
+            const unsigned int hp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{x0, x1}, bf16x2));
+            const float t0 = x0 - __builtin_bit_cast(float, hp << 16), t1 = x1 - __builtin_bit_cast(float, hp & 0xffff0000u);
+            const unsigned int mp = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{t0, t1}, bf16x2));
+            const float q0 = t0 - __builtin_bit_cast(float, mp << 16), q1 = t1 - __builtin_bit_cast(float, mp & 0xffff0000u);
+            sh[e] = hp;
+            sm[e] = mp;
+            sl[e] = __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2v{q0, q1}, bf16x2));
+        }
+        char* B = lds + buf * STAGE + b_lds[i];
+        *reinterpret_cast<u32x2*>(B + 0 * B_PLANE) = sh;
+        *reinterpret_cast<u32x2*>(B + 1 * B_PLANE) = sm;
+        *reinterpret_cast<u32x2*>(B + 2 * B_PLANE) = sl;
     };
     if (n_chunks > 0) {
         gload();
-        lstore(0);
+        store_taps(0);
+#pragma unroll
+        for (int i = 0; i < BL; i++) split_row(i, 0);
     }
     if (n_chunks > 1) gload();
     if (p.lastcol) {
@@ -755,38 +773,45 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
         }
     }
     __syncthreads();
-    // fragment addresses: row = wave tile origin + 32 * sub-tile + (lane & 31), k half = lane >> 5 (swapped on rows with bit 3 set)
+    // fragment addresses.  A: row = wave tile origin + 32 * sub-tile + (lane & 31), k half = lane >> 5 (swapped on rows with bit 3 set).
+    // B (transpose read, per 16-lane group: lane 4 q + pp supplies row q, columns 4 pp .. 4 pp + 3 of a 4 x 16 block and receives column
+    // lane & 15 of its four rows): block rows 8 * (lane >> 5) + 4 * s + q, block columns tile origin + 16 * ((lane >> 4) & 1) ..
     const int lr = lane & 31, lh = lane >> 5;
-    int a_off[TM], b_off[TN];
+    int a_off[TM], b_off[TN][2];
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int r = wm * 64 + i * 32 + lr;
         a_off[i] = r * 32 + ((lh ^ ((r >> 3) & 1)) * 16);
     }
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int r = wn * 64 + j * 32 + lr;
-        b_off[j] = 3 * PLANE + r * 32 + ((lh ^ ((r >> 3) & 1)) * 16);
-    }
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int sb = 0; sb < 2; sb++)
+            b_off[j][sb] = 3 * A_PLANE + b_img(8 * lh + 4 * sb + ((lane & 15) >> 2), wn * 64 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto chunk_fn = [&](const int q, const int buf) {
         const char* base = lds + buf * STAGE;
         bf16x8 af[3][TM], bf[3][TN];
 #pragma unroll
         for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + a_off[i]);
+            for (int i = 0; i < TM; i++) af[pl][i] = *reinterpret_cast<const bf16x8*>(base + pl * A_PLANE + a_off[i]);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[pl][j] = *reinterpret_cast<const bf16x8*>(base + pl * PLANE + b_off[j]);
+            for (int j = 0; j < TN; j++) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + pl * B_PLANE + b_off[j][0]));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + pl * B_PLANE + b_off[j][1]));
+                bf[pl][j] = __builtin_bit_cast(bf16x8, s16x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w});
+            }
         }
-        // six products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); four independent accumulators between dependent MFMAs
+        // six products, smallest first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); the next chunk's registers -> LDS and the loads of the chunk after
+        // it sit between the groups
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
         const bool more = q + 1 < n_chunks;                   // wave-uniform
 #pragma unroll
         for (int t = 0; t < 6; t++) {
             if (more) {
                 if (t == 0) store_taps(buf ^ 1);
-                if (t >= 1 && t <= 4) split_pair(t - 1);
-                if (t == 5) store_acts(buf ^ 1);
+                if (t >= 1 && t - 1 < BL) split_row(t - 1, buf ^ 1);
             }
             if (t == 5 && q + 2 < n_chunks) gload();
 #pragma unroll
@@ -1496,15 +1521,16 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
 
 // Can this operator / operand take convtaps_bf16x3_kernel?  (The planes must exist: convtaps_build_bf16 at first use, kn_api.hip.)
 bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy) {
-    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && A.cout_pad % 128 == 0 && A.Cout > 64 && n_vecs > 0 && n_vecs % 128 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
-           ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && A.max_slots <= MAX_FAST_SLOTS && !A.has_dups;
+    const bool wide = A.Cout > 64;
+    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && (wide ? (A.cout_pad % 128 == 0) : (A.cout_pad == 64)) && n_vecs > 0 && n_vecs % (wide ? 128 : 256) == 0 &&
+           ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && A.max_slots <= MAX_FAST_SLOTS;
 }
 
 // Three bf16 planes of the taps, laid out as the kernel's LDS image: [plane][tap][channel chunk of 16][cout_pad][16 k], the two 8-k halves of
 // a row swapped on rows (cout) with bit 3 set.  Truncation split: w = h + m + l exactly.
 int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps /* [ntaps][Cout][Cin] */) {
     if (A.tapsB) return KN_OK;
-    if (A.Cin % 16 != 0 || A.cin_pad != A.Cin || A.cout_pad % 128 != 0) return KN_OK;      // not eligible: nothing to build
+    if (A.Cin % 16 != 0 || A.cin_pad != A.Cin || A.cout_pad % 64 != 0) return KN_OK;      // not eligible: nothing to build
     const int64_t cpk = A.cin_pad / 16;
     const size_t plane = (size_t)(A.ntaps * cpk * A.cout_pad * 16);
     std::vector<uint16_t> hb(3 * plane, 0);
@@ -1612,12 +1638,16 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.tapsB = A.tapsB;
     a.tapsB_plane = A.tapsB_plane;
     if ((flags & KN_FLAG_BF16X3) && convtaps_bf16x3_ok(A, x, ldx, n_vecs, y, ldy)) {
-        a.n_mt = (int32_t)(A.cout_pad / 128);
-        a.n_bt = (int32_t)(n_vecs / 128);
+        const bool wide = A.Cout > 64;                          // 128 x 128 tiles; 64-channel layers take 64 x 256
+        a.n_mt = (int32_t)(A.cout_pad / (wide ? 128 : 64));
+        a.n_bt = (int32_t)(n_vecs / (wide ? 128 : 256));
         const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
         const int64_t grid = 8 * ((items + 7) / 8);
-        if (A.unit_coef) KN_LAUNCH("convtaps_bf16x3_kernel<128x128, 3-way bf16 split, 6 products>", (convtaps_bf16x3_kernel<false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else KN_LAUNCH("convtaps_bf16x3_kernel<128x128, 3-way bf16 split, 6 products>+coef", (convtaps_bf16x3_kernel<true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        const std::string d = std::string("convtaps_bf16x3_kernel<") + (wide ? "128x128" : "64x256") + ", 3-way bf16 split, 6 products>" + (A.unit_coef ? "" : "+coef");
+        if (wide && A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else if (wide) KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else if (A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 256, 1, 4, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 256, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
             KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,

@@ -44,7 +44,7 @@ def timeit(f, reps=5):
 
 
 def main():
-  for (cin, cout, hw, B, coef) in [(64, 128, 28, 256, False), (256, 256, 56, 256, False), (512, 512, 28, 256, False), (512, 512, 14, 256, False), (128, 128, 28, 256, True)]:
+  for (cin, cout, hw, B, coef) in [(64, 64, 56, 256, False), (64, 128, 28, 256, False), (256, 256, 56, 256, False), (512, 512, 28, 256, False), (512, 512, 14, 256, False), (128, 128, 28, 256, True)]:
       W = make(cin, cout, hw, coef=coef)
       x = torch.randn(cin * hw * hw + 1, B, device=dev)
       x[-1] = 1.0
