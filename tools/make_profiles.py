@@ -40,7 +40,7 @@ def per_kernel(d, counter):
 def main(R, tag, out='profiles', forwards=None):
     os.makedirs(out, exist_ok=True)
     pre = '%s/%s_vgg16_b256_' % (out, tag)
-    for name in ('bench.json', 'bench_under_rocprof.json', 'kernel_stats.csv', 'layers.log', 'per_layer_pmc.csv', 'traffic.json'):     # only what this script writes
+    for name in ('bench.json', 'bench_under_rocprof.json', 'kernel_stats.csv', 'layers.log', 'per_layer_pmc.csv', 'per_layer_trace.csv', 'traffic.json'):     # only what this script writes
         if os.path.exists(pre + name):
             os.remove(pre + name)
     rows = list(csv.DictReader(open(glob.glob(R + '/stats/runc/*kernel_stats.csv')[0])))
@@ -97,6 +97,8 @@ def main(R, tag, out='profiles', forwards=None):
     json.dump(tr, open(pre + 'traffic.json', 'w'), indent=1)
     if os.path.exists(R + '/per_layer.csv'):
         shutil.copy(R + '/per_layer.csv', pre + 'per_layer_pmc.csv')
+    if os.path.exists(R + '/per_layer_trace.csv'):
+        shutil.copy(R + '/per_layer_trace.csv', pre + 'per_layer_trace.csv')
     b = json.load(open(R + '/bench.json'))
     print('value %.1f img/s, %.2f ms/step, roofline frac %.4f (%.1f TF), conv traffic %.1f GB (fetch %.1f + write %.1f), alg bytes %.1f GB' %
           (b['value'], b['ms_per_step'], b['roofline']['frac'], b['roofline']['achieved'], (tot_f + tot_w) / 1e9, tot_f / 1e9, tot_w / 1e9, b['roofline']['algorithmic_bytes'] / 1e9))
