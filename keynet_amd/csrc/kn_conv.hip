@@ -110,7 +110,7 @@ struct ConvArgs {
     const uint16_t* tapsB;    // bf16x3 path: taps split into three bf16 planes (ConvTapsDev::tapsB), or null
     int64_t tapsB_plane;      // bytes between planes
 #ifdef KN_ABLATION
-    int32_t abl;           // diagnostic build only (tools/ablate_conv.sh): bit 0 no chunk barrier, 1 no LDS stores, 2 no global loads, 4 no pointer walk, 5 / 6 no tap / activation loads
+    int32_t abl;           // diagnostic build only (tools/ablate_conv.sh): bit 0 no chunk barrier, 1 no LDS stores, 2 no global loads, 4 no pointer walk, 5 / 6 no tap / activation loads; bf16x3 kernel (tools/ablate_bf16x3.sh): 8 no split + activation stores, 9 no global loads, 10 no barrier, 11 no tap stores
 #endif
 };
 
@@ -810,16 +810,16 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
 #pragma unroll
         for (int t = 0; t < 6; t++) {
             if (more) {
-                if (t == 0) store_taps(buf ^ 1);
-                if (t >= 1 && t - 1 < BL) split_row(t - 1, buf ^ 1);
+                if (t == 0 && !KN_ABL(p, 11)) store_taps(buf ^ 1);
+                if (t >= 1 && t - 1 < BL && !KN_ABL(p, 8)) split_row(t - 1, buf ^ 1);
             }
-            if (t == 5 && q + 2 < n_chunks) gload();
+            if (t == 5 && q + 2 < n_chunks && !KN_ABL(p, 9)) gload();
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]][i], bf[PB[t]][j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        if (!KN_ABL(p, 10)) __syncthreads();
     };
     for (int q = 0; q < n_chunks; q++) chunk_fn(q, q & 1);
 

@@ -9,4 +9,4 @@ from keynet_amd import build
 print(build.build(out='/tmp/libkeynet_hip_abl.so', defines=('KN_ABLATION',)))
 PY
 export KEYNET_HIP_LIB=/tmp/libkeynet_hip_abl.so
-for A in 0 256 512 1024 2048 768 2816 3840; do echo "== KN_ABL=$A"; KN_ABL=$A python3 tools/bf16x3_bench.py 2>&1 | grep "Cin 512 Cout 512 28x28\|Cin 256" | cut -c 95-200; done
+for A in 0 256 512 1024 2048 2304 2816 3840; do echo "== KN_ABL=$A"; KN_ABL=$A python3 tools/bf16x3_bench.py 2>&1 | grep "Cin 512 Cout 512 28x28\|Cin 256" | cut -c 95-200; done
