@@ -1,0 +1,89 @@
+"""Host-side pieces of the float-key contract and of the round-3 ABI additions that need no GPU: the operator factor of the error screen
+(max_abs_rowsum from the factored form without expanding it), the contract states and their transitions, their persistence in the neutral
+file format, and argument validation of kn_chain_create / kn_spmm_plan."""
+import ctypes
+import os
+import numpy as np
+import pytest
+import torch
+
+from keynet_amd import io as kio
+from keynet_amd import sparse as ksp
+from keynet_amd import system as ksys
+from keynet_amd import _capi
+from keynet_amd.layer import KeyedLayer, _contract
+from nets import MiniNet, load_weights
+
+
+def _mini(golden, factory=ksys.TiledPermutationKeynet, **kw):
+    z = golden('mini_tiled_permutation.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    return factory((2, 16, 16), net, 4, **kw)
+
+
+@pytest.mark.parametrize('direct', [False, True])
+def test_max_abs_rowsum_equals_the_expanded_operator(golden, direct):
+    import warnings
+    z = golden('mini_tiled_orthogonal.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4, direct=direct)
+    n = 0
+    for c in knet._keynet.children():
+        if isinstance(c, KeyedLayer):
+            M = c.W.tocsr() if isinstance(c.W, ksp.TiledMatrix) else c.W._matrix.tocsr()
+            want = float(abs(M).sum(axis=1).max())
+            got = c.W.max_abs_rowsum()
+            # the factored form sums |coef| * |tap| per entry: an upper bound that equals the expansion's row sum unless two entries hit one
+            # (output, input) pixel pair with opposite signs
+            assert got >= want * (1 - 1e-6) and got <= want * 1.5 + 1e-6, (type(c.W).__name__, got, want)
+            n += 1
+    assert n == 5
+
+
+def test_contract_states_and_transitions(golden):
+    assert _contract(None, True) is True and _contract(None, False) == 'auto'
+    assert _contract(True, False) is True and _contract(False, True) is False and _contract('auto', True) == 'auto' and _contract('bf16x3', True) == 'bf16x3'
+    with pytest.raises(AssertionError):
+        _contract('fast', True)
+    (sensor, knet) = _mini(golden)
+    layers = [c for c in knet._keynet.children() if isinstance(c, KeyedLayer)]
+    assert all(c._exact == 'auto' for c in layers)                                 # tiled key-nets: decided at the first forward
+    assert set(knet.contract_report()['undecided']) == {'conv1', 'pool1', 'conv2', 'pool2', 'fc1'}
+    knet.exact_mode(True)
+    assert all(c._exact is True for c in layers)
+    knet.exact_mode(False)
+    assert all(c._exact is False for c in layers)
+    knet.exact_mode('auto-bf16x3')
+    assert all(c._exact == 'auto' and c._allow_bf16x3 for c in layers)
+    knet.exact_mode(None)
+    assert all(c._exact == 'auto' and not c._allow_bf16x3 for c in layers)
+    (_, kp) = ksys.PermutationKeynet((2, 16, 16), load_weights(MiniNet(), golden('mini_tiled_permutation.npz')))
+    assert all(c._exact is True for c in kp._keynet.children() if isinstance(c, KeyedLayer))      # untiled: bit-exact by default
+    (_, kf) = _mini(golden, exact=False)
+    assert all(c._exact is False for c in kf._keynet.children() if isinstance(c, KeyedLayer))
+
+
+def test_contract_survives_the_neutral_file_format(golden, tmp_path):
+    (sensor, knet) = _mini(golden)
+    knet.conv2._exact = False              # pretend calibration decided: the DECLARED contract ('auto') is what is saved
+    f = kio.save_keynet(knet, str(tmp_path / 'k.npz'), sensor=sensor)
+    k2 = kio.load_keynet(f)
+    assert k2.conv2._exact == 'auto' and k2.pool1._exact == 'auto'
+    (_, kx) = _mini(golden, exact=True)
+    k3 = kio.load_keynet(kio.save_keynet(kx, str(tmp_path / 'x.npz')))
+    assert k3.conv1._exact is True
+
+
+def test_chain_and_plan_argument_validation():
+    L = _capi.lib()
+    h = ctypes.c_void_p()
+    assert L.kn_chain_create(0, None, None, ctypes.byref(h)) == 1 and h.value is None          # KN_ERR_INVALID: no operators
+    assert L.kn_chain_create(2, None, None, ctypes.byref(h)) == 1
+    assert L.kn_chain_create(1, (ctypes.c_void_p * 1)(None), None, None) == 1                 # NULL out handle
+    buf = ctypes.create_string_buffer(16)
+    assert L.kn_spmm_plan(None, 4, 4, 4, 0, buf, 16) == 1                                     # NULL handle
+    assert len(L.kn_last_error()) > 0
