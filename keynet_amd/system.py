@@ -120,6 +120,17 @@ class KeyedModel(object):
     def __repr__(self):
         return self._keynet.__repr__()
 
+    def __getstate__(self):
+        """Whole key-nets are pickled by the reference's users (test/test_keynet.py:106, vipy.util.save): device-side state -- the overlapped
+        forward's workspaces and streams, the whole-net kernel's handle -- is dropped and rebuilt on first use (operators: SparseMatrix.__getstate__)."""
+        d = dict(self.__dict__)
+        d.pop('_overlap_plans', None)
+        d.pop('_chain_ops', None)
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+
     def __getattr__(self, attr):
         if attr.startswith('__') or '_keynet' not in self.__dict__:
             raise AttributeError(attr)

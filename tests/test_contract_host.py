@@ -87,3 +87,16 @@ def test_chain_and_plan_argument_validation():
     buf = ctypes.create_string_buffer(16)
     assert L.kn_spmm_plan(None, 4, 4, 4, 0, buf, 16) == 1                                     # NULL handle
     assert len(L.kn_last_error()) > 0
+
+
+def test_keyed_model_pickles_without_device_state(golden):
+    """test/test_keynet.py:106 pickles (sensor, knet); the device caches a forward leaves behind (operator handles, overlap plans, the whole-net
+    kernel) must not travel."""
+    import pickle
+    (sensor, knet) = _mini(golden)
+    knet.__dict__['_overlap_plans'] = {'x': object()}
+    knet.__dict__['_chain_ops'] = {0: ((), ctypes.c_void_p(1))}          # what a forward would have cached (not picklable)
+    (s2, k2) = pickle.loads(pickle.dumps((sensor, knet)))
+    assert '_chain_ops' not in k2.__dict__ and '_overlap_plans' not in k2.__dict__
+    assert k2.conv1._exact == 'auto' and tuple(k2.conv1.W.shape) == tuple(knet.conv1.W.shape) and k2._outshape == knet._outshape
+    assert (s2._encryptkey != sensor._encryptkey).nnz == 0
