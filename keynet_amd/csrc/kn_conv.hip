@@ -621,32 +621,31 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
+template <int MT, int NB>
+struct Bf16x3Lds {
+    static constexpr int A_PLANE = MT * 32;                         // bytes: MT rows x 16 bf16
+    static constexpr int B_PLANE = ((NB + 127) / 128) * 4096;       // bytes: per 128 columns an image of 16 rows x 256 bytes
+    static constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
+    static constexpr int BYTES = 2 * STAGE + 2 * MAX_FAST_SLOTS * 8 + 2 * (MT + NB) * 4;
+};
+
 template <int MT, int NB, int WM, int WN, bool COEF>
-__global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
-    constexpr int TM = 2, TN = 2;
-    static_assert(MT == WM * 64 && NB == WN * 64 && WM * WN == 4, "four wavefronts of 64 x 64");
-    constexpr int A_PLANE = MT * 32;                 // bytes: MT rows x 16 bf16
-    constexpr int B_PLANE = 16 * NB * 2;             // bytes: NB / 128 images of 16 rows x 256 bytes
-    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
+__device__ __forceinline__ void convtaps_bf16x3_tile(const ConvArgs& p, const int o, const int m0, const int b0, char* lds) {
+    constexpr int TM = MT / (WM * 32), TN = NB / (WN * 32);
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && MT == WM * TM * 32 && NB == WN * TN * 32, "four wavefronts of (TM x 32) x (TN x 32)");
+    constexpr int A_PLANE = Bf16x3Lds<MT, NB>::A_PLANE;
+    constexpr int B_PLANE = Bf16x3Lds<MT, NB>::B_PLANE;
+    constexpr int STAGE = Bf16x3Lds<MT, NB>::STAGE;
     constexpr int A16 = A_PLANE / 16;                // 16-byte pieces of one tap plane (threads tid < A16 load them)
     constexpr int TPR = NB / 4;                      // threads per activation row
     constexpr int RPP = 256 / TPR;                   // rows per load pass
     constexpr int BL = 16 / RPP;                     // load passes (dwordx4 per thread) per chunk
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE + 2 * MAX_FAST_SLOTS * 8 + 2 * (MT + NB) * 4];
+    static_assert(RPP >= 1 && BL >= 1 && BL <= 4, "activation tile 16 x NB as whole 16-byte passes");
     int64_t* s_da = reinterpret_cast<int64_t*>(lds + 2 * STAGE);
     int64_t* s_db = s_da + MAX_FAST_SLOTS;
     float* bias_a = reinterpret_cast<float*>(s_db + MAX_FAST_SLOTS);      // [2][MT]
     float* bias_b = bias_a + 2 * MT;                                      // [2][NB]
 
-    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
-    const int64_t chunk = (n_items + 7) >> 3;
-    const int64_t xl = blockIdx.x & 7;
-    const int64_t item = xl * chunk + (blockIdx.x >> 3);
-    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
-    int mt, pi, bt;
-    decode_conv_item(p, item, mt, pi, bt);
-    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
-    const int m0 = mt * MT, b0 = bt * NB;
     const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
     const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
     const int cpk = p.cin_pad / 16;
@@ -780,14 +779,14 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
     int a_off[TM], b_off[TN][2];
 #pragma unroll
     for (int i = 0; i < TM; i++) {
-        const int r = wm * 64 + i * 32 + lr;
+        const int r = wm * (TM * 32) + i * 32 + lr;
         a_off[i] = r * 32 + ((lh ^ ((r >> 3) & 1)) * 16);
     }
 #pragma unroll
     for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int sb = 0; sb < 2; sb++)
-            b_off[j][sb] = 3 * A_PLANE + b_img(8 * lh + 4 * sb + ((lane & 15) >> 2), wn * 64 + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+            b_off[j][sb] = 3 * A_PLANE + b_img(8 * lh + 4 * sb + ((lane & 15) >> 2), wn * (TN * 32) + j * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     auto chunk_fn = [&](const int q, const int buf) {
         const char* base = lds + buf * STAGE;
@@ -829,13 +828,42 @@ __global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[lh * MT + wm * 64 + i * 32 + lr], bias_b[lh * NB + wn * 64 + j * 32 + lr], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bias_a[lh * MT + wm * (TM * 32) + i * 32 + lr], bias_b[lh * NB + wn * (TN * 32) + j * 32 + lr], acc[i][j], 0, 0, 0);
     }
-    const int m_first = m0 + wm * 64;
+    const int m_first = m0 + wm * (TM * 32);
     constexpr int COLS = TN * 32, LPR = COLS / 4;
     float* stage = reinterpret_cast<float*>(lds) + wave * (8 * COLS);
     float* yp = p.Y + ((int64_t)(m_first + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wn * COLS + (lane % LPR) * 4);
     kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu);
+}
+
+// Work items as in convtaps_mfma_kernel (contiguous chunks per XCD, Cout tile fastest).  TAIL: the items of a chunk beyond `tail_main` -- the last,
+// partial round of resident workgroups -- run as four quarter tiles each (conv5_x of VGG-16: 196 items per XCD = 2.04 rounds of 96).
+template <int MT, int NB, int WM, int WN, bool COEF, bool TAIL>
+__global__ __launch_bounds__(256, 2) void convtaps_bf16x3_kernel(ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[Bf16x3Lds<MT, NB>::BYTES];
+    const int64_t n_items = (int64_t)p.n_pix * p.n_bt * p.n_mt;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t xl = blockIdx.x & 7;
+    const int64_t q = blockIdx.x >> 3;
+    int64_t item = xl * chunk + q;
+    int quad = -1;
+    if (TAIL && q >= p.tail_main) {
+        const int64_t t = q - p.tail_main;
+        item = xl * chunk + p.tail_main + (t >> 2);
+        quad = (int)(t & 3);
+    }
+    if (item >= ((xl + 1) * chunk < n_items ? (xl + 1) * chunk : n_items)) return;
+    int mt, pi, bt;
+    decode_conv_item(p, item, mt, pi, bt);
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
+    if constexpr (TAIL) {
+        if (quad >= 0) {
+            convtaps_bf16x3_tile<MT / 2, NB / 2, WM, WN, COEF>(p, o, mt * MT + (quad & 1) * (MT / 2), bt * NB + (quad >> 1) * (NB / 2), lds);
+            return;
+        }
+    }
+    convtaps_bf16x3_tile<MT, NB, WM, WN, COEF>(p, o, mt * MT, bt * NB, lds);
 }
 
 // ---- one-shot small-K path -----------------------------------------------------------------------------------------------
@@ -1522,7 +1550,7 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
 // Can this operator / operand take convtaps_bf16x3_kernel?  (The planes must exist: convtaps_build_bf16 at first use, kn_api.hip.)
 bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy) {
     const bool wide = A.Cout > 64;
-    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && (wide ? (A.cout_pad % 128 == 0) : (A.cout_pad == 64)) && n_vecs > 0 && n_vecs % (wide ? 128 : 256) == 0 &&
+    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && (wide ? (A.cout_pad % 128 == 0) : (A.cout_pad == 64)) && n_vecs > 0 && n_vecs % 128 == 0 &&
            ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && A.max_slots <= MAX_FAST_SLOTS;
 }
 
@@ -1638,16 +1666,33 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.tapsB = A.tapsB;
     a.tapsB_plane = A.tapsB_plane;
     if ((flags & KN_FLAG_BF16X3) && convtaps_bf16x3_ok(A, x, ldx, n_vecs, y, ldy)) {
-        const bool wide = A.Cout > 64;                          // 128 x 128 tiles; 64-channel layers take 64 x 256
+        const bool wide = A.Cout > 64;                          // 128 x 128 tiles; 64-channel layers take 64 x 128 (four wavefronts of 32 x 64)
         a.n_mt = (int32_t)(A.cout_pad / (wide ? 128 : 64));
-        a.n_bt = (int32_t)(n_vecs / (wide ? 128 : 256));
+        a.n_bt = (int32_t)(n_vecs / 128);
         const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
-        const int64_t grid = 8 * ((items + 7) / 8);
-        const std::string d = std::string("convtaps_bf16x3_kernel<") + (wide ? "128x128" : "64x256") + ", 3-way bf16 split, 6 products>" + (A.unit_coef ? "" : "+coef");
-        if (wide && A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else if (wide) KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else if (A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 256, 1, 4, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 256, 1, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        const int64_t chunk = (items + 7) / 8;
+        a.tail_main = (int32_t)chunk;
+        const std::string d = std::string("convtaps_bf16x3_kernel<") + (wide ? "128x128" : "64x128") + ", 3-way bf16 split, 6 products>" + (A.unit_coef ? "" : "+coef");
+        if (wide) {
+            // last partial round of resident workgroups as quarter tiles (same split as launch_conv)
+            static const int64_t slots0 = xcd_slots(convtaps_bf16x3_kernel<128, 128, 2, 2, false, true>);
+            static const int64_t slots1 = xcd_slots(convtaps_bf16x3_kernel<128, 128, 2, 2, true, true>);
+            const int64_t slots = A.unit_coef ? slots0 : slots1;
+            const int64_t rem = slots > 0 ? chunk % slots : 0;
+            static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
+            if (rem > 0 && !no_tail) {
+                a.tail_main = (int32_t)(chunk - rem);
+                const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
+                if (A.unit_coef) KN_LAUNCH(d + " tail_split", (convtaps_bf16x3_kernel<128, 128, 2, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+                else KN_LAUNCH(d + " tail_split", (convtaps_bf16x3_kernel<128, 128, 2, 2, true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+            } else {
+                if (A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, false, false>), dim3((unsigned)(8 * chunk)), dim3(256), 0, s, a);
+                else KN_LAUNCH(d, (convtaps_bf16x3_kernel<128, 128, 2, 2, true, false>), dim3((unsigned)(8 * chunk)), dim3(256), 0, s, a);
+            }
+        } else {
+            if (A.unit_coef) KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 128, 2, 2, false, false>), dim3((unsigned)(8 * chunk)), dim3(256), 0, s, a);
+            else KN_LAUNCH(d, (convtaps_bf16x3_kernel<64, 128, 2, 2, true, false>), dim3((unsigned)(8 * chunk)), dim3(256), 0, s, a);
+        }
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
             KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
