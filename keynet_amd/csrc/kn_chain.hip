@@ -63,7 +63,20 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // The activation buffers are addressed as OFFSETS into this one LDS array, never through pointers: a pointer picked at run time
 // (buf[l & 1]) loses its address space, and the compiler then reads LDS with flat_load -- slow, and counted on vmcnt AND lgkmcnt, so
 // every wait for an activation would also drain the operator words requested ahead (measured: 420 cycles per non-zero instead of ~15).
-extern __shared__ __attribute__((aligned(16))) float chain_lds[];
+extern __shared__ __attribute__((aligned(16))) float chain_lds_dyn[];
+// ST = the whole 160 KiB as ONE statically sized array at LDS address 0: every LDS address in the walk is then the loaded byte offset itself.
+// With the dynamically sized array the compiler adds the array's (link-time, zero) base to each of them: four `v_add 0` per quad, and a lone
+// wavefront pays 5-6 cycles of issue per instruction.  Used when the key-net needs more than half of the LDS anyway (one workgroup per CU).
+template <bool ST>
+__device__ __forceinline__ float* chain_lds_base() {
+    if constexpr (ST) {
+        __shared__ __attribute__((aligned(16))) float chain_lds_all[CHAIN_LDS_BYTES / 4];
+        return chain_lds_all;
+    } else {
+        return chain_lds_dyn;
+    }
+}
+#define chain_lds (chain_lds_base<ST>())
 
 // One output row per lane, all four batch columns: acc[j] = acc[j] + v * x[j] over the row's stored non-zeros, serial in k.
 // A wavefront walks its slices s = wave, wave + 16, ...; per slice the operator words arrive through a register ring of D quads per lane
@@ -75,7 +88,7 @@ extern __shared__ __attribute__((aligned(16))) float chain_lds[];
 // bit for bit, and no NaN / Inf of a live activation can leak through a padded entry.  So there is no predicate anywhere in the walk.
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
-template <int D, int NP>
+template <int D, int NP, bool ST>
 __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane) {
     constexpr int RPS = 64;                    // rows per slice (wavefront)
     constexpr int NW = CHAIN_THREADS / 64;
@@ -188,6 +201,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     }
 }
 
+template <bool ST>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     const int boff[2] = {0, 4 * a.buf1_off};       // float offsets of the two activation buffers
     const int tid = threadIdx.x;
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     for (int l = 0; l < a.n_layers; l++) {
         const ChainLayerArg& L = a.L[l];
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
-        chain_rows<4, 2>(L, out_off, wave, lane);
+        chain_rows<4, 2, ST>(L, out_off, wave, lane);
         __syncthreads();
     }
     const int res_off = (a.n_layers & 1) ? boff[1] : boff[0];
@@ -429,7 +443,7 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     c->args.buf1_off = (int32_t)feat[0];
     c->args.zero_off = (int32_t)(feat[0] + feat[1]);
     c->lds_bytes = lds;
-    KN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_BYTES));
+    KN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_BYTES));
     *rows_out = ops[n_ops - 1]->rows;
     *cols_out = ops[0]->cols;
     *nnz_out = nnz;
@@ -446,8 +460,9 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
     a.n_vecs = (int32_t)n_vecs;
     const int64_t n_grp = (n_vecs + CHAIN_BT - 1) / CHAIN_BT;
     const int64_t grid = 8 * ((((n_grp + 7) >> 3) + 7) & ~(int64_t)7);      // 8 XCD lanes x a chunk rounded to whole 128-byte lines (idle workgroups return at once)
-    KN_LAUNCH("chain_kernel<" + std::to_string(a.n_layers) + " operators, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>", chain_kernel,
-              dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
+    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
+    if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
+    else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
     KN_HIP(hipGetLastError());
     return KN_OK;
 }
