@@ -147,3 +147,47 @@ def test_float_key_vgg16_with_photometric_gain_equals_plain_network():
     assert np.abs(y - yp).max() <= 1e-5 * max(1.0, np.abs(yp).max()) + 1e-5, np.abs(y - yp).max()
     back = sensor.fromtensor(x[:2].to(dev)).encrypt().decrypt().astensor().cpu().numpy()
     assert np.allclose(back, x[:2].numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_bf16x3_candidate_at_full_size(vgg):
+    """EXPERIMENTAL path at BASELINE's full size: with exact_mode('auto-bf16x3') the conv layers that qualify (Cin % 16 == 0: all but conv1_1) take the
+    kernel that emulates f32 products on the bf16 matrix pipe, each only after its result was measured against the order-preserving kernel on the
+    calibration batch (4x headroom under 1e-5 * max(1, |y|)).  Keyed logits still equal the source network's; on three layers of different shapes the
+    full 256-image output is compared with the order-preserving kernel once more, independently of the calibration record."""
+    (net, sensor, knet) = vgg
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+    x256 = torch.cat([xc] * 64, dim=0).t().contiguous().t()
+    try:
+        knet.exact_mode('auto-bf16x3')
+        y = knet.forward_linear(x256)
+        rep = knet.contract_report()
+        on = [r['name'] for r in rep['layers'] if r['exact'] == 'bf16x3']
+        assert on == ['conv1_2', 'conv2_1', 'conv2_2', 'conv3_1', 'conv3_2', 'conv3_3', 'conv4_1', 'conv4_2', 'conv4_3', 'conv5_1', 'conv5_2', 'conv5_3'], rep
+        for r in rep['layers']:
+            if r['exact'] == 'bf16x3':
+                assert r['calibration']['measured_bf16x3_vs_exact'] <= 0.25 * r['calibration']['tol'], r
+        with torch.no_grad():
+            yp = net(x).numpy()
+        err = float(np.abs(y[:4, :-1].cpu().numpy() - yp).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(yp).max())) + 1e-5, err
+        assert torch.equal(y[:4], y[4:8])
+        # independent re-check, chained on the bf16x3 forward's own activations
+        yin = x256
+        children = list(knet._keynet.named_children())
+        for (i, (name, c)) in enumerate(children):
+            if not isinstance(c, KeyedLayer):
+                continue
+            fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+            out = c.forward(yin, fuse_relu=fuse)
+            if name in ('conv1_2', 'conv3_2', 'conv5_1'):
+                assert 'bf16x3' in c.W._device_op().plan(256, 4 | (1 if fuse else 0))
+                ye = c.W.torchdot(yin.t(), relu=fuse, exact=True)
+                (d, m) = (float((ye - out.t()).abs().max()), float(ye.abs().max()))
+                assert d <= 1e-5 * max(1.0, m), (name, d, m)
+                del ye
+            yin = out
+    finally:
+        knet.exact_mode(None)
