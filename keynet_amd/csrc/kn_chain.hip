@@ -40,6 +40,7 @@ static constexpr int CHAIN_BT = 4;            // batch columns per workgroup
 static constexpr int CHAIN_THREADS = 1024;    // 16 wavefronts
 static constexpr int CHAIN_MAX_LAYERS = 12;
 static constexpr size_t CHAIN_LDS_BYTES = 160 * 1024;
+static constexpr int CHAIN_OVERREAD_QUADS = 16;                // >= ring depth + next-slice quads: how far the walk may request past the end of an array
 
 struct ChainLayerArg {
     const float* vals;          // quads: [slice][q][lane][4]
@@ -95,11 +96,16 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
+    // Operator words are addressed as (array base, wave-uniform) + (32-bit byte offset): the slice's offset and the running quad offset are scalar,
+    // the lane's own offset is a constant of the slice -- the loads take the saddr form and the walk has no 64-bit vector address arithmetic and no
+    // clamp: a request past a slice's last quad reads the next slice's words (or the arrays' zero padding) and is never used.
     struct Meta {
-        int row, nq, cstride;
-        const i32x4* cp;
-        const f32x4* vp;
+        int row, nq;
+        uint32_t cstride_b;                    // bytes between a row's consecutive column quads (16, or 16 * 64 for per-lane columns)
+        uint32_t coff, voff;                   // byte offsets of the lane's quad 0 in L.cols / L.vals
     };
+    const char* const cols_b = reinterpret_cast<const char*>(L.cols);
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
     auto load_meta = [&](int s) {
         s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
         const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * s);
@@ -107,16 +113,14 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
         Meta m;
         m.row = lm.x;
         m.nq = __builtin_amdgcn_readfirstlane(info.x);
-        m.cstride = __builtin_amdgcn_readfirstlane(info.y);
-        m.vp = reinterpret_cast<const f32x4*>(L.vals) + (int64_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + lane;     // + q * RPS
-        m.cp = reinterpret_cast<const i32x4*>(L.cols) + lm.y;                                                          // + q * cstride
+        m.cstride_b = 16u * (uint32_t)__builtin_amdgcn_readfirstlane(info.y);
+        m.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+        m.coff = 16u * (uint32_t)lm.y;
         return m;
     };
-    auto fetch = [&](const Meta& m, const int q, i32x4& c, f32x4& v) {      // quad q, clamped to the slice's last quad (results past it unused)
-        const int ql = m.nq > 0 ? m.nq - 1 : 0;
-        const int qq = q < ql ? q : ql;
-        c = m.cp[(int64_t)qq * m.cstride];
-        v = m.vp[(int64_t)qq * RPS];
+    auto fetch = [&](const Meta& m, const int q, i32x4& c, f32x4& v) {
+        c = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)q * m.cstride_b) + m.coff);
+        v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     Meta m0 = load_meta(wave), m1 = load_meta(wave + NW);
@@ -395,7 +399,8 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         info[(size_t)(4 * s + 2)] = (int32_t)vq;
         vq += nq;
     }
-    vals.resize(vals.size() + (size_t)RPS * 4, 0.0f);          // a slice without entries still has a readable quad 0
+    vals.resize(vals.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, 0.0f);       // requests run past a slice's (and the array's) last quad: readable, never used
+    colpool.resize(colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
     L.n_slices = (int32_t)n_slices;
     L.n_rows = (int32_t)rows;
     L.relu = relu;
