@@ -40,6 +40,7 @@ static constexpr int CHAIN_BT = 4;            // batch columns per workgroup
 static constexpr int CHAIN_THREADS = 1024;    // 16 wavefronts
 static constexpr int CHAIN_MAX_LAYERS = 12;
 static constexpr size_t CHAIN_LDS_BYTES = 160 * 1024;
+static constexpr size_t CHAIN_THIN_POOL_BYTES = 12 * 1024;    // column pool of a thin layer that may be staged in LDS (two copies)
 static constexpr int CHAIN_OVERREAD_QUADS = 16;                // >= ring depth + next-slice quads: how far the walk may request past the end of an array
 
 struct ChainLayerArg {
@@ -47,7 +48,8 @@ struct ChainLayerArg {
     const int32_t* cols;        // pool of column quads; an entry is the LDS BYTE offset of the feature in this layer's input buffer
     const int32_t* lane_meta;   // [n_slices * 64][2]: output row (-1 = empty slot), index of the row's first column QUAD in `cols`
     const int32_t* slice_info;  // [n_slices][4]: quads, column quad stride, first value quad / 64, 0
-    int32_t n_slices, n_rows, relu, pad_;
+    int32_t n_slices, n_rows, relu;
+    int32_t cols_quads;         // > 0: a THIN layer (see chain_rows_thin): size of its column pool in quads, staged in LDS before the walk
 };
 
 struct ChainArgs {
@@ -56,6 +58,7 @@ struct ChainArgs {
     float* Y;
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
+    int32_t cols_off;                                              // float4 index of the LDS area a thin layer's column pool is staged in (two copies)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -205,6 +208,99 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     }
 }
 
+// A THIN layer (a keyed nn.Linear: 121 rows = two slices, 785 columns) is a serial walk that few wavefronts can work on, and a wavefront alone on
+// its SIMD pays ~5.5 cycles per VECTOR instruction whatever it is (tools/micro/dep_chain.hip: one quad of the general walk -- 16 packed
+// multiplies / adds, 4 ds_read_b128, 2 loads, a few moves -- = 170-190 cycles; scalar instructions are free: trimming them changed nothing).
+// So the walk is made of fewer vector instructions per wavefront: each slice is walked by TWO wavefronts, one per pair of batch columns
+// (8 packed instructions + 4 ds_read_b64 per quad instead of 16 + 4 ds_read_b128), and the column quads come from LDS, where all sixteen
+// wavefronts first stage the layer's column pool (one or two shared patterns: a few KB) -- twice, the second copy with + 8 bytes on every
+// entry, so that a wavefront's activation address is the staged entry itself (no per-read address add) and only the VALUE quads are loaded from
+// memory (the two wavefronts of a slice load the same values: with the columns also from memory that would double the texture addresser's
+// work, which is shared by the CU -- the reason an earlier two-/four-lanes-per-row variant was slower).
+template <int DV, bool ST>
+__device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane) {
+    constexpr int RPS = 64;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tid = wave * 64 + lane;
+    const int pool = 4 * L.cols_quads;                                            // entries of one copy
+    for (int i = tid; i < 2 * pool; i += CHAIN_THREADS) {
+        const int half = i >= pool ? 1 : 0;
+        reinterpret_cast<int*>(chain_lds)[4 * cols_off4 + i] = L.cols[i - half * pool] + 8 * half;
+    }
+    __syncthreads();
+    if (wave >= 2 * L.n_slices) return;
+    const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
+    const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
+    const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (sl * RPS + lane));
+    const int nq = __builtin_amdgcn_readfirstlane(info.x);
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const uint32_t voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+    const int cbase = 4 * cols_off4 + half * pool + 4 * lm.y;                    // int index of the row's column quad 0 in the wavefront's copy (+ 4 q)
+    auto ldc = [&](const int q) { return *reinterpret_cast<const i32x4*>(&reinterpret_cast<const int*>(chain_lds)[cbase + 4 * q]); };      // (the pool is padded: requests past the row's end are readable)
+    auto ldv = [&](const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + voff); };
+    auto xread = [&](const i32x4& cq, f32x2 (&x)[4]) {
+        x[0] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.x);
+        x[1] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.y);
+        x[2] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.z);
+        x[3] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.w);
+    };
+    f32x2 acc = {0.f, 0.f};
+    auto macs = [&](const f32x2 (&x)[4], const f32x4& vq) {
+        const float vv[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const f32x2 p = x[e] * vv[e];
+            acc = acc + p;
+        }
+    };
+    f32x4 v[DV];
+#pragma unroll
+    for (int i = 0; i < DV; i++) v[i] = ldv(i);
+    __builtin_amdgcn_sched_barrier(0);
+    i32x4 c1 = ldc(1);                       // columns two quads ahead, activations one quad ahead
+    f32x2 xa[4], xb[4];
+    {
+        const i32x4 c0 = ldc(0);
+        xread(c0, xa);
+    }
+    int q = 0;
+    for (; q + DV <= nq; q += DV) {
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            f32x2 (&xc)[4] = (i & 1) ? xb : xa;
+            f32x2 (&xn)[4] = (i & 1) ? xa : xb;
+            const i32x4 c2 = ldc(q + i + 2);
+            xread(c1, xn);
+            __builtin_amdgcn_sched_barrier(0);             // next quad's LDS reads in flight under this quad's arithmetic
+            macs(xc, v[i]);
+            v[i] = ldv(q + DV + i);
+            __builtin_amdgcn_sched_barrier(0);             // the value request stays HERE (see chain_rows)
+            c1 = c2;
+        }
+        static_assert(DV % 2 == 0, "the x double buffer alternates per quad");
+    }
+#pragma unroll
+    for (int i = 0; i < DV - 1; i++) {
+        if (q + i < nq) {
+            f32x2 (&xc)[4] = (i & 1) ? xb : xa;
+            f32x2 (&xn)[4] = (i & 1) ? xa : xb;
+            const i32x4 c2 = ldc(q + i + 2);
+            xread(c1, xn);
+            __builtin_amdgcn_sched_barrier(0);
+            macs(xc, v[i]);
+            c1 = c2;
+        }
+    }
+    if (lm.x >= 0) {
+        f32x2 t = acc;
+        if (L.relu) {                                          // torch relu: NaN stays NaN
+            t.x = (t.x < 0.0f) ? 0.0f : t.x;
+            t.y = (t.y < 0.0f) ? 0.0f : t.y;
+        }
+        *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * lm.x + 2 * half]) = t;
+    }
+}
+
 template <bool ST>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     const int boff[2] = {0, 4 * a.buf1_off};       // float offsets of the two activation buffers
@@ -238,7 +334,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     for (int l = 0; l < a.n_layers; l++) {
         const ChainLayerArg& L = a.L[l];
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
-        chain_rows<4, 2, ST>(L, out_off, wave, lane);
+        if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane);
+        else chain_rows<4, 2, ST>(L, out_off, wave, lane);
         __syncthreads();
     }
     const int res_off = (a.n_layers & 1) ? boff[1] : boff[0];
@@ -400,11 +497,20 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         vq += nq;
     }
     vals.resize(vals.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, 0.0f);       // requests run past a slice's (and the array's) last quad: readable, never used
+    const size_t pool_quads = colpool.size() / 4 + 2;                               // what a thin layer stages: the patterns + the two quads its walk requests ahead
     colpool.resize(colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
     L.n_slices = (int32_t)n_slices;
     L.n_rows = (int32_t)rows;
     L.relu = relu;
-    L.pad_ = 0;
+    // thin layer: two wavefronts per slice fit the workgroup, every slice on shared patterns, a walk long enough to be bound by one wavefront's
+    // instruction issue, a column pool of a few KB (staged twice)
+    bool thin = n_slices >= 1 && 2 * n_slices <= CHAIN_THREADS / 64 && pool_quads * 16 <= CHAIN_THIN_POOL_BYTES;
+    int longest = 0;
+    for (int64_t s = 0; s < n_slices; s++) {
+        thin = thin && s_shared[(size_t)s];
+        longest = std::max(longest, s_max[(size_t)s]);
+    }
+    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : 0;
     int rc;
     if ((rc = chain_upload(c, &L.vals, vals)) || (rc = chain_upload(c, &L.cols, colpool)) || (rc = chain_upload(c, &L.lane_meta, lane_meta)) ||
         (rc = chain_upload(c, &L.slice_info, info)))
@@ -447,7 +553,14 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     c->args.n_out = (int32_t)ops[n_ops - 1]->rows;
     c->args.buf1_off = (int32_t)feat[0];
     c->args.zero_off = (int32_t)(feat[0] + feat[1]);
-    c->lds_bytes = lds;
+    c->args.cols_off = (int32_t)(feat[0] + feat[1] + 1);
+    size_t pool_quads = 0;
+    for (int64_t l = 0; l < n_ops; l++) pool_quads = std::max(pool_quads, (size_t)c->args.L[l].cols_quads);
+    if (lds + 2 * pool_quads * 16 > CHAIN_LDS_BYTES) {        // no room for the staging area: the thin layers take the general walk
+        for (int64_t l = 0; l < n_ops; l++) c->args.L[l].cols_quads = 0;
+        pool_quads = 0;
+    }
+    c->lds_bytes = lds + 2 * pool_quads * 16;
     KN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_BYTES));
     *rows_out = ops[n_ops - 1]->rows;
     *cols_out = ops[0]->cols;
