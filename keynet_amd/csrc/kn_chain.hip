@@ -26,6 +26,8 @@
 // What was tried on the way is in DESIGN.md (thin layers over 2 / 4 lanes per row: the redundant operator loads cost more texture-address
 // time than the extra wavefronts gained; deeper rings; an L2 warm-up pass; all neutral or slower).
 #include "kn_internal.h"
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <numeric>
@@ -59,7 +61,28 @@ struct ChainArgs {
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
     int32_t cols_off;                                              // float4 index of the LDS area a thin layer's column pool is staged in (two copies)
+#ifdef KN_ABLATION
+    unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries, then [workgroup][12 layers][16 waves][8] inside the walks (tools/chain_stamps.sh), or null
+    unsigned long long* wstamps;
+#endif
 };
+#ifdef KN_ABLATION
+#define CHAIN_STAMP(k)                                                                           \
+    do {                                                                                         \
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 16 + (k)] = wall_clock64(); \
+    } while (0)
+// inside a walk: `drain` = wait for everything requested so far first (what the stamp then shows is the LATENCY of those requests; the walk is perturbed)
+#define CHAIN_WSTAMP(k, drain)                                                                   \
+    do {                                                                                         \
+        if (ws) {                                                                                \
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");               \
+            if (lane == 0) ws[(k)] = wall_clock64();                                             \
+        }                                                                                        \
+    } while (0)
+#else
+#define CHAIN_STAMP(k) do { } while (0)
+#define CHAIN_WSTAMP(k, drain) do { } while (0)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -93,7 +116,7 @@ __device__ __forceinline__ float* chain_lds_base() {
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
 template <int D, int NP, bool ST>
-__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane) {
+__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, unsigned long long* const ws) {
     constexpr int RPS = 64;                    // rows per slice (wavefront)
     constexpr int NW = CHAIN_THREADS / 64;
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
@@ -126,11 +149,14 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
         v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    CHAIN_WSTAMP(0, false);
     Meta m0 = load_meta(wave), m1 = load_meta(wave + NW);
+    CHAIN_WSTAMP(1, true);                                          // slice + lane records landed
     i32x4 c[D], cn[NP];
     f32x4 v[D], vn[NP];
 #pragma unroll
     for (int i = 0; i < D; i++) fetch(m0, i, c[i], v[i]);
+    CHAIN_WSTAMP(2, true);                                          // first ring landed
     for (int s = wave; s < n_slices; s += NW) {
 #pragma unroll
         for (int i = 0; i < NP; i++) fetch(m1, i, cn[i], vn[i]);
@@ -194,6 +220,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
             }
             *reinterpret_cast<f32x4*>(&chain_lds[out_off + 4 * m0.row]) = t;
         }
+        if (s == wave) CHAIN_WSTAMP(3, false);                      // first slice done
         // the next slice becomes the current one: its early quads are the head of the ring, the rest is requested now
         m0 = m1;
         m1 = m2;
@@ -218,7 +245,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // memory (the two wavefronts of a slice load the same values: with the columns also from memory that would double the texture addresser's
 // work, which is shared by the CU -- the reason an earlier two-/four-lanes-per-row variant was slower).
 template <int DV, bool ST>
-__device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane) {
+__device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane, unsigned long long* const ws) {
     constexpr int RPS = 64;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int tid = wave * 64 + lane;
@@ -227,7 +254,9 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
         const int half = i >= pool ? 1 : 0;
         reinterpret_cast<int*>(chain_lds)[4 * cols_off4 + i] = L.cols[i - half * pool] + 8 * half;
     }
+    CHAIN_WSTAMP(0, false);
     __syncthreads();
+    CHAIN_WSTAMP(1, false);                                                      // pool staged
     if (wave >= 2 * L.n_slices) return;
     const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
     const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
@@ -257,6 +286,7 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
 #pragma unroll
     for (int i = 0; i < DV; i++) v[i] = ldv(i);
     __builtin_amdgcn_sched_barrier(0);
+    CHAIN_WSTAMP(2, true);                                                       // records + first ring landed
     i32x4 c1 = ldc(1);                       // columns two quads ahead, activations one quad ahead
     f32x2 xa[4], xb[4];
     {
@@ -315,6 +345,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     const int64_t grp = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((blockIdx.x >> 3) >= chunk || grp >= n_grp) return;
     const int64_t c0 = grp * CHAIN_BT;
+    CHAIN_STAMP(0);
     const bool full = (c0 + CHAIN_BT <= a.n_vecs) && (a.ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
     for (int f = tid; f < a.n_in; f += CHAIN_THREADS) {
         const float* src = a.X + (int64_t)f * a.ldx + c0;
@@ -331,12 +362,21 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     }
     if (tid == 0) *reinterpret_cast<f32x4*>(&chain_lds[4 * a.zero_off]) = f32x4{0.f, 0.f, 0.f, 0.f};      // what padded operator entries read
     __syncthreads();
+    CHAIN_STAMP(1);
     for (int l = 0; l < a.n_layers; l++) {
         const ChainLayerArg& L = a.L[l];
+#ifdef KN_ABLATION
+        unsigned long long* const ws = a.wstamps ? a.wstamps + (((size_t)blockIdx.x * CHAIN_MAX_LAYERS + l) * 16 + wave) * 8 : nullptr;
+#else
+        constexpr unsigned long long* ws = nullptr;
+#endif
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
-        if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane);
-        else chain_rows<4, 2, ST>(L, out_off, wave, lane);
+        if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane, ws);
+        else chain_rows<4, 2, ST>(L, out_off, wave, lane, ws);
+        CHAIN_WSTAMP(6, false);
         __syncthreads();
+        CHAIN_WSTAMP(7, false);
+        CHAIN_STAMP(2 + l);
     }
     const int res_off = (a.n_layers & 1) ? boff[1] : boff[0];
     for (int f = tid; f < a.n_out; f += CHAIN_THREADS) {
@@ -347,6 +387,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         if (c0 + 2 < a.n_vecs) dst[2] = v.z;
         if (c0 + 3 < a.n_vecs) dst[3] = v.w;
     }
+    CHAIN_STAMP(2 + a.n_layers);
 }
 
 // ---- host -----------------------------------------------------------------------------------------------------------------------
@@ -578,10 +619,35 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
     a.n_vecs = (int32_t)n_vecs;
     const int64_t n_grp = (n_vecs + CHAIN_BT - 1) / CHAIN_BT;
     const int64_t grid = 8 * ((((n_grp + 7) >> 3) + 7) & ~(int64_t)7);      // 8 XCD lanes x a chunk rounded to whole 128-byte lines (idle workgroups return at once)
+#ifdef KN_ABLATION
+    // diagnostic build only: KN_CHAIN_STAMPS=<file> makes every launch synchronous and dumps the timestamps of the LAST launch
+    const char* stamp_path = getenv("KN_CHAIN_STAMPS");
+    a.stamps = a.wstamps = nullptr;
+    const size_t n_stamps = (size_t)grid * 16 + (getenv("KN_CHAIN_WSTAMPS") ? (size_t)grid * CHAIN_MAX_LAYERS * 16 * 8 : 0);
+    if (stamp_path && !plan_sink()) {
+        KN_HIP(hipMalloc((void**)&a.stamps, n_stamps * sizeof(unsigned long long)));
+        KN_HIP(hipMemsetAsync(a.stamps, 0, n_stamps * sizeof(unsigned long long), s));
+        if (n_stamps > (size_t)grid * 16) a.wstamps = a.stamps + (size_t)grid * 16;
+    }
+#endif
     const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
     else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
     KN_HIP(hipGetLastError());
+#ifdef KN_ABLATION
+    if (a.stamps) {
+        std::vector<unsigned long long> h(n_stamps);
+        KN_HIP(hipStreamSynchronize(s));
+        KN_HIP(hipMemcpy(h.data(), a.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        KN_HIP(hipFree(a.stamps));
+        if (FILE* f = fopen(stamp_path, "wb")) {
+            const unsigned long long hdr[2] = {(unsigned long long)grid, (unsigned long long)(a.wstamps ? 1 : 0)};
+            fwrite(hdr, sizeof(unsigned long long), 2, f);
+            fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+            fclose(f);
+        }
+    }
+#endif
     return KN_OK;
 }
 
