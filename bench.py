@@ -826,7 +826,13 @@ def main():
             torch.cuda.synchronize()
             ch_ms = e0.elapsed_time(e1) / 50
             ach = total_bytes / ch_ms / 1e6
+            # What really bounds it: bit-exactness with scipy forbids the FMA, so a stored non-zero costs one packed multiply and one
+            # packed add per two batch columns, 4 cycles each on one of the CU's four SIMDs; a workgroup owns 4 columns, 256 CUs run a round.
+            nnz_net = float(sum(r['nnz'] for r in table))
+            rounds = -(-((batch + 3) // 4) // 256)
+            valu_floor_ms = rounds * (nnz_net / 64.0) * 4 * 4 / 4 / 2.4e9 * 1e3
             roof = dict(bound='hbm', kernel=chain.plan(batch), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                        valu_floor_ms=valu_floor_ms, frac_of_valu_floor=valu_floor_ms / ch_ms,
                         algorithmic_bytes=total_bytes, algorithmic_macs=float(sum(r['nnz'] for r in table)) * batch, ms_per_forward=ch_ms,
                         t_mac_per_s=float(sum(r['nnz'] for r in table)) * batch / ch_ms / 1e9,
                         launch_per_layer_ms={r['name']: round(r['ms'], 4) for r in table},
