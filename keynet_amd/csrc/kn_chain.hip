@@ -21,10 +21,12 @@
 //     the values;
 //   * a row shorter than its slice's longest row is padded with (zero feature, 0.0f), see chain_rows: no predicate anywhere.
 //
-// Measured (LeNet_AvgPool, 1024 images, tools/chain_bench.py): 59 us per forward against 138 us for seven launches; per layer conv1 + pool1
-// 16 us, conv2 + pool2 14 us, fc1 17 us (a 785-step serial walk that only two wavefronts of the CU can work on), fc2 + fc3 6 us, launch 5 us.
-// What was tried on the way is in DESIGN.md (thin layers over 2 / 4 lanes per row: the redundant operator loads cost more texture-address
-// time than the extra wavefronts gained; deeper rings; an L2 warm-up pass; all neutral or slower).
+// Measured (LeNet_AvgPool, 1024 images, tools/chain_bench.py, tools/chain_stamps.sh): 49 us per forward against 138 us for seven launches; per
+// layer (timestamps at the barriers, median of 256 workgroups) conv1 8.7, pool1 3.6, conv2 15.6, pool2 2.6, fc1 8-12, fc2 2.7, fc3 2.0 us.  The
+// floor of this formulation is VALU issue, not memory: without the FMA a stored non-zero costs a packed multiply and a packed add per two batch
+// columns -- 18.7 us per launch for LeNet's 718 k non-zeros.  What was tried on the way is in DESIGN.md (thin layers over 2 / 4 lanes per
+// row, deeper rings, an L2 warm-up pass, cross-layer prefetch in registers or as a per-wavefront item stream, products software-pipelined one
+// quad ahead of the dependent adds: neutral or slower).
 #include "kn_internal.h"
 #include <cstdio>
 #include <cstdlib>
@@ -630,7 +632,10 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
         if (n_stamps > (size_t)grid * 16) a.wstamps = a.stamps + (size_t)grid * 16;
     }
 #endif
-    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
+    int n_thin = 0;
+    for (int l = 0; l < a.n_layers; l++) n_thin += a.L[l].cols_quads > 0 ? 1 : 0;
+    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk), 4 batch columns per workgroup, " +
+                          std::to_string(c->lds_bytes) + " B LDS>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
     else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
     KN_HIP(hipGetLastError());
