@@ -53,7 +53,7 @@ struct ChainLayerArg {
     const int32_t* lane_meta;   // [n_slices * 64][2]: output row (-1 = empty slot), index of the row's first column QUAD in `cols`
     const int32_t* slice_info;  // [n_slices][4]: quads, column quad stride, first value quad / 64, 0
     int32_t n_slices, n_rows, relu;
-    int32_t cols_quads;         // > 0: a THIN layer (see chain_rows_thin): size of its column pool in quads, staged in LDS before the walk
+    int32_t cols_quads;         // size of the layer's column pool in quads when it is staged in LDS before the walk: > 0 a THIN layer (chain_rows_thin, two copies), < 0 a layer of shared patterns on all wavefronts (chain_rows_cl, one copy), 0 columns from memory
 };
 
 struct ChainArgs {
@@ -237,6 +237,124 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     }
 }
 
+// The same walk with the COLUMN quads read from LDS (layers whose rows share column patterns -- the Cout rows of a conv output pixel -- and
+// whose pool of patterns fits beside the activations: LeNet's conv1 38 KB, conv2 41 KB).  Why: a wave-wide 16-byte load costs the CU's one
+// texture addresser 16 cycles whatever the number of distinct addresses, so the column quad (the same 16 bytes for all lanes of a pattern)
+// cost as much as the value quad -- 32 addresser cycles per wavefront and quad, 128 per SIMD with four SIMDs sharing it, against 64 cycles
+// of arithmetic: the conv layers ran at the addresser's rate (conv2: 157 k non-zeros x 8 B / 64 B per clock = 8.2 us of its 15.6).  Staged
+// once per launch and layer by all sixteen wavefronts (one pass through the addresser instead of one per lane), a pattern's quad is a
+// broadcast ds_read_b128; the activation reads run one quad behind the column reads and one ahead of the arithmetic, as in the thin walk.
+template <int D, int NP, bool ST>
+__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane) {
+    constexpr int RPS = 64;
+    constexpr int NW = CHAIN_THREADS / 64;
+    static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
+    const int tid = wave * 64 + lane;
+    const int pool4 = -L.cols_quads;                                             // quads
+    for (int i = tid; i < pool4; i += CHAIN_THREADS)
+        *reinterpret_cast<i32x4*>(&chain_lds[4 * (cols_off4 + i)]) = *reinterpret_cast<const i32x4*>(L.cols + 4 * i);
+    __syncthreads();
+    const int n_slices = L.n_slices;
+    if (wave >= n_slices) return;
+    struct Meta {
+        int row, nq;
+        uint32_t coff, voff;                   // LDS byte offset of the row's column quad 0 in the staged pool; byte offset of the lane's value quad 0 in L.vals
+    };
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    auto load_meta = [&](int s) {
+        s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
+        const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * s);
+        const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (s * RPS + lane));
+        Meta m;
+        m.row = lm.x;
+        m.nq = __builtin_amdgcn_readfirstlane(info.x);
+        m.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+        m.coff = 16u * (uint32_t)(cols_off4 + lm.y);
+        return m;
+    };
+    auto ldv = [&](const Meta& m, const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff); };
+    auto ldc = [&](const Meta& m, const int q) { return *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(chain_lds) + m.coff + 16u * (uint32_t)q); };     // (the pool is padded: quads past a row's end are readable)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    Meta m0 = load_meta(wave), m1 = load_meta(wave + NW);
+    f32x4 v[D], vn[NP];
+#pragma unroll
+    for (int i = 0; i < D; i++) v[i] = ldv(m0, i);
+    for (int s = wave; s < n_slices; s += NW) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) vn[i] = ldv(m1, i);
+        const Meta m2 = load_meta(s + 2 * NW);
+        __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
+        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        auto xread = [&](const i32x4& cq, f32x4 (&x)[4]) {
+            x[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.x);
+            x[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.y);
+            x[2] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.z);
+            x[3] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.w);
+        };
+        auto macs = [&](const f32x4 (&x)[4], const f32x4& vq) {
+            const float vv[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const f32x2 p01 = f32x2{x[e].x, x[e].y} * vv[e];
+                const f32x2 p23 = f32x2{x[e].z, x[e].w} * vv[e];
+                a01 = a01 + p01;
+                a23 = a23 + p23;
+            }
+        };
+        const int nq = m0.nq;
+        i32x4 c1 = ldc(m0, 1);                                    // columns two quads ahead, activations one quad ahead
+        f32x4 xa[4], xb[4];
+        {
+            const i32x4 c0 = ldc(m0, 0);
+            xread(c0, xa);                                         // (a slice without entries reads the padded quad 0: unused)
+        }
+        int q = 0;
+        for (; q + D <= nq; q += D) {
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                f32x4 (&xc)[4] = (i & 1) ? xb : xa;
+                f32x4 (&xn)[4] = (i & 1) ? xa : xb;
+                const i32x4 c2 = ldc(m0, q + i + 2);
+                xread(c1, xn);
+                __builtin_amdgcn_sched_barrier(0);                 // next quad's LDS reads in flight under this quad's arithmetic
+                macs(xc, v[i]);
+                v[i] = ldv(m0, q + D + i);
+                __builtin_amdgcn_sched_barrier(0);                 // the value request stays HERE (see chain_rows)
+                c1 = c2;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < D - 1; i++) {
+            if (q + i < nq) {
+                f32x4 (&xc)[4] = (i & 1) ? xb : xa;
+                f32x4 (&xn)[4] = (i & 1) ? xa : xb;
+                const i32x4 c2 = ldc(m0, q + i + 2);
+                xread(c1, xn);
+                __builtin_amdgcn_sched_barrier(0);
+                macs(xc, v[i]);
+                c1 = c2;
+            }
+        }
+        if (m0.row >= 0) {
+            f32x4 t = {a01.x, a01.y, a23.x, a23.y};
+            if (L.relu) {                                          // torch relu: NaN stays NaN
+                t.x = (t.x < 0.0f) ? 0.0f : t.x;
+                t.y = (t.y < 0.0f) ? 0.0f : t.y;
+                t.z = (t.z < 0.0f) ? 0.0f : t.z;
+                t.w = (t.w < 0.0f) ? 0.0f : t.w;
+            }
+            *reinterpret_cast<f32x4*>(&chain_lds[out_off + 4 * m0.row]) = t;
+        }
+        m0 = m1;
+        m1 = m2;
+#pragma unroll
+        for (int i = 0; i < NP; i++) v[i] = vn[i];
+#pragma unroll
+        for (int i = NP; i < D; i++) v[i] = ldv(m0, i);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // A THIN layer (a keyed nn.Linear: 121 rows = two slices, 785 columns) is a serial walk that few wavefronts can work on, and a wavefront alone on
 // its SIMD pays ~5.5 cycles per VECTOR instruction whatever it is (tools/micro/dep_chain.hip: one quad of the general walk -- 16 packed
 // multiplies / adds, 4 ds_read_b128, 2 loads, a few moves -- = 170-190 cycles; scalar instructions are free: trimming them changed nothing).
@@ -374,6 +492,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
 #endif
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
         if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane, ws);
+        else if (L.cols_quads < 0) chain_rows_cl<4, 2, ST>(L, out_off, a.cols_off, wave, lane);
         else chain_rows<4, 2, ST>(L, out_off, wave, lane, ws);
         CHAIN_WSTAMP(6, false);
         __syncthreads();
@@ -480,11 +599,23 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         }
         s_max[(size_t)s] = mx;
         s_shared[(size_t)s] = (distinct * 2 <= real) ? 1 : 0;     // most lanes share a pattern with a neighbour: one copy per pattern
-        if (s_shared[(size_t)s])
-            for (int i = 0; i < real; i++) {
-                const int32_t p = pat[(size_t)order[(size_t)(s * RPS + i)]];
-                pat_quads[(size_t)p] = std::max(pat_quads[(size_t)p], (mx + 3) / 4);
-            }
+    }
+    // a layer that is shared almost everywhere (a conv layer and its odd last slice: the homogeneous row) stores every slice that way -- one layout
+    // per layer lets its whole pool be staged in LDS (chain_rows_cl); the few unrelated rows then read scattered instead of lane-adjacent quads
+    {
+        int64_t rows_shared = 0;
+        for (int64_t s = 0; s < n_slices; s++)
+            if (s_shared[(size_t)s]) rows_shared += std::min<int64_t>(RPS, rows - s * RPS);
+        if (rows_shared * 10 >= rows * 9)
+            for (int64_t s = 0; s < n_slices; s++) s_shared[(size_t)s] = 1;
+    }
+    for (int64_t s = 0; s < n_slices; s++) {
+        if (!s_shared[(size_t)s]) continue;
+        const int real = (int)std::min<int64_t>(RPS, rows - s * RPS);
+        for (int i = 0; i < real; i++) {
+            const int32_t p = pat[(size_t)order[(size_t)(s * RPS + i)]];
+            pat_quads[(size_t)p] = std::max(pat_quads[(size_t)p], (s_max[(size_t)s] + 3) / 4);
+        }
     }
     // pass 2: storage.  Padding = (zero feature, 0.0f).
     std::vector<float> vals;
@@ -553,7 +684,10 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         thin = thin && s_shared[(size_t)s];
         longest = std::max(longest, s_max[(size_t)s]);
     }
-    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : 0;
+    bool all_shared = n_slices >= 1;
+    for (int64_t s = 0; s < n_slices; s++) all_shared = all_shared && s_shared[(size_t)s];
+    // (chain_create drops either choice when the staging area does not fit beside the activations)
+    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : (all_shared && !getenv("KN_CHAIN_NO_CL")) ? -(int32_t)pool_quads : 0;
     int rc;
     if ((rc = chain_upload(c, &L.vals, vals)) || (rc = chain_upload(c, &L.cols, colpool)) || (rc = chain_upload(c, &L.lane_meta, lane_meta)) ||
         (rc = chain_upload(c, &L.slice_info, info)))
@@ -597,13 +731,16 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     c->args.buf1_off = (int32_t)feat[0];
     c->args.zero_off = (int32_t)(feat[0] + feat[1]);
     c->args.cols_off = (int32_t)(feat[0] + feat[1] + 1);
-    size_t pool_quads = 0;
-    for (int64_t l = 0; l < n_ops; l++) pool_quads = std::max(pool_quads, (size_t)c->args.L[l].cols_quads);
-    if (lds + 2 * pool_quads * 16 > CHAIN_LDS_BYTES) {        // no room for the staging area: the thin layers take the general walk
-        for (int64_t l = 0; l < n_ops; l++) c->args.L[l].cols_quads = 0;
-        pool_quads = 0;
+    // one staging area for the column pools, reused layer after layer (thin layers hold two copies); a layer whose pool does not fit beside
+    // the activations reads its columns from memory (general walk)
+    size_t stage_quads = 0;
+    for (int64_t l = 0; l < n_ops; l++) {
+        ChainLayerArg& L = c->args.L[l];
+        const size_t need = L.cols_quads > 0 ? 2 * (size_t)L.cols_quads : (size_t)(-(int64_t)L.cols_quads);
+        if (lds + need * 16 > CHAIN_LDS_BYTES) L.cols_quads = 0;
+        else stage_quads = std::max(stage_quads, need);
     }
-    c->lds_bytes = lds + 2 * pool_quads * 16;
+    c->lds_bytes = lds + stage_quads * 16;
     KN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_BYTES));
     *rows_out = ops[n_ops - 1]->rows;
     *cols_out = ops[0]->cols;
@@ -633,8 +770,13 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
     }
 #endif
     int n_thin = 0;
-    for (int l = 0; l < a.n_layers; l++) n_thin += a.L[l].cols_quads > 0 ? 1 : 0;
-    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk), 4 batch columns per workgroup, " +
+    int n_cl = 0;
+    for (int l = 0; l < a.n_layers; l++) {
+        n_thin += a.L[l].cols_quads > 0 ? 1 : 0;
+        n_cl += a.L[l].cols_quads < 0 ? 1 : 0;
+    }
+    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk, " + std::to_string(n_cl) +
+                          " with column patterns in LDS), 4 batch columns per workgroup, " +
                           std::to_string(c->lds_bytes) + " B LDS>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
     else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
