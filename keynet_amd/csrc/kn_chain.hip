@@ -88,6 +88,9 @@ struct ChainArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// Slice records are read with SCALAR loads (the address is wave-uniform): a vector load + readfirstlane makes the wavefront wait for the load where
+// the readfirstlane stands -- at the START of every slice, for records it needs two slices later (44.3 against 45.5 us per LeNet launch).
+typedef const int32_t __attribute__((address_space(4))) * chain_const_i32;
 
 // The activation buffers are addressed as OFFSETS into this one LDS array, never through pointers: a pointer picked at run time
 // (buf[l & 1]) loses its address space, and the compiler then reads LDS with flat_load -- slow, and counted on vmcnt AND lgkmcnt, so
@@ -136,13 +139,13 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
     auto load_meta = [&](int s) {
         s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
-        const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * s);
+        const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
         const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (s * RPS + lane));
         Meta m;
         m.row = lm.x;
-        m.nq = __builtin_amdgcn_readfirstlane(info.x);
-        m.cstride_b = 16u * (uint32_t)__builtin_amdgcn_readfirstlane(info.y);
-        m.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+        m.nq = si[0];
+        m.cstride_b = 16u * (uint32_t)si[1];
+        m.voff = 16u * ((uint32_t)si[2] * RPS + (uint32_t)lane);
         m.coff = 16u * (uint32_t)lm.y;
         return m;
     };
@@ -245,7 +248,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // once per launch and layer by all sixteen wavefronts (one pass through the addresser instead of one per lane), a pattern's quad is a
 // broadcast ds_read_b128; the activation reads run one quad behind the column reads and one ahead of the arithmetic, as in the thin walk.
 template <int D, int NP, bool ST>
-__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane) {
+__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane, unsigned long long* const ws) {
     constexpr int RPS = 64;
     constexpr int NW = CHAIN_THREADS / 64;
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
@@ -263,12 +266,12 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
     auto load_meta = [&](int s) {
         s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
-        const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * s);
+        const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
         const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (s * RPS + lane));
         Meta m;
         m.row = lm.x;
-        m.nq = __builtin_amdgcn_readfirstlane(info.x);
-        m.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+        m.nq = si[0];
+        m.voff = 16u * ((uint32_t)si[2] * RPS + (uint32_t)lane);
         m.coff = 16u * (uint32_t)(cols_off4 + lm.y);
         return m;
     };
@@ -279,7 +282,9 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
     f32x4 v[D], vn[NP];
 #pragma unroll
     for (int i = 0; i < D; i++) v[i] = ldv(m0, i);
-    for (int s = wave; s < n_slices; s += NW) {
+    int si = 0;                                                   // (slice counter: timestamps of the diagnostic build only)
+    for (int s = wave; s < n_slices; s += NW, si++) {
+        if (si < 8) CHAIN_WSTAMP(8 + 4 * si + 0, false);
 #pragma unroll
         for (int i = 0; i < NP; i++) vn[i] = ldv(m1, i);
         const Meta m2 = load_meta(s + 2 * NW);
@@ -309,6 +314,12 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
             xread(c0, xa);                                         // (a slice without entries reads the padded quad 0: unused)
         }
         int q = 0;
+#ifdef KN_ABLATION
+        if (ws && si < 8) {                                        // when the slice's first activations have landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            CHAIN_WSTAMP(8 + 4 * si + 1, false);
+        }
+#endif
         for (; q + D <= nq; q += D) {
 #pragma unroll
             for (int i = 0; i < D; i++) {
@@ -335,6 +346,7 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
                 c1 = c2;
             }
         }
+        if (si < 8) CHAIN_WSTAMP(8 + 4 * si + 2, false);
         if (m0.row >= 0) {
             f32x4 t = {a01.x, a01.y, a23.x, a23.y};
             if (L.relu) {                                          // torch relu: NaN stays NaN
@@ -486,13 +498,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
     for (int l = 0; l < a.n_layers; l++) {
         const ChainLayerArg& L = a.L[l];
 #ifdef KN_ABLATION
-        unsigned long long* const ws = a.wstamps ? a.wstamps + (((size_t)blockIdx.x * CHAIN_MAX_LAYERS + l) * 16 + wave) * 8 : nullptr;
+        unsigned long long* const ws = a.wstamps ? a.wstamps + (((size_t)blockIdx.x * CHAIN_MAX_LAYERS + l) * 16 + wave) * 40 : nullptr;
 #else
         constexpr unsigned long long* ws = nullptr;
 #endif
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
         if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane, ws);
-        else if (L.cols_quads < 0) chain_rows_cl<4, 2, ST>(L, out_off, a.cols_off, wave, lane);
+        else if (L.cols_quads < 0) chain_rows_cl<4, 2, ST>(L, out_off, a.cols_off, wave, lane, ws);
         else chain_rows<4, 2, ST>(L, out_off, wave, lane, ws);
         CHAIN_WSTAMP(6, false);
         __syncthreads();
@@ -762,7 +774,7 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
     // diagnostic build only: KN_CHAIN_STAMPS=<file> makes every launch synchronous and dumps the timestamps of the LAST launch
     const char* stamp_path = getenv("KN_CHAIN_STAMPS");
     a.stamps = a.wstamps = nullptr;
-    const size_t n_stamps = (size_t)grid * 16 + (getenv("KN_CHAIN_WSTAMPS") ? (size_t)grid * CHAIN_MAX_LAYERS * 16 * 8 : 0);
+    const size_t n_stamps = (size_t)grid * 16 + (getenv("KN_CHAIN_WSTAMPS") ? (size_t)grid * CHAIN_MAX_LAYERS * 16 * 40 : 0);
     if (stamp_path && !plan_sink()) {
         KN_HIP(hipMalloc((void**)&a.stamps, n_stamps * sizeof(unsigned long long)));
         KN_HIP(hipMemsetAsync(a.stamps, 0, n_stamps * sizeof(unsigned long long), s));

@@ -8,7 +8,7 @@ import numpy as np
 raw = np.fromfile(sys.argv[1], dtype=np.uint64).astype(np.int64)
 grid, has_w = int(raw[0]), int(raw[1])
 t = raw[2:2 + grid * 16].reshape(-1, 16)
-w = raw[2 + grid * 16:].reshape(grid, 12, 16, 8) if has_w else None
+w = raw[2 + grid * 16:].reshape(grid, 12, 16, 40) if has_w else None
 live = t[:, 0] > 0
 t = t[live]                                   # idle workgroups return before the first stamp
 nph = int((t[0] > 0).sum())
@@ -39,3 +39,14 @@ if w is not None:
                 continue
             f = lambda k: ('%6.2f' % ((x[k] - base) / 100.0)) if x[k] else '     -'
             print('   wave %2d: enter %s | %s %s %s | done %s barrier %s' % (wv, f(0), f(1), f(2), f(3), f(6), f(7)))
+
+    print('slices of the column-patterns-in-LDS walk (workgroup %d): per wavefront and slice, us since the phase began: start / first activations landed / arithmetic issued' % g)
+    for l in range(nph - 3):
+        base = t[0, 1 + l]
+        if not w[g, l, :, 8:].any():
+            continue
+        print(' op%d' % l)
+        for wv in range(16):
+            x = w[g, l, wv, 8:].reshape(8, 4)
+            cells = ['%5.2f/%5.2f/%5.2f' % tuple((x[i, k] - base) / 100.0 for k in range(3)) for i in range(8) if x[i, 0]]
+            print('   wave %2d: %s' % (wv, '  '.join(cells)))
