@@ -19,14 +19,14 @@
 //   * columns: stored as the LDS byte offset of the feature (no address arithmetic in the walk); rows sharing a pattern read ONE copy of
 //     it (per-lane base, quad stride 1: the lanes of a group hit the same address), slices of unrelated rows (pooling) store them like
 //     the values;
-//   * a row shorter than its slice's longest row is padded with (zero feature, 0.0f), see chain_rows: no predicate anywhere.
+//   * a row shorter than its slice's longest row is padded with (zero feature, 0.0f), see chain_rows: no predicate anywhere;
+//   * layers whose rows share column patterns (conv, Linear) keep their pool of patterns in LDS during their walk (chain_rows_cl, chain_rows_thin).
 //
-// Measured (LeNet_AvgPool, 1024 images, tools/chain_bench.py, tools/chain_stamps.sh): 49 us per forward against 138 us for seven launches; per
-// layer (timestamps at the barriers, median of 256 workgroups) conv1 8.7, pool1 3.6, conv2 15.6, pool2 2.6, fc1 8-12, fc2 2.7, fc3 2.0 us.  The
-// floor of this formulation is VALU issue, not memory: without the FMA a stored non-zero costs a packed multiply and a packed add per two batch
-// columns -- 18.7 us per launch for LeNet's 718 k non-zeros.  What was tried on the way is in DESIGN.md (thin layers over 2 / 4 lanes per
-// row, deeper rings, an L2 warm-up pass, cross-layer prefetch in registers or as a per-wavefront item stream, products software-pipelined one
-// quad ahead of the dependent adds: neutral or slower).
+// Measured (LeNet_AvgPool, 1024 images, tools/chain_bench.py, tools/chain_stamps.sh): 44 us per forward against 138 us for seven launches; per
+// layer (timestamps at the barriers, median of 256 workgroups) conv1 7.8, pool1 3.3, conv2 12.1, pool2 2.3, fc1 8-12, fc2 2.6, fc3 1.9 us.  The
+// floor of this formulation is vector-instruction issue, not memory: a SIMD issues one vector instruction per ~4.5 cycles whatever its kind, and a
+// stored non-zero costs 5.5 of them per 64 rows and four batch columns (without the FMA: two packed multiplies, two packed adds, one ds_read_b128,
+// half a load) -- ~17 us per launch for LeNet's 323 k non-zeros.  What was tried on the way is in DESIGN.md 5.
 #include "kn_internal.h"
 #include <cstdio>
 #include <cstdlib>
