@@ -359,6 +359,11 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
         }
         m0 = m1;
         m1 = m2;
+        // the next slice's lane record (requested a whole slice ago) is consumed HERE, before the value requests below: left to the compiler its first use
+        // is the column read that opens the next slice, and the wait it places there (the counter is in-order, its count across the loop edge
+        // conservative) also covers the value quads requested a few instructions earlier -- a full memory latency at every slice start
+        asm volatile("" : "+v"(m0.coff), "+v"(m0.row));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NP; i++) v[i] = vn[i];
 #pragma unroll
