@@ -885,6 +885,65 @@ def test_whole_net_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(per.cpu().numpy(), ref)
 
 
+def test_whole_net_kernel_layout_choices_vs_oracle():
+    """The whole-net kernel's per-layer layout choices, each against the CPU oracle bit for bit: conv-like layers (groups of rows sharing an
+    unsorted column sequence) with their pattern pool in LDS -- including a last slice of unrelated rows that is stored the same way --, a
+    conv-like layer whose pool does NOT fit beside the activations (columns from memory), and a Linear on the thin walk behind them."""
+    rng = np.random.RandomState(7)
+
+    def grouped(rows, cols, group, nnz, tail_loose):
+        (ip, ix, dt) = ([0], [], [])
+        shared = None
+        for r in range(rows):
+            if r >= rows - tail_loose:
+                c = rng.randint(0, cols, size=rng.randint(1, 6))         # the odd rows at the end: patterns of their own (e.g. the homogeneous row)
+            else:
+                if r % group == 0:
+                    shared = rng.randint(0, cols, size=nnz)
+                c = shared
+            ix.extend(int(v) for v in c)
+            dt.extend(rng.randn(len(c)).astype(np.float32))
+            ip.append(len(ix))
+        return (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+
+    def dense(rows, cols):
+        perm = rng.permutation(cols)
+        (ip, ix, dt) = ([0], [], [])
+        for r in range(rows):
+            ix.extend(int(v) for v in perm)
+            dt.extend(rng.randn(cols).astype(np.float32))
+            ip.append(len(ix))
+        return (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+
+    def run(layers, want):
+        (ops, mats) = ([], [])
+        for (shape, (ip, ix, dt), relu) in layers:
+            mats.append((shape, ip, ix, dt, relu))
+            ops.append(_capi.Operator.csr(shape, ip, ix, dt))
+        chain = _capi.Operator.chain(ops, [m[4] for m in mats])
+        n_vecs = 37
+        assert want in chain.plan(n_vecs), chain.plan(n_vecs)
+        X = rng.randn(layers[0][0][1], n_vecs).astype(np.float32)
+        X[3, 5] = np.inf                                                     # non-finite activations travel exactly where the reference's entries carry them
+        X[4, 6] = np.nan
+        xd = torch.as_tensor(X).to(dev())
+        yd = torch.empty((layers[-1][0][0], n_vecs), device=dev())
+        chain.spmm(xd.data_ptr(), n_vecs, n_vecs, yd.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        ref = X
+        for (shape, ip, ix, dt, relu) in mats:
+            with np.errstate(invalid='ignore', over='ignore'):
+                ref = oracle.csr_matvecs(shape, ip, ix, dt, ref)
+                if relu:
+                    ref = np.where(ref < 0, np.float32(0), ref)              # torch relu: NaN stays NaN
+        assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True)
+
+    run([((645, 200), grouped(645, 200, 6, 11, 5), 1), ((130, 645), grouped(130, 645, 16, 50, 2), 0), ((70, 130), dense(70, 130), 1), ((10, 70), dense(10, 70), 0)],
+        '4 operators (2 on the thin walk, 2 with column patterns in LDS)')
+    # 4200 + 4100 features of four columns = 133 KB of activations; 700 patterns of 28 quads = 314 KB: no room for the pool
+    run([((4100, 4200), grouped(4100, 4200, 6, 110, 2), 1), ((64, 4100), grouped(64, 4100, 8, 9, 0), 0)],
+        '2 operators (0 on the thin walk, 1 with column patterns in LDS)')
+
+
 def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
     """LeNet_AvgPool (BASELINE configs[0]-[1]) takes the whole-net kernel by default; KN_NO_CHAIN=1 selects the launch-per-layer forward;
     both equal the reference's vectors bit for bit, for the golden batch, a ragged one and 1024 images."""
