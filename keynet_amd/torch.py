@@ -114,3 +114,47 @@ def netshape(net, inshape):
         for h in hooks:
             h.remove()
     return chain
+
+
+class TiledMatrix(object):
+    """The explicit tile loop of keynet/torch.py:165-184 (`keynet.torch.TiledMatrix._torchdot`; dead code in the reference, kept for API coverage):
+
+        for (i, j, k) in blocks:  for (ii, jj, v) in tiles[k]:  y[i + ii, :] += v * x[j + jj, :]
+
+    Here the loop is the ORDER of an order-preserving CSR: every output row accumulates its terms in exactly the sequence the loop visits them
+    (blocks in the given order, a tile's entries in their stored order), f32 multiply then f32 add, on the device (kn_csr_create + kn_spmm).  The
+    reference compiles its loop with numba fastmath + parallel, so its own rounding is unspecified; the serial loop is what tests compare with."""
+
+    @staticmethod
+    def _loop_csr(tileshape, shape, tiles, blocks):
+        """(indptr, indices, data) whose rows list the loop's terms in visiting order.  `tiles[k]`: array [nnz_k, 3] of (ii, jj, v)."""
+        (H, W) = (int(shape[0]), int(shape[1]))
+        (rows, cols, vals) = ([], [], [])
+        for (i, j, k) in blocks:
+            b = np.asarray(tiles[int(k)], dtype=np.float64).reshape(-1, 3)
+            rows.append(int(i) + b[:, 0].astype(np.int64))
+            cols.append(int(j) + b[:, 1].astype(np.int64))
+            vals.append(b[:, 2].astype(np.float32))
+        cat = (lambda L, dt: np.concatenate(L).astype(dt) if len(L) else np.zeros(0, dt))
+        (r, c, v) = (cat(rows, np.int64), cat(cols, np.int64), cat(vals, np.float32))
+        assert r.size == 0 or (r.min() >= 0 and r.max() < H and c.min() >= 0 and c.max() < W), 'tile entry outside the operator'
+        order = np.argsort(r, kind='stable')                              # stable: a row keeps the loop's sequence
+        indptr = np.zeros(H + 1, np.int64)
+        np.cumsum(np.bincount(r, minlength=H), out=indptr[1:])
+        return (indptr.astype(np.int32), c[order].astype(np.int32), v[order])
+
+    @staticmethod
+    def _torchdot(x, tileshape, shape, tiles, blocks):
+        """x: [W, N] float32 torch tensor on a ROCm device (or numpy, moved to the current device) -> y [H, N] on the same device."""
+        was_numpy = isinstance(x, np.ndarray)
+        if was_numpy:
+            x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(torch.device('cuda', torch.cuda.current_device()))
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == int(shape[1]), 'non-conformal operand'
+        (ip, ix, dt) = TiledMatrix._loop_csr(tileshape, shape, tiles, blocks)
+        with torch.cuda.device(x.device):
+            op = _capi.Operator.csr((int(shape[0]), int(shape[1])), ip, ix, dt)
+            xc = x.contiguous()
+            y = torch.empty((int(shape[0]), xc.shape[1]), dtype=torch.float32, device=x.device)
+            op.spmm(xc.data_ptr(), xc.shape[1], xc.shape[1], y.data_ptr(), xc.shape[1], _capi.KN_FLAG_EXACT, _stream_ptr())
+            torch.cuda.current_stream().synchronize()                     # the operator is destroyed on return
+        return y.cpu().numpy() if was_numpy else y

@@ -25,7 +25,7 @@ import subprocess
 import numpy as np
 
 __all__ = ['csr_matvecs', 'relu_', 'coo_to_canonical_csr', 'tiled_to_csr', 'conv2dtiled_to_csr', 'operator_from_golden',
-           'layer_forward', 'keynet_forward', 'affine_to_linear', 'linear_to_affine', 'load_golden_layers', 'build']
+           'layer_forward', 'keynet_forward', 'affine_to_linear', 'linear_to_affine', 'load_golden_layers', 'build', 'tiled_torchdot_loop']
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -212,3 +212,16 @@ def keynet_forward(layers, x_cipher, collect=False):
         if collect:
             outs[name] = y
     return (y, outs) if collect else y
+
+
+def tiled_torchdot_loop(x, tileshape, shape, tiles, blocks):
+    """Serial restatement of keynet/torch.py:173-184 (`keynet.torch.TiledMatrix._torchdot`): y[i+ii, :] += v * x[j+jj, :] over blocks, then over the
+    entries of tile k, in f32 (the reference jit-compiles this loop with fastmath + parallel; serial, unfused f32 is the one well-defined reading)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros((int(shape[0]), x.shape[1]), dtype=np.float32)
+    for (i, j, k) in blocks:
+        b = np.asarray(tiles[int(k)]).reshape(-1, 3)
+        for u in range(b.shape[0]):
+            (ii, jj, v) = (int(b[u, 0]), int(b[u, 1]), np.float32(b[u, 2]))
+            y[int(i) + ii, :] = y[int(i) + ii, :] + v * x[int(j) + jj, :]
+    return y

@@ -86,6 +86,29 @@ def test_tiled_cases(golden):
     assert np.allclose(z['D.y_coo'], z['D.W'].dot(z['D.x']), atol=1e-5)
 
 
+def _tile_list(z, p):
+    """tiles[k] = [nnz_k, 3] arrays of (ii, jj, v): the operand form of keynet.torch.TiledMatrix._torchdot (keynet/torch.py:173-184)."""
+    (ptr, tr, tc, tv) = (z[p + 'tile_ptr'], z[p + 'tile_row'], z[p + 'tile_col'], z[p + 'tile_val'])
+    return [np.stack([tr[ptr[k]:ptr[k + 1]], tc[ptr[k]:ptr[k + 1]], tv[ptr[k]:ptr[k + 1]]], axis=1).astype(np.float64) for k in range(len(ptr) - 1)]
+
+
+def test_explicit_tile_loop_oracle(golden):
+    """the serial reading of the reference's explicit tile loop equals the reference's TiledMatrix.torchdot results (golden y,
+    produced through tocsr() + csr_matvecs) to its own 1e-5, on every tiled fixture; and the host half of the product's version
+    (keynet_amd.torch.TiledMatrix._loop_csr: the loop's visiting order as an order-preserving CSR) reproduces the loop bit for bit through the oracle."""
+    from keynet_amd.torch import TiledMatrix as TorchTiled
+    z = golden('tiled_cases.npz')
+    names = sorted({k.split('.')[1] for k in z.files if k.startswith('C.') and k.endswith('.tile_ptr')})
+    assert len(names) == 3                                       # the TiledMatrix / DiagonalTiledMatrix fixtures (conv tiles are channel matrices: another operand form)
+    for n in names:
+        p = 'C.%s.' % n
+        (shape, tileshape, blocks, tiles) = (tuple(int(v) for v in z[p + 'shape']), tuple(int(v) for v in z[p + 'tileshape']), z[p + 'blocks'], _tile_list(z, p))
+        y = oracle.tiled_torchdot_loop(z[p + 'x'], tileshape, shape, tiles, blocks)
+        assert np.allclose(y, z[p + 'y'], atol=1e-5, rtol=1e-5), n
+        (ip, ix, dt) = TorchTiled._loop_csr(tileshape, shape, tiles, blocks)
+        assert np.array_equal(oracle.csr_matvecs(shape, ip, ix, dt, z[p + 'x']), y), n
+
+
 def test_oracle_matches_scipy_on_random_unsorted():
     """The C restatement == scipy's own csr_matvecs on a non-canonical matrix (the third-party engine the reference calls)."""
     import scipy.sparse

@@ -885,6 +885,24 @@ def test_whole_net_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(per.cpu().numpy(), ref)
 
 
+def test_explicit_tile_loop_on_device(golden):
+    """SURVEY 8(a) row a10 (keynet/torch.py:173-184): keynet_amd.torch.TiledMatrix._torchdot applies the tiles in the loop's own order on the
+    device -- bit-equal to the serial loop of the oracle, for a device tensor and for a numpy operand."""
+    from keynet_amd.torch import TiledMatrix as TorchTiled
+    from test_oracle_golden import _tile_list
+    z = golden('tiled_cases.npz')
+    names = sorted({k.split('.')[1] for k in z.files if k.startswith('C.') and k.endswith('.tile_ptr')})
+    for n in names:
+        p = 'C.%s.' % n
+        (shape, tileshape, blocks, tiles) = (tuple(int(v) for v in z[p + 'shape']), tuple(int(v) for v in z[p + 'tileshape']), z[p + 'blocks'], _tile_list(z, p))
+        ref = oracle.tiled_torchdot_loop(z[p + 'x'], tileshape, shape, tiles, blocks)
+        y = TorchTiled._torchdot(torch.as_tensor(z[p + 'x']).to(dev()), tileshape, shape, tiles, blocks)
+        assert y.is_cuda and np.array_equal(y.cpu().numpy(), ref), n
+        assert np.array_equal(TorchTiled._torchdot(np.asarray(z[p + 'x']), tileshape, shape, tiles, blocks), ref), n
+    with pytest.raises(AssertionError):
+        TorchTiled._torchdot(torch.zeros(3, 2, device=dev()), (2, 2), (4, 4), [np.zeros((0, 3))], [])
+
+
 def test_whole_net_kernel_layout_choices_vs_oracle():
     """The whole-net kernel's per-layer layout choices, each against the CPU oracle bit for bit: conv-like layers (groups of rows sharing an
     unsorted column sequence) with their pattern pool in LDS -- including a last slice of unrelated rows that is stored the same way --, a
