@@ -53,7 +53,9 @@ struct ChainLayerArg {
     const int32_t* lane_meta;   // [n_slices * 64][2]: output row (-1 = empty slot), index of the row's first column QUAD in `cols`
     const int32_t* slice_info;  // [n_slices][4]: quads, column quad stride, first value quad / 64, 0
     int32_t n_slices, n_rows, relu;
-    int32_t cols_quads;         // size of the layer's column pool in quads when it is staged in LDS before the walk: > 0 a THIN layer (chain_rows_thin, two copies), < 0 a layer of shared patterns on all wavefronts (chain_rows_cl, one copy), 0 columns from memory
+    int32_t cols_quads;         // size of the layer's column pool in quads when the pool is staged in LDS before the walk:
+                                //   > 0 a THIN layer (chain_rows_thin, two copies), < 0 a layer of shared patterns on all wavefronts
+                                //   (chain_rows_cl, one copy); 0 = columns from memory (chain_rows)
 };
 
 struct ChainArgs {
@@ -62,10 +64,10 @@ struct ChainArgs {
     float* Y;
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
-    int32_t cols_off;                                              // float4 index of the LDS area a thin layer's column pool is staged in (two copies)
+    int32_t cols_off;                                              // float4 index of the LDS area column pools are staged in (one layer at a time)
 #ifdef KN_ABLATION
-    unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries, then [workgroup][12 layers][16 waves][8] inside the walks (tools/chain_stamps.sh), or null
-    unsigned long long* wstamps;
+    unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries (tools/chain_stamps.sh), or null
+    unsigned long long* wstamps;                                   // [workgroup][12 layers][16 wavefronts][40] inside the walks: 0-7 per walk, 8 + 4 * slice + k per slice
 #endif
 };
 #ifdef KN_ABLATION
