@@ -94,6 +94,21 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // the readfirstlane stands -- at the START of every slice, for records it needs two slices later (44.3 against 45.5 us per LeNet launch).
 typedef const int32_t __attribute__((address_space(4))) * chain_const_i32;
 
+// (x0, x1) * v for the v in the LOW / HIGH half of an aligned register pair: the packed multiply picks the half with op_sel, so the four values of
+// a loaded quad need no move into a pair of their own (the compiler spends a v_mov on .y / .w: two of ~24 vector instructions per quad, and the walk
+// is bound by vector-instruction issue).  The same IEEE f32 multiply either way.
+typedef float chain_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ chain_f32x2 chain_mul_lo(const chain_f32x2 x, const chain_f32x2 vpair) {
+    chain_f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(vpair), "v"(x));
+    return r;
+}
+__device__ __forceinline__ chain_f32x2 chain_mul_hi(const chain_f32x2 x, const chain_f32x2 vpair) {
+    chain_f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(vpair), "v"(x));
+    return r;
+}
+
 // The activation buffers are addressed as OFFSETS into this one LDS array, never through pointers: a pointer picked at run time
 // (buf[l & 1]) loses its address space, and the compiler then reads LDS with flat_load -- slow, and counted on vmcnt AND lgkmcnt, so
 // every wait for an activation would also drain the operator words requested ahead (measured: 420 cycles per non-zero instead of ~15).
@@ -179,11 +194,12 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
             x[3] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.w);
         };
         auto macs = [&](const f32x4 (&x)[4], const f32x4& vq) {
-            const float vv[4] = {vq.x, vq.y, vq.z, vq.w};
+            const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const f32x2 p01 = f32x2{x[e].x, x[e].y} * vv[e];
-                const f32x2 p23 = f32x2{x[e].z, x[e].w} * vv[e];
+                const f32x2 x01 = {x[e].x, x[e].y}, x23 = {x[e].z, x[e].w};
+                const f32x2 p01 = (e & 1) ? chain_mul_hi(x01, vp[e >> 1]) : chain_mul_lo(x01, vp[e >> 1]);
+                const f32x2 p23 = (e & 1) ? chain_mul_hi(x23, vp[e >> 1]) : chain_mul_lo(x23, vp[e >> 1]);
                 a01 = a01 + p01;
                 a23 = a23 + p23;
             }
@@ -299,11 +315,12 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
             x[3] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.w);
         };
         auto macs = [&](const f32x4 (&x)[4], const f32x4& vq) {
-            const float vv[4] = {vq.x, vq.y, vq.z, vq.w};
+            const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const f32x2 p01 = f32x2{x[e].x, x[e].y} * vv[e];
-                const f32x2 p23 = f32x2{x[e].z, x[e].w} * vv[e];
+                const f32x2 x01 = {x[e].x, x[e].y}, x23 = {x[e].z, x[e].w};
+                const f32x2 p01 = (e & 1) ? chain_mul_hi(x01, vp[e >> 1]) : chain_mul_lo(x01, vp[e >> 1]);
+                const f32x2 p23 = (e & 1) ? chain_mul_hi(x23, vp[e >> 1]) : chain_mul_lo(x23, vp[e >> 1]);
                 a01 = a01 + p01;
                 a23 = a23 + p23;
             }
@@ -414,10 +431,10 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     };
     f32x2 acc = {0.f, 0.f};
     auto macs = [&](const f32x2 (&x)[4], const f32x4& vq) {
-        const float vv[4] = {vq.x, vq.y, vq.z, vq.w};
+        const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const f32x2 p = x[e] * vv[e];
+            const f32x2 p = (e & 1) ? chain_mul_hi(x[e], vp[e >> 1]) : chain_mul_lo(x[e], vp[e >> 1]);
             acc = acc + p;
         }
     };
