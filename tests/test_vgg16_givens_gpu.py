@@ -119,3 +119,46 @@ def test_givens_vgg16_exact_mode_bit_equal_to_oracle(givens):
         if name == 'conv4_1':
             break
     assert checked == ['conv1_1', 'conv1_2', 'conv2_1', 'conv4_1']
+
+
+def test_givens_vgg16_with_the_bf16x3_candidate(givens):
+    """EXPERIMENTAL path on the reference's own float-key net: under exact_mode('auto-bf16x3') a conv layer keeps the bf16x3 kernel only with 4x
+    headroom under the tolerance on the calibration batch; whatever each layer ends up on, every conv layer as shipped is within the UNCONDITIONED
+    1e-5 * max(1, |y|) of the order-preserving path on the same input, and the keyed logits still equal the source network (reference criterion)."""
+    (net, sensor, knet) = givens
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 224, 224, generator=g)
+    xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+    x256 = torch.cat([xc] * 64, dim=0).t().contiguous().t()
+    try:
+        knet.exact_mode('auto-bf16x3')
+        y = knet.forward_linear(x256)
+        rep = knet.contract_report()
+        assert not rep['undecided']
+        on = [r['name'] for r in rep['layers'] if r['exact'] == 'bf16x3']
+        for r in rep['layers']:
+            if r['exact'] == 'bf16x3':
+                assert r['calibration']['measured_bf16x3_vs_exact'] <= 0.25 * r['calibration']['tol'], r
+        with torch.no_grad():
+            yp = net(x).numpy()
+        err = float(np.abs(y[:4, :-1].cpu().numpy() - yp).max())
+        assert err <= 1e-3, err
+        print('givens VGG-16, bf16x3 candidate: %d conv layers on bf16x3 %s; switched to exact: %s; keyed vs plain %.3g' % (len(on), on, rep['switched'], err))
+        children = list(knet._keynet.named_children())
+        yin = x256
+        for (i, (name, c)) in enumerate(children):
+            if not isinstance(c, KeyedLayer):
+                continue
+            fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+            if isinstance(c.W, ksp.Conv2dTiledMatrix) and name in ('conv1_2', 'conv2_2', 'conv3_3', 'conv4_2', 'conv5_1'):
+                ye = c.W.torchdot(yin.t(), relu=fuse, exact=True)
+                ys = c.forward(yin, fuse_relu=fuse).t()
+                (d, m) = (float((ye - ys).abs().max()), float(ye.abs().max()))
+                assert d <= 1e-5 * max(1.0, m), (name, d, m, c._exact)
+                print(name, c._exact, 'diff %.3g of %.3g' % (d, m))
+                yin = ye.t()
+            else:
+                yin = c.forward(yin, fuse_relu=fuse)
+    finally:
+        knet.exact_mode('auto')
