@@ -888,28 +888,7 @@ def main():
                 res['graph'] = {'error': str(e)}
         if secondary is not None:
             res['secondary'] = secondary
-        # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key")
-        if args.workload == 'vgg16' and world == 1 and not args.exact and not args.no_exact_leg and replay is None:
-            knet.exact_mode(True)
-            t0 = time.time()
-            knet.forward_linear(x_cipher)                    # uploads the CSR twins of fc6-8
-            torch.cuda.synchronize()
-            log('[bench exact] exact-mode operators resident + first forward in %.1f s' % (time.time() - t0))
-            (el_x, out_x) = timed(1, args.steps)
-            err_x = float((out_x[:n_gate].contiguous().cpu() - y_plain).abs().max())
-            del out_x
-            table_x = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
-            for r in table_x:
-                log('[bench exact] %-8s %-9s %8.3f ms  %7.2f T MAC/s' % (r['name'], r['kind'], r['ms'], r['nnz'] * batch / r['ms'] / 1e9))
-            par_x = exact_parity(knet, x_cipher)
-            par_x['vs_source_network_max_abs_err'] = err_x
-            if not par_x['ok'] or err_x > 1e-3:
-                raise AssertionError('exact-mode parity failed: %s' % json.dumps(par_x))
-            res['exact'] = {'images_per_s': batch * args.steps / el_x, 'ms_per_step': 1e3 * el_x / args.steps, 'steps': args.steps,
-                            'mode': 'KeyedModel.exact_mode(True): every layer in the reference\'s accumulation order and rounding (no FMA, no MFMA)',
-                            'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
-                            'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
-            knet.exact_mode(None)
+        def experimental_bf16x3():
             # EXPERIMENTAL (never the headline): the same key-net with the bf16x3 kernel as the first candidate of the float-key contract.
             # Each conv layer keeps it only if its result, measured against the order-preserving kernel on the calibration batch, has 4x
             # headroom under 1e-5 * max(1, |y|).
@@ -935,11 +914,37 @@ def main():
                     'layers_ms': {r['name']: round(r['ms'], 4) for r in table_b}}}
             except Exception as e:
                 res['experimental'] = {'bf16x3': {'error': str(e)}}
+        # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key")
+        if args.workload == 'vgg16' and world == 1 and not args.exact and not args.no_exact_leg and replay is None:
+            knet.exact_mode(True)
+            t0 = time.time()
+            knet.forward_linear(x_cipher)                    # uploads the CSR twins of fc6-8
+            torch.cuda.synchronize()
+            log('[bench exact] exact-mode operators resident + first forward in %.1f s' % (time.time() - t0))
+            (el_x, out_x) = timed(1, args.steps)
+            err_x = float((out_x[:n_gate].contiguous().cpu() - y_plain).abs().max())
+            del out_x
+            table_x = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
+            for r in table_x:
+                log('[bench exact] %-8s %-9s %8.3f ms  %7.2f T MAC/s' % (r['name'], r['kind'], r['ms'], r['nnz'] * batch / r['ms'] / 1e9))
+            par_x = exact_parity(knet, x_cipher)
+            par_x['vs_source_network_max_abs_err'] = err_x
+            if not par_x['ok'] or err_x > 1e-3:
+                raise AssertionError('exact-mode parity failed: %s' % json.dumps(par_x))
+            res['exact'] = {'images_per_s': batch * args.steps / el_x, 'ms_per_step': 1e3 * el_x / args.steps, 'steps': args.steps,
+                            'mode': 'KeyedModel.exact_mode(True): every layer in the reference\'s accumulation order and rounding (no FMA, no MFMA)',
+                            'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
+                            'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
+            knet.exact_mode(None)
+            experimental_bf16x3()
             knet.exact_mode(None)
             try:
                 res['float_key_parity'] = float_key_parity(dev)
             except Exception as e:      # a reported-only record must never break the bench line
                 res['float_key_parity'] = {'error': str(e)}
+        if args.workload in ('vgg16-givens', 'vgg16-gain') and world == 1 and not args.exact and not args.no_exact_leg and replay is None:
+            experimental_bf16x3()                         # float keys with coefficient entries: which layers keep the candidate, and what it buys
+            knet.exact_mode(None)
         os.write(json_fd, (json.dumps(res) + '\n').encode())
     if use_dist:
         dist.barrier()
