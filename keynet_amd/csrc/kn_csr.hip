@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 
 void csr_free(CsrDev& c) {
     void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
-                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows};
+                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows, c.patch_rows, c.patch_ptr, c.patch_cols};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c = CsrDev();
@@ -545,6 +545,49 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         }
         members[found].push_back((int32_t)r);
     }
+    // PATCHED members.  A permutation-keyed conv layer whose filter holds an exact zero has rows that are their pixel group's column sequence minus
+    // that entry (AllConvNet conv5: 752 of 49 153 rows; walked alone they cost 1.9 ms of the layer's 11.4 -- a serial gather walk per row against one
+    // shared gather per sixteen rows).  Such a row joins the group with 0.0f at the missing positions: a running sum that started at +0.0 is never
+    // -0.0, so adding +-0.0 = 0.0f * x leaves it unchanged bit for bit whenever x is finite; csr_patch_guard_kernel rewrites the output for batch
+    // columns where x at a missing position is NOT finite (0 * Inf would leak a NaN the reference's row does not have).
+    constexpr int MAX_PATCH = 4;
+    std::vector<std::vector<std::pair<int32_t, std::vector<int32_t>>>> patched(members.size());    // group -> (row, missing positions in the group's sequence)
+    if (!getenv("KN_NO_PATCH")) {
+        std::unordered_map<int32_t, std::vector<int32_t>> by_col;      // one of a group's first MAX_PATCH + 1 columns -> group
+        for (size_t g = 0; g < members.size(); g++) {
+            const int32_t s = indptr[rep[g]], e = indptr[rep[g] + 1];
+            if (members[g].size() < 8 || e - s < 32) continue;
+            for (int32_t t = 0; t <= MAX_PATCH && s + t < e; t++) by_col[indices[s + t]].push_back((int32_t)g);
+        }
+        for (size_t g1 = 0; g1 < members.size() && !by_col.empty(); g1++) {
+            if (members[g1].size() != 1) continue;
+            const int32_t r = members[g1][0];
+            const int32_t rs = indptr[r], re = indptr[r + 1];
+            if (re - rs < 32 - MAX_PATCH) continue;
+            auto it = by_col.find(indices[rs]);
+            if (it == by_col.end()) continue;
+            for (int32_t G : it->second) {
+                const int32_t gs = indptr[rep[G]], ge = indptr[rep[G] + 1];
+                const int32_t miss = (ge - gs) - (re - rs);
+                if (miss < 1 || miss > MAX_PATCH) continue;
+                std::vector<int32_t> pos;
+                int32_t k = rs;
+                for (int32_t j = gs; j < ge; j++) {
+                    if (k < re && indices[k] == indices[j]) k++;
+                    else {
+                        pos.push_back(j - gs);
+                        if ((int)pos.size() > miss) break;
+                    }
+                }
+                if (k == re && (int)pos.size() == miss) {
+                    patched[(size_t)G].emplace_back(r, std::move(pos));
+                    members[g1].clear();
+                    break;
+                }
+            }
+        }
+    }
+    std::vector<int32_t> patch_rows, patch_ptr{0}, patch_cols;
     std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose;
     std::vector<int64_t> valptr{0};
     std::vector<float> vals;
@@ -559,8 +602,11 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         cols.insert(cols.end(), indices + s, indices + e);
         colptr.push_back((int32_t)cols.size());
         grows.insert(grows.end(), m.begin(), m.end());
+        const auto& pm = patched[g];
+        for (const auto& pr : pm) grows.push_back(pr.first);
         rowptr.push_back((int32_t)grows.size());
-        const int64_t rpad = ((int64_t)m.size() + RB - 1) / RB * RB;
+        const int64_t n_mem = (int64_t)m.size() + (int64_t)pm.size();
+        const int64_t rpad = (n_mem + RB - 1) / RB * RB;
         const int64_t v0 = (int64_t)vals.size();
         vals.resize((size_t)(v0 + rpad * ncol), 0.0f);
         for (size_t mi = 0; mi < m.size(); mi++) {
@@ -568,19 +614,36 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             for (int32_t j = 0; j < ncol; j++) vals[(size_t)(v0 + (int64_t)j * rpad + (int64_t)mi)] = data[rs + j];
             in_group[(size_t)m[mi]] = 1;
         }
+        for (size_t pi = 0; pi < pm.size(); pi++) {
+            const int32_t r = pm[pi].first;
+            const std::vector<int32_t>& pos = pm[pi].second;
+            int32_t k = indptr[r];
+            size_t pp = 0;
+            for (int32_t j = 0; j < ncol; j++) {
+                if (pp < pos.size() && pos[pp] == j) {                  // missing here: the value stays 0.0f
+                    patch_cols.push_back(indices[s + j]);
+                    pp++;
+                } else {
+                    vals[(size_t)(v0 + (int64_t)j * rpad + (int64_t)(m.size() + pi))] = data[k++];
+                }
+            }
+            patch_rows.push_back(r);
+            patch_ptr.push_back((int32_t)patch_cols.size());
+            in_group[(size_t)r] = 1;
+        }
         valptr.push_back((int64_t)vals.size());
-        if ((int64_t)m.size() >= 256 && ncol >= 2048 && !getenv("KN_NO_BIG_GROUPS")) {      // a keyed nn.Linear: LDS-staged kernel, 32 rows per workgroup
-            for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += BIG_ROWS) {
+        if (n_mem >= 256 && ncol >= 2048 && !getenv("KN_NO_BIG_GROUPS")) {      // a keyed nn.Linear: LDS-staged kernel, 32 rows per workgroup
+            for (int64_t r0 = 0; r0 < n_mem; r0 += BIG_ROWS) {
                 bgrp.push_back(gid);
                 br0.push_back((int32_t)r0);
             }
         } else {
-            for (int64_t r0 = 0; r0 < (int64_t)m.size(); r0 += RB) {
+            for (int64_t r0 = 0; r0 < n_mem; r0 += RB) {
                 wgrp.push_back(gid);
                 wr0.push_back((int32_t)r0);
             }
         }
-        grouped_nnz += (int64_t)m.size() * ncol;
+        grouped_nnz += n_mem * ncol;
     }
     std::vector<int32_t> longrows;
     const bool use_long = !getenv("KN_NO_BIG_GROUPS");
@@ -601,7 +664,11 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     A.n_long = (int64_t)longrows.size();
     A.n_loose = (int64_t)loose.size();
     A.grouped_nnz = grouped_nnz;
+    A.n_patch = (int64_t)patch_rows.size();
     int rc;
+    if ((rc = upload(&A.patch_rows, patch_rows.data(), patch_rows.size()))) return rc;
+    if ((rc = upload(&A.patch_ptr, patch_ptr.data(), patch_ptr.size()))) return rc;
+    if ((rc = upload(&A.patch_cols, patch_cols.data(), patch_cols.size()))) return rc;
     if ((rc = upload(&A.grp_colptr, colptr.data(), colptr.size()))) return rc;
     if ((rc = upload(&A.grp_cols, cols.data(), cols.size()))) return rc;
     if ((rc = upload(&A.grp_rowptr, rowptr.data(), rowptr.size()))) return rc;
@@ -877,7 +944,46 @@ static int launch_csr_pipe(const CsrDev& A, const float* x, int64_t ldx, int64_t
     return KN_OK;
 }
 
+// Patched group members (csr_build_groups): one lane per (patched row, batch column).  Nothing to do where the activations at the row's missing
+// positions are finite -- the group kernel's result is then the reference's, bit for bit.  Otherwise the row is walked again in its OWN stored
+// sequence (separate multiply and add), which is what the reference computes.  Runs after the group kernels, on their stream.
+__global__ __launch_bounds__(256) void csr_patch_guard_kernel(int64_t n_patch, const int32_t* __restrict__ patch_rows, const int32_t* __restrict__ patch_ptr,
+                                                              const int32_t* __restrict__ patch_cols, const int32_t* __restrict__ indptr,
+                                                              const int32_t* __restrict__ indices, const float* __restrict__ data, const float* __restrict__ X,
+                                                              int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    const int64_t p = (int64_t)blockIdx.x / n_ct;
+    const int64_t c = ((int64_t)blockIdx.x % n_ct) * 256 + threadIdx.x;
+    if (p >= n_patch || c >= n_vecs) return;
+    bool bad = false;
+    for (int32_t k = patch_ptr[p]; k < patch_ptr[p + 1]; k++) {
+        const float xv = X[(int64_t)patch_cols[k] * ldx + c];
+        bad = bad || !(__builtin_fabsf(xv) <= 3.4028234663852886e38f);       // Inf or NaN
+    }
+    if (!bad) return;
+    const int32_t r = patch_rows[p];
+    float acc = 0.0f;
+    for (int32_t k = indptr[r]; k < indptr[r + 1]; k++) {
+        const float t = data[k] * X[(int64_t)indices[k] * ldx + c];
+        acc = acc + t;
+    }
+    if (relu) acc = (acc < 0.0f) ? 0.0f : acc;                              // torch relu: NaN stays NaN
+    Y[(int64_t)r * ldy + c] = acc;
+}
+
+static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
+    const int rc = csr_spmm_groups(A, x, ldx, n_vecs, y, ldy, flags, s);
+    if (rc != KN_OK || A.n_patch == 0) return rc;
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    KN_LAUNCH("csr_patch_guard_kernel<" + std::to_string(A.n_patch) + " patched rows>", csr_patch_guard_kernel, dim3((unsigned)(A.n_patch * n_ct)), dim3(256), 0, s, A.n_patch,
+              A.patch_rows, A.patch_ptr, A.patch_cols, A.indptr, A.indices, A.data, x, ldx, y, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0);
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
     const int relu = (flags & KN_FLAG_RELU) ? 1 : 0;
     // a vector width is usable when pointers / strides allow it AND it keeps the wavefronts filled (64 * v columns per wave): n_vecs = 128
     // (a half-batch column window) takes v = 2 with every lane active rather than v = 4 with lanes 32..63 idle

@@ -98,6 +98,13 @@ struct CsrDev {
     int32_t* loose_rows = nullptr;
     int64_t n_loose = 0;
     int64_t grouped_nnz = 0;
+    // PATCHED group members: rows whose stored column sequence is a group's sequence minus a few entries (a keyed conv row that lost a weight to an
+    // exact zero) ride in the group with 0.0f at the missing positions; csr_patch_guard_kernel recomputes them in the reference's own sequence for
+    // the batch columns whose activation at a missing position is not finite (see kn_csr.hip)
+    int32_t* patch_rows = nullptr;   // [n_patch]
+    int32_t* patch_ptr = nullptr;    // [n_patch+1] into patch_cols
+    int32_t* patch_cols = nullptr;   // the missing column indices
+    int64_t n_patch = 0;
 };
 
 // Factored conv operator  W = sum_e coef_e * taps[tap_e] (x) E[out_e,in_e] + lastcol + e_last.

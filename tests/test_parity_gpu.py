@@ -885,6 +885,62 @@ def test_whole_net_kernel_vs_oracle_random(n_vecs):
     assert np.array_equal(per.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize('n_vecs', [256, 37])
+def test_patched_group_members_vs_oracle(n_vecs):
+    """Rows that are their pattern group's column sequence minus a few entries (a keyed conv row that lost a weight to an exact zero: AllConvNet
+    conv5) ride in the group with 0.0f at the missing positions -- bit-equal to the CPU oracle on the rows' OWN stored sequences; and where the
+    activation at a missing position is Inf / NaN the guard kernel restores exactly what the reference computes (no 0 * Inf leak)."""
+    rng = np.random.RandomState(11 + n_vecs)
+    (n_cols, n_groups, members, seq_len) = (700, 9, 21, 70)
+    (ip, ix, dt) = ([0], [], [])
+    patched_missing = []
+    for g in range(n_groups):
+        seq = rng.permutation(n_cols)[:seq_len]                                   # unsorted shared sequence
+        for m in range(members):
+            keep = np.ones(seq_len, bool)
+            if m in (3, 7, 20):                                                  # lose 1..3 entries: first, last and middle positions all occur
+                lose = {3: [0], 7: [seq_len - 1, 5], 20: [1, 30, 31]}[m]
+                keep[lose] = False
+                patched_missing.append((len(ip) - 1, seq[lose]))
+            if m == 11:
+                keep[rng.choice(seq_len, 6, replace=False)] = False              # too many missing: stays a row of its own
+            c = seq[keep]
+            ix.extend(int(v) for v in c)
+            dt.extend(rng.randn(len(c)).astype(np.float32))
+            ip.append(len(ix))
+    for _ in range(13):                                                          # unrelated rows
+        c = rng.randint(0, n_cols, size=rng.randint(0, 9))
+        ix.extend(int(v) for v in c)
+        dt.extend(rng.randn(len(c)).astype(np.float32))
+        ip.append(len(ix))
+    shape = (len(ip) - 1, n_cols)
+    (ip, ix, dt) = (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+    op = _capi.Operator.csr(shape, ip, ix, dt)
+    plan = op.plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_patch_guard_kernel<%d patched rows>' % len(patched_missing) in plan, plan
+    X = rng.randn(n_cols, n_vecs).astype(np.float32)
+    for relu in (0, 1):
+        for poison in (False, True):
+            Xp = X.copy()
+            if poison:
+                (r0, miss0) = patched_missing[0]
+                (r1, miss1) = patched_missing[4]
+                Xp[miss0[0], 1] = np.inf                                        # at a missing position of a patched row: must NOT reach that row
+                Xp[miss1[-1], 2] = np.nan
+                Xp[ix[ip[r0]], 3] = -np.inf                                     # at a present position: must reach it
+            xd = torch.as_tensor(Xp).to(dev())
+            yd = torch.empty((shape[0], n_vecs), device=dev())
+            op.spmm(xd.data_ptr(), n_vecs, n_vecs, yd.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT | (_capi.KN_FLAG_RELU if relu else 0), torch.cuda.current_stream().cuda_stream)
+            with np.errstate(invalid='ignore', over='ignore'):
+                ref = oracle.csr_matvecs(shape, ip, ix, dt, Xp)
+                if relu:
+                    ref = np.where(ref < 0, np.float32(0), ref)
+            got = yd.cpu().numpy()
+            assert np.array_equal(got, ref, equal_nan=True), (relu, poison, np.argwhere(~((got == ref) | (np.isnan(got) & np.isnan(ref))))[:5])
+            if poison:
+                assert np.isfinite(ref[r0, 1]) and np.isfinite(got[r0, 1]) and (relu or not np.isfinite(got[r0, 3]))
+
+
 def test_explicit_tile_loop_on_device(golden):
     """SURVEY 8(a) row a10 (keynet/torch.py:173-184): keynet_amd.torch.TiledMatrix._torchdot applies the tiles in the loop's own order on the
     device -- bit-equal to the serial loop of the oracle, for a device tensor and for a numpy operand."""
