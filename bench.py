@@ -234,9 +234,8 @@ def cpu_baseline(knet, workload, budget_s=24.0):
                       % (', '.join('%s x%d cols%s' % (r['layer'], r['columns'], (' [%s]' % sampled[r['layer']]) if sampled.get(r['layer'], 'whole operator') != 'whole operator' else '')
                                    for r in rows), conv_big, ', '.join(extrapolated) or 'none', total_nnz),
                layers=rows)
-    res['sample_short'] = ('%d of %d layers timed on 1 thread (%s; %d-%d batch columns each, %.1f s of scipy work), %s; %.4g nnz/image'
-                           % (len(rows), len(layers), ','.join(r['layer'] for r in rows) if len(rows) <= 12 else '%s..%s' % (rows[0]['layer'], rows[-1]['layer']),
-                              min(r['columns'] for r in rows), max(r['columns'] for r in rows), sum(r['seconds'] for r in rows),
+    res['sample_short'] = ('%d of %d layers timed on 1 thread, %d-%d batch columns each, %.1f s of scipy work; %s; %.4g nnz/image'
+                           % (len(rows), len(layers), min(r['columns'] for r in rows), max(r['columns'] for r in rows), sum(r['seconds'] for r in rows),
                               ('%d conv layers extrapolated at the conv5_1 rate %.3f ns/(nz*col)' % (len(extrapolated), conv_big)) if extrapolated else 'none extrapolated', total_nnz))
     # (ii) every physical core: one process per core, each owning a contiguous band of the operator's ROWS for all batch columns
     # (scipy's kernel is serial; rows are independent, so this is what a whole-host deployment of the same arithmetic would do)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KN_ABI_VERSION 1
+#define KN_ABI_VERSION 2
 
 enum kn_status {
     KN_OK = 0,
@@ -142,10 +142,29 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
 int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
             float* y_dev, int64_t ldy, uint32_t flags, void* stream);
 
+/* kn_spmm that additionally raises *y_absmax_dev (device f32, caller-initialised, e.g. to 0) to max |Y[r, b]| over the block it wrote,
+ * stream-ordered.  No reference counterpart: the reference applies ONE arithmetic on every call (keynet/sparse.py:488-492), so its 1e-5
+ * float-key agreement holds per call; a host that runs a layer on the matrix cores because a calibration batch showed the re-ordered sum
+ * inside that tolerance must notice when a later batch is larger.  max |Y| of layer l is max |X| of layer l+1, and the matrix-core kernels
+ * fold it into their store epilogue (no extra pass over a multi-GB activation block); behind the other kernel families the library runs
+ * one reduction pass over Y.  NaN entries are ignored, +-Inf counts.  y_absmax_dev == NULL is kn_spmm. */
+int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
+                   float* y_dev, int64_t ldy, uint32_t flags, float* y_absmax_dev, void* stream);
+
+/* max |X[r, b]| of an activation block (the input of the first layer: nothing produced it on the device), raised into *absmax_dev like
+ * kn_spmm_screen does. */
+int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax_dev, void* stream);
+
+/* Pre-size the per-stream state kn_spmm would otherwise allocate at first use on `stream` for `n_vecs` batch columns (only a
+ * kn_dense_create handle has any: its split-K partial sums), so that the first kn_spmm on that stream can be captured into a HIP graph.
+ * A no-op for every other operator kind. */
+int kn_reserve_workspace(kn_handle_t h, int64_t n_vecs, void* stream);
+
 /* Introspection: which kernels kn_spmm would launch for this operator, batch width, leading dimensions (16-byte aligned activations
  * assumed) and flags -- the SAME dispatch code runs, every launch site describes itself instead of launching.  No reference
  * counterpart (scipy has one kernel); it exists so that measurements can state which loader / tile shape produced them
- * ("choices evidenced").  Writes a NUL-terminated, ';'-separated list into buf. */
+ * ("choices evidenced").  Writes a NUL-terminated, ';'-separated list into buf.  Launches nothing and allocates nothing
+ * (with KN_FLAG_BF16X3 it reports eligibility from the operator's shape; the bf16 planes are built by the first real kn_spmm). */
 int kn_spmm_plan(kn_handle_t h, int64_t n_vecs, int64_t ldx, int64_t ldy, uint32_t flags, char* buf, int64_t buf_len);
 
 /* unkeyed nn.ReLU on a whole activation block (keynet/system.py:92) when it could not be fused */

@@ -16,11 +16,11 @@ KN_OK = 0
 KN_FLAG_RELU = 1
 KN_FLAG_EXACT = 2
 KN_FLAG_BF16X3 = 4
-KN_ABI_VERSION = 1
+KN_ABI_VERSION = 2
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_plan', 'kn_relu',
+           'kn_convtaps_create', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -63,6 +63,9 @@ def lib():
         L.kn_export_csr.argtypes = [p, p, p, p]
         L.kn_spmm.argtypes = [p, p, i64, i64, p, i64, u32, p]
         L.kn_spmm_plan.argtypes = [p, i64, i64, i64, u32, p, i64]
+        L.kn_spmm_screen.argtypes = [p, p, i64, i64, p, i64, u32, p, p]
+        L.kn_absmax.argtypes = [p, i64, i64, i64, p, p]
+        L.kn_reserve_workspace.argtypes = [p, i64, p]
         L.kn_relu.argtypes = [p, i64, i64, i64, p]
         L.kn_affine_to_linear.argtypes = [p, i64, i64, p, i64, p]
         L.kn_linear_to_affine.argtypes = [p, i64, i64, i64, p, p, p]
@@ -209,14 +212,25 @@ class Operator(object):
         check(lib().kn_export_csr(self._h, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p), data.ctypes.data_as(ctypes.c_void_p)))
         return (indptr, indices[:n], data[:n])
 
-    def spmm(self, x_ptr, ldx, n_vecs, y_ptr, ldy, flags, stream):
-        check(lib().kn_spmm(self._h, x_ptr, int(ldx), int(n_vecs), y_ptr, int(ldy), int(flags), stream))
+    def spmm(self, x_ptr, ldx, n_vecs, y_ptr, ldy, flags, stream, absmax_ptr=None):
+        """kn_spmm, or kn_spmm_screen when `absmax_ptr` (device f32 raised to max |Y|) is given."""
+        if absmax_ptr:
+            check(lib().kn_spmm_screen(self._h, x_ptr, int(ldx), int(n_vecs), y_ptr, int(ldy), int(flags), absmax_ptr, stream))
+        else:
+            check(lib().kn_spmm(self._h, x_ptr, int(ldx), int(n_vecs), y_ptr, int(ldy), int(flags), stream))
+
+    def reserve_workspace(self, n_vecs, stream):
+        check(lib().kn_reserve_workspace(self._h, int(n_vecs), stream))
 
     def plan(self, n_vecs, flags=0, ldx=None, ldy=None):
         """The kernels kn_spmm would launch for this batch width / flags (kn_spmm_plan): '; '-separated descriptions."""
         buf = ctypes.create_string_buffer(1024)
         check(lib().kn_spmm_plan(self._h, int(n_vecs), int(n_vecs if ldx is None else ldx), int(n_vecs if ldy is None else ldy), int(flags), buf, 1024))
         return buf.value.decode()
+
+
+def absmax(x_ptr, rows, ld, n_vecs, out_ptr, stream):
+    check(lib().kn_absmax(x_ptr, int(rows), int(ld), int(n_vecs), out_ptr, stream))
 
 
 def relu(y_ptr, rows, ld, n_vecs, stream):

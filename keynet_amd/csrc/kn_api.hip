@@ -612,8 +612,52 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
     });
 }
 
-int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, void* stream) {
-    return guarded([&]() -> int {
+// split-K partial-sum workspace of a dense operator for stream `s`, grown to `n_vecs` batch columns on demand.  The growing call is not
+// capturable in a HIP graph: run one eager forward per stream and batch size first (KeyedModel.capture does), or kn_reserve_workspace.
+static int dense_workspace(kn_handle_t h, hipStream_t s, int64_t n_vecs, float** out) {
+    const int64_t outs = h->rows - 1, S = h->dense_splits;
+    std::lock_guard<std::mutex> g(h->lazy_mu);
+    kn_operator::DenseWs& w = h->dense_ws[s];
+    if (w.vecs < n_vecs) {
+        // reap retired buffers whose last possible reader has finished, then retire this stream's outgrown one behind an event
+        for (size_t k = 0; k < h->dense_ws_retired.size();) {
+            kn_operator::Retired& r = h->dense_ws_retired[k];
+            if (r.done == nullptr || hipEventQuery(r.done) == hipSuccess) {
+                if (r.done) (void)hipEventDestroy(r.done);
+                (void)hipFree(r.ptr);
+                h->dense_ws_retired.erase(h->dense_ws_retired.begin() + (long)k);
+            } else {
+                k++;
+            }
+        }
+        (void)hipGetLastError();                            // hipEventQuery's hipErrorNotReady is not an error of this call
+        if (w.ptr) {
+            kn_operator::Retired r;
+            r.ptr = w.ptr;                                  // launches already queued on `s` may still use it
+            if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, s) != hipSuccess) {
+                if (r.done) (void)hipEventDestroy(r.done);
+                r.done = nullptr;
+                (void)hipStreamSynchronize(s);              // no event: wait for the stream, then the buffer is free at the next reap
+            }
+            h->dense_ws_retired.push_back(r);
+        }
+        w.ptr = nullptr;
+        w.vecs = 0;
+        hipError_t e = hipMalloc((void**)&w.ptr, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs);
+        if (e != hipSuccess) {
+            w.ptr = nullptr;
+            return fail(e == hipErrorOutOfMemory ? KN_ERR_NOMEM : KN_ERR_HIP, std::string("dense workspace hipMalloc: ") + hipGetErrorString(e) +
+                        " (during a HIP-graph capture: run one eager kn_spmm on the capture stream first, or call kn_reserve_workspace)");
+        }
+        w.vecs = n_vecs;
+    }
+    *out = w.ptr;
+    return KN_OK;
+}
+
+// kn_spmm / kn_spmm_screen.  `absmax` (device float or null): raised to max |Y| -- folded into the stores of the matrix-core kernels, one
+// extra pass over Y behind every other kernel family.
+static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, float* absmax, void* stream) {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
     KN_REQUIRE(n_vecs >= 0, KN_ERR_INVALID, "negative n_vecs");
     if (n_vecs == 0 || h->rows == 0) return KN_OK;
@@ -628,63 +672,64 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
         KN_HIP(hipGetDevice(&cur));
         KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one (create it under the device of x)");
     }
-    if (h->kind == KIND_CSR) return csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
-    if (h->kind == KIND_CHAIN) return chain_forward(h->chain, x_dev, ldx, n_vecs, y_dev, ldy, s);   // order-preserving by construction; ReLU flags were fixed at create
-    if (h->kind == KIND_DENSE) {
+    int rc = KN_OK;
+    bool fused = false;
+    if (h->kind == KIND_CSR) {
+        rc = csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    } else if (h->kind == KIND_CHAIN) {
+        rc = chain_forward(h->chain, x_dev, ldx, n_vecs, y_dev, ldy, s);   // order-preserving by construction; ReLU flags were fixed at create
+    } else if (h->kind == KIND_DENSE) {
         KN_REQUIRE(!(flags & KN_FLAG_EXACT), KN_ERR_UNSUPPORTED, "KN_FLAG_EXACT on a dense (MFMA) operator: create it with kn_csr_create instead");
         const int64_t outs = h->rows - 1, S = h->dense_splits;
         float* ws = nullptr;
         if (plan_sink() == nullptr) {
-            // partial-sum workspace of THIS stream, grown on demand (the growing call is not capturable in a HIP graph: run one
-            // eager forward per stream and batch size first, as KeyedModel.capture does)
-            std::lock_guard<std::mutex> g(h->lazy_mu);
-            kn_operator::DenseWs& w = h->dense_ws[s];
-            if (w.vecs < n_vecs) {
-                // reap retired buffers whose last possible reader has finished, then retire this stream's outgrown one behind an event
-                for (size_t k = 0; k < h->dense_ws_retired.size();) {
-                    kn_operator::Retired& r = h->dense_ws_retired[k];
-                    if (r.done == nullptr || hipEventQuery(r.done) == hipSuccess) {
-                        if (r.done) (void)hipEventDestroy(r.done);
-                        (void)hipFree(r.ptr);
-                        h->dense_ws_retired.erase(h->dense_ws_retired.begin() + (long)k);
-                    } else {
-                        k++;
-                    }
-                }
-                (void)hipGetLastError();                            // hipEventQuery's hipErrorNotReady is not an error of this call
-                if (w.ptr) {
-                    kn_operator::Retired r;
-                    r.ptr = w.ptr;                                  // launches already queued on `s` may still use it
-                    if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, s) != hipSuccess) {
-                        if (r.done) (void)hipEventDestroy(r.done);
-                        r.done = nullptr;
-                        (void)hipStreamSynchronize(s);              // no event: wait for the stream, then the buffer is free at the next reap
-                    }
-                    h->dense_ws_retired.push_back(r);
-                }
-                w.ptr = nullptr;
-                w.vecs = 0;
-                hipError_t e = hipMalloc((void**)&w.ptr, sizeof(float) * (size_t)(outs * S) * (size_t)n_vecs);
-                if (e != hipSuccess) {
-                    w.ptr = nullptr;
-                    return fail(e == hipErrorOutOfMemory ? KN_ERR_NOMEM : KN_ERR_HIP, std::string("dense workspace hipMalloc: ") + hipGetErrorString(e) +
-                                " (during a HIP-graph capture: run one eager kn_spmm on the capture stream first, or call kn_reserve_workspace)");
-                }
-                w.vecs = n_vecs;
-            }
-            ws = w.ptr;
+            rc = dense_workspace(h, s, n_vecs, &ws);
+            if (rc) return rc;
         }
-        int rc = convtaps_spmm(h->dense_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, ws, n_vecs, 0, s);
+        rc = convtaps_spmm(h->dense_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, ws, n_vecs, 0, s);
         if (rc) return rc;
-        return dense_reduce(ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
+        rc = dense_reduce(ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
+    } else {
+        // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
+        if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr && plan_sink() == nullptr) {
+            std::lock_guard<std::mutex> g(h->lazy_mu);           // bf16 planes of the taps, once (not capturable: like any first use)
+            rc = convtaps_build_bf16(h->ct, h->h_taps);
+            if (rc) return rc;
+        }
+        rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
     }
-    // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
-    if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr) {        // (also under kn_spmm_plan: the plan must say what a launch would do)
-        std::lock_guard<std::mutex> g(h->lazy_mu);           // bf16 planes of the taps, once (not capturable: like any first use)
-        int rc = convtaps_build_bf16(h->ct, h->h_taps);
-        if (rc) return rc;
-    }
-    return convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+    if (rc) return rc;
+    if (absmax && !fused) return absmax_pass(y_dev, h->rows, ldy, n_vecs, absmax, s);
+    return KN_OK;
+}
+
+int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, void* stream) {
+    return guarded([&]() -> int { return spmm_impl(h, x_dev, ldx, n_vecs, y_dev, ldy, flags, nullptr, stream); });
+}
+
+int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, float* y_absmax_dev, void* stream) {
+    return guarded([&]() -> int { return spmm_impl(h, x_dev, ldx, n_vecs, y_dev, ldy, flags, y_absmax_dev, stream); });
+}
+
+int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax_dev, void* stream) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(rows >= 0 && n_vecs >= 0, KN_ERR_INVALID, "negative size");
+    KN_REQUIRE(absmax_dev != nullptr && (x_dev || rows * n_vecs == 0), KN_ERR_INVALID, "NULL pointer");
+    KN_REQUIRE(ld >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
+    return absmax_pass(x_dev, rows, ld, n_vecs, absmax_dev, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
+int kn_reserve_workspace(kn_handle_t h, int64_t n_vecs, void* stream) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    KN_REQUIRE(n_vecs >= 0 && n_vecs < INT32_MAX, KN_ERR_INVALID, "n_vecs out of range");
+    if (h->kind != KIND_DENSE || n_vecs == 0) return KN_OK;      // only a dense operator keeps per-call state (its split-K partial sums)
+    int cur = -1;
+    KN_HIP(hipGetDevice(&cur));
+    KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one");
+    float* ws = nullptr;
+    return dense_workspace(h, reinterpret_cast<hipStream_t>(stream), n_vecs, &ws);
     });
 }
 

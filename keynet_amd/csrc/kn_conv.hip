@@ -53,7 +53,7 @@ __device__ __forceinline__ void kn_order() { __builtin_amdgcn_sched_barrier(0); 
 // that every row of the sub-tile exists (< Cout): the per-row test disappears for channel counts that fill the tile.
 template <int TM, int TN, bool ALL_ROWS = false>
 __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float* stage, const int lane, float* yp, const int64_t row_step_bytes,
-                                              const int m_first, const int Cout, const bool rows_ok, const int relu) {
+                                              const int m_first, const int Cout, const bool rows_ok, const int relu, float* absmax = nullptr) {
     // ReLU without a branch: clamp from below at 0, or at -inf (a no-op; NaN stays NaN either way).  ALL_ROWS (compile time: the
     // tile lies inside Cout) additionally removes the per-row test, so the 16 stores are straight-line code and a caller that
     // keeps loads in flight across them gets an exact counted vmcnt from the compiler instead of a drain.
@@ -63,6 +63,9 @@ __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float
     constexpr int RPI = 64 / LPR;                 // rows per wave-instruction
     const int rl = lane / LPR, c4 = lane % LPR;
     char* ypb = reinterpret_cast<char*>(yp);
+    // running max |y| of what this lane stores (kn_spmm_screen: the float-key contract re-screens every forward on the NEXT layer's
+    // max |x|): two v_max3_f32 with |.| source modifiers per 16-byte store, NaN operands ignored; rows beyond Cout are zero (zero-padded taps)
+    float am = 0.0f;
 #pragma unroll
     for (int i = 0; i < TM; i++) {
 #pragma unroll
@@ -80,12 +83,15 @@ __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float
                 v.y = (v.y < lo) ? lo : v.y;
                 v.z = (v.z < lo) ? lo : v.z;
                 v.w = (v.w < lo) ? lo : v.w;
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(am) : "v"(v.x), "v"(v.y));
+                asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(am) : "v"(v.z), "v"(v.w));
                 if (ALL_ROWS || rows_ok || m_first + i * 32 + 8 * g + rloc < Cout) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ypb));
                 ypb += row_step_bytes;            // next visited row: RPI rows further (also across g and i: 8 and 32 are multiples of RPI steps)
             }
             kn_wave_sync();
         }
     }
+    if (absmax) kn_wave_absmax_commit(am, absmax, lane);      // wave-uniform branch; one relaxed load (+ rarely an atomic) per tile
 }
 
 struct ConvArgs {
@@ -109,6 +115,7 @@ struct ConvArgs {
     int32_t sk_stride, sk_tab_rows;
     const uint16_t* tapsB;    // bf16x3 path: taps split into three bf16 planes (ConvTapsDev::tapsB), or null
     int64_t tapsB_plane;      // bytes between planes
+    float* absmax;            // kn_spmm_screen: device slot raised to max |Y| by the wide-store epilogue, or null
 #ifdef KN_ABLATION
     int32_t abl;           // diagnostic build only (tools/ablate_conv.sh): bit 0 no chunk barrier, 1 no LDS stores, 2 no global loads, 4 no pointer walk, 5 / 6 no tap / activation loads; bf16x3 kernel (tools/ablate_bf16x3.sh): 8 no split + activation stores, 9 no global loads, 10 no barrier, 11 no tap stores
 #endif
@@ -532,7 +539,7 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
         float* stage = lds + wave * (8 * COLS);       // [8 rows][COLS]  (all tile reads are behind the last barrier)
         float* yp = p.Y + ((int64_t)(m_first + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wn * COLS + (lane % LPR) * 4);
         const int64_t row_step_bytes = (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4;
-        kn_store_tile<TM, TN>(acc, stage, lane, yp, row_step_bytes, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu);
+        kn_store_tile<TM, TN>(acc, stage, lane, yp, row_step_bytes, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu, p.absmax);
         return;
     }
 #pragma unroll
@@ -834,7 +841,7 @@ __device__ __forceinline__ void convtaps_bf16x3_tile(const ConvArgs& p, const in
     constexpr int COLS = TN * 32, LPR = COLS / 4;
     float* stage = reinterpret_cast<float*>(lds) + wave * (8 * COLS);
     float* yp = p.Y + ((int64_t)(m_first + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wn * COLS + (lane % LPR) * 4);
-    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu);
+    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m_first, p.Cout, m_first + TM * 32 <= p.Cout, p.relu, p.absmax);
 }
 
 // Work items as in convtaps_mfma_kernel (contiguous chunks per XCD, Cout tile fastest).  TAIL: the items of a chunk beyond `tail_main` -- the last,
@@ -968,7 +975,7 @@ __global__ __launch_bounds__(256, 4) void convtaps_smallk_kernel(ConvArgs p) {
     constexpr int LPR = COLS / 4;
     float* stage = lds + wave * (8 * COLS);
     float* yp = p.Y + ((int64_t)(m0 + lane / LPR) * p.HoWo + o) * p.ldy + (b0 + wave * COLS + (lane % LPR) * 4);
-    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m0, p.Cout, m0 + TM * 32 <= p.Cout, p.relu);
+    kn_store_tile<TM, TN>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, m0, p.Cout, m0 + TM * 32 <= p.Cout, p.relu, p.absmax);
 }
 
 // ---- small-K path, persistent and software-pipelined ------------------------------------------------------------------------
@@ -1108,7 +1115,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_smallk_pipe_kernel(ConvArgs p
             const int o = __builtin_amdgcn_readlane(cur.x, 31);
             float* stage = lds + buf * KM * NB + wave * (8 * COLS);
             float* yp = p.Y + ((int64_t)(lane / LPR) * p.HoWo + o) * p.ldy + (cur.b0 + wave * COLS + (lane % LPR) * 4);
-            kn_store_tile<TM, TN, true>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, 0, p.Cout, true, p.relu);   // Cout == 64 on this path
+            kn_store_tile<TM, TN, true>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, 0, p.Cout, true, p.relu, p.absmax);   // Cout == 64 on this path
         }
         // ---- next pixel's rows -> the other buffer (their loads are older than the stores above: the wait leaves those in flight) ----
         stage_in(nxt, buf ^ 1);
@@ -1422,13 +1429,16 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
 
 // homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
 __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
-                                                           float* __restrict__ ylast, int64_t n_vecs, int relu) {
+                                                           float* __restrict__ ylast, int64_t n_vecs, int relu, float* absmax) {
     const float w = lastcol[out_last];
+    float am = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vecs; i += (int64_t)gridDim.x * blockDim.x) {
         float v = w * xlast[i];
         if (relu) v = (v < 0.0f) ? 0.0f : v;
         ylast[i] = v;
+        am = fmaxf(am, fabsf(v));
     }
+    if (absmax) kn_wave_absmax_commit(am, absmax, threadIdx.x & 63);     // the tile epilogues cover every other row (kn_spmm_screen)
 }
 
 void convtaps_free(ConvTapsDev& c) {
@@ -1550,12 +1560,13 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
 // Can this operator / operand take convtaps_bf16x3_kernel?  (The planes must exist: convtaps_build_bf16 at first use, kn_api.hip.)
 bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy) {
     const bool wide = A.Cout > 64;
-    return A.tapsB != nullptr && A.Cin % 16 == 0 && A.cin_pad == A.Cin && (wide ? (A.cout_pad % 128 == 0) : (A.cout_pad == 64)) && n_vecs > 0 && n_vecs % 128 == 0 &&
+    const bool planes = A.tapsB != nullptr || plan_sink() != nullptr;      // kn_spmm_plan allocates nothing: the first real kn_spmm builds the planes
+    return planes && A.Cin % 16 == 0 && A.cin_pad == A.Cin && (wide ? (A.cout_pad % 128 == 0) : (A.cout_pad == 64)) && n_vecs > 0 && n_vecs % 128 == 0 &&
            ldx % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)y) % 16 == 0 && A.max_slots <= MAX_FAST_SLOTS;
 }
 
 // Three bf16 planes of the taps, laid out as the kernel's LDS image: [plane][tap][channel chunk of 16][cout_pad][16 k], the two 8-k halves of
-// a row swapped on rows (cout) with bit 3 set.  Truncation split: w = h + m + l exactly.
+// a row swapped on rows (cout) with bit 3 set.  Round-to-nearest-even split at each step: w = h + m + l to 2^-27 |w|, the residuals r1, r2 exact.
 int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps /* [ntaps][Cout][Cin] */) {
     if (A.tapsB) return KN_OK;
     if (A.Cin % 16 != 0 || A.cin_pad != A.Cin || A.cout_pad % 64 != 0) return KN_OK;      // not eligible: nothing to build
@@ -1598,10 +1609,12 @@ int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps /* [ntaps
 }
 
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
-                  uint32_t flags, hipStream_t s) {
+                  uint32_t flags, hipStream_t s, float* absmax, bool* absmax_fused) {
     (void)rows;
     (void)cols;
     ConvArgs a;
+    a.absmax = nullptr;
+    if (absmax_fused) *absmax_fused = false;
     a.tapsT = A.tapsT;
     a.pix_ptr = A.pix_ptr;
     a.slot_in = A.slot_in;
@@ -1654,12 +1667,18 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
             KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
-                               x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+                               x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu, a.absmax);
         }
         KN_HIP(hipGetLastError());
         return KN_OK;
     }
     a.wide_store = (a.vec_ok && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0) ? 1 : 0;
+    // every matrix-core kernel below streams its tiles out through kn_store_tile when the stores are wide and the batch fills whole tiles
+    // (256 covers every tile width): then max |Y| rides in the epilogues (tiles + conv_lastrow_kernel for the homogeneous row)
+    if (absmax && a.wide_store && n_vecs % 256 == 0) {
+        a.absmax = absmax;
+        if (absmax_fused) *absmax_fused = true;
+    }
     a.max_slots = A.max_slots;
     a.ntaps = (int32_t)A.ntaps;
     a.last_in_row = A.Cin * A.Hin * A.Win;
@@ -1696,7 +1715,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         if (A.has_last) {
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
             KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
-                      x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+                      x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu, a.absmax);
         }
         KN_HIP(hipGetLastError());
         return KN_OK;
@@ -1730,7 +1749,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     if (A.has_last) {
         const int64_t out_last = A.Cout * A.Hout * A.Wout;
         KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
-                           x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu);
+                           x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu, a.absmax);
     }
     KN_HIP(hipGetLastError());
     return KN_OK;

@@ -125,6 +125,40 @@ __global__ __launch_bounds__(256) void lastrow_dev_kernel(const float* __restric
     if (threadIdx.x == 0) *maxdev = red[0];
 }
 
+// max |y| over [rows, n_vecs] (leading dimension ld) raised into *absmax (kn_absmax; kn_spmm_screen after kernels that do not fold it into
+// their stores).  NaN entries are ignored (max of the finite and infinite ones); grid-stride, 16 bytes per lane when the block is dense.
+__global__ __launch_bounds__(256) void absmax_kernel_v4(const float4* __restrict__ y, int64_t total4, float* __restrict__ absmax) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = y[i];
+        m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+        m = fmaxf(fmaxf(m, fabsf(v.z)), fabsf(v.w));
+    }
+    kn_wave_absmax_commit(m, absmax, threadIdx.x & 63);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ y, int64_t rows, int64_t ld, int64_t n_vecs, float* __restrict__ absmax) {
+    float m = 0.0f;
+    const int64_t total = rows * n_vecs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_vecs;
+        m = fmaxf(m, fabsf(y[r * ld + (i - r * n_vecs)]));
+    }
+    kn_wave_absmax_commit(m, absmax, threadIdx.x & 63);
+}
+
+int absmax_pass(const float* y, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax, hipStream_t s) {
+    if (rows <= 0 || n_vecs <= 0 || absmax == nullptr) return KN_OK;
+    if (ld == n_vecs && (rows * n_vecs) % 4 == 0 && ((uintptr_t)y) % 16 == 0) {
+        const int64_t total4 = rows * n_vecs / 4;
+        KN_LAUNCH("absmax_kernel_v4", absmax_kernel_v4, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 4096)), dim3(256), 0, s, reinterpret_cast<const float4*>(y), total4, absmax);
+    } else {
+        KN_LAUNCH("absmax_kernel", absmax_kernel, dim3((unsigned)std::min<int64_t>((rows * n_vecs + 255) / 256, 4096)), dim3(256), 0, s, y, rows, ld, n_vecs, absmax);
+    }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
 int linear_to_affine(const float* y, int64_t ldy, int64_t n, int64_t d, float* out, float* maxdev, hipStream_t s) {
     if (n <= 0) return KN_OK;
     if (d > 0) {

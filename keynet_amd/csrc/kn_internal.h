@@ -174,8 +174,26 @@ namespace kn {
 // kernels (kn_csr.hip / kn_conv.hip / kn_elementwise.hip)
 int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+// `absmax` (device float or null): when the launch takes a kernel whose epilogue can fold max |Y| into its stores, the slot is raised atomically
+// and *absmax_fused is set; otherwise the caller runs absmax_pass over Y afterwards (kn_spmm_screen)
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
-                  uint32_t flags, hipStream_t s);
+                  uint32_t flags, hipStream_t s, float* absmax = nullptr, bool* absmax_fused = nullptr);
+int absmax_pass(const float* y, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax, hipStream_t s);
+
+// Raise *slot (a non-negative f32 kept as its bit pattern: for such values unsigned order == float order) to the wavefront's max of `m`.
+// One relaxed load first: after the first few tiles of a launch almost no wavefront still has to issue the atomic.
+__device__ __forceinline__ void kn_wave_absmax_commit(float m, float* slot, int lane) {
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const float o = __shfl_xor(m, sft, 64);
+        m = (o > m) ? o : m;
+    }
+    if (lane == 0) {
+        const unsigned bits = __float_as_uint(m);
+        unsigned* u = reinterpret_cast<unsigned*>(slot);
+        if (bits > __atomic_load_n(u, __ATOMIC_RELAXED)) atomicMax(u, bits);
+    }
+}
 int relu_inplace(float* y, int64_t rows, int64_t ld, int64_t n_vecs, hipStream_t s);
 int dense_reduce(const float* z, int64_t ldz, int64_t outs, int64_t splits, const float* lastcol, const float* xlast, float* y, int64_t ldy, int64_t n_vecs,
                  int relu, hipStream_t s);
