@@ -906,10 +906,13 @@ def main():
     replay = knet.capture(x_cipher) if args.graph else None
 
     def step():
-        yl = (replay(x_cipher) if replay is not None else knet.forward_linear(x_cipher))[:, :-1]
         if not use_dist:
-            return yl
-        return kdist.gather_logits(yl, total=batch * world)     # RCCL all-gather over xGMI (gloo rigs bounce through the host)
+            return (replay(x_cipher) if replay is not None else knet.forward_linear(x_cipher))[:, :-1]
+        # N ranks: this rank's shard with the replicas' calibrated contracts kept in agreement (one tiny all-reduce per step for key-nets
+        # under the 'auto' contract, none otherwise: keynet_amd.dist.replicated_forward), then ONE RCCL all-gather of the logits over xGMI
+        # (gloo rigs bounce through the host)
+        yl = replay(x_cipher)[:, :-1] if replay is not None else kdist.replicated_forward(knet, x_cipher)
+        return kdist.gather_logits(yl, total=batch * world)
 
     def timed(n_warm, n_steps):
         for _ in range(n_warm):

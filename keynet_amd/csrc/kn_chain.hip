@@ -746,6 +746,14 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     }
     const size_t lds = (feat[0] + feat[1] + 1) * CHAIN_BT * sizeof(float);      // two activation buffers + the always-zero feature
     KN_REQUIRE(lds <= CHAIN_LDS_BYTES, KN_ERR_UNSUPPORTED, "activations of four batch columns do not fit the CU's 160 KiB of LDS");
+    {
+        // the kernel is written for gfx950's 160 KiB of LDS per workgroup: ask the device rather than assume (the caller falls back to one
+        // launch per layer on KN_ERR_UNSUPPORTED)
+        int dev = 0, max_lds = 0;
+        KN_HIP(hipGetDevice(&dev));
+        KN_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        KN_REQUIRE((size_t)max_lds >= CHAIN_LDS_BYTES, KN_ERR_UNSUPPORTED, "this device offers less than 160 KiB of LDS per workgroup: the whole-net kernel does not apply");
+    }
     std::unique_ptr<ChainDev, void (*)(ChainDev*)> c(new ChainDev(), chain_free);
     std::memset(&c->args, 0, sizeof(ChainArgs));
     for (int64_t l = 0; l < n_ops; l++) {

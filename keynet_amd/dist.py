@@ -62,5 +62,20 @@ def sharded_forward(knet, x_cipher_full):
     """Forward of this rank's shard of an [N, D0+1] encrypted batch + all-gather: returns [N, classes] logits on every rank."""
     (rank, ws) = world()
     xs = shard_batch(x_cipher_full, rank, ws)
-    y = knet.forward_linear(xs)[:, :-1]
-    return gather_logits(y, total=x_cipher_full.shape[0])
+    return gather_logits(replicated_forward(knet, xs), total=x_cipher_full.shape[0])
+
+
+def replicated_forward(knet, x_cipher_local):
+    """This rank's forward of ITS batch with the replicas' arithmetic kept identical: [n_local, classes] logits.
+    Collective when a process group is initialised and the key-net has layers decided by calibration (one all-reduce of one small integer
+    per keyed layer, KeyedModel.sync_contract): a layer that ANY rank's batch moved to the more conservative contract runs there on every
+    rank from this step on, and a rank whose decision changed recomputes its batch -- so every shard of the gathered result is what a
+    single process would have computed for those images with the final contracts (bench.py re-computes a peer's shard on rank 0 and
+    compares bit for bit).  Key-nets under declared contracts (exact=True / False everywhere) need and do no collective."""
+    y = knet.forward_linear(x_cipher_local)
+    if dist.is_available() and dist.is_initialized() and hasattr(knet, 'sync_contract') and any(r['calibration'] is not None or r['exact'] == 'auto' or r['declared'] == 'auto' for r in knet.contract_report()['layers']):
+        # exactly ONE collective per call on every rank (the condition above only looks at state that is replicated: which layers are under
+        # the calibrated contract); the recompute below is local
+        if knet.sync_contract():
+            y = knet.forward_linear(x_cipher_local)
+    return y[:, :-1]

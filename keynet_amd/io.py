@@ -9,9 +9,13 @@ Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_gold
     tiled:        shape, tileshape, blocks, tile_shapes, tile_ptr, tile_row, tile_col, tile_val
     conv2dtiled:  shape, inshape, outshape, tileshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias
     convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol [, tileshape]
-    L.<name>.exact                   (save_keynet only) the layer's arithmetic contract: True = the reference's accumulation order and
-                                     rounding, False = matrix cores, 'auto' = decided at the first forward (float-key tolerance 1e-5);
-                                     absent (golden files) = the default
+    L.<name>.exact                   (save_keynet only) the layer's arithmetic contract IN FORCE when it was saved, as a string: 'exact' = the
+                                     reference's accumulation order and rounding, 'mfma' = f32 matrix cores, 'bf16x3' = f32 products emulated
+                                     on the bf16 matrix pipe, 'auto' = not decided yet (float-key tolerance 1e-5, decided at the first forward);
+                                     absent (golden files) = the default.  (Older archives hold a bool, or the string 'auto'.)
+    L.<name>.exact_decl              (save_keynet only) the contract the layer was DECLARED with (what exact_mode(None) returns to)
+    L.<name>.contract_record         (save_keynet only) JSON of the calibration record behind a decided 'auto' layer (measured difference,
+                                     tolerance, the max |x| the decision covers): a loaded key-net keeps re-screening against it
     outshape                         (C,1,1) of the logits
     sensor.*                         (optional) the image key pair as stored-order CSR + 'sensor.inshape'
 
@@ -20,12 +24,13 @@ demo/keynet_challenge_lenet_10AUG20.pkl) into this container; it needs the refer
 container only.
 """
 from collections import OrderedDict
+import json
 import numpy as np
 import scipy.sparse
 from torch import nn
 
 from . import sparse as ksp
-from .layer import KeyedLayer
+from .layer import KeyedLayer, CONTRACTS, contract_name, _contract
 from .system import KeyedModel, KeyedSensor
 
 
@@ -98,18 +103,37 @@ def operator_to_arrays(W, p, out):
             out[p + k] = v
 
 
-def keynet_from_arrays(z):
-    """KeyedModel (public: no keys) from a neutral archive / golden file."""
+def _contract_from_array(a, what):
+    """'exact' / 'mfma' / 'auto' / 'bf16x3' (or a bool of an older archive) -> True / False / 'auto' / 'bf16x3'; anything else is refused."""
+    if a.dtype.kind in 'US':
+        v = str(a)
+        if v not in CONTRACTS:
+            raise ValueError('%s: unknown arithmetic contract "%s" (expected one of %s)' % (what, v, ', '.join(CONTRACTS)))
+        return _contract(v, True)
+    if a.dtype.kind == 'b':
+        return bool(a)
+    raise ValueError('%s: arithmetic contract must be a string or a bool, got dtype %s' % (what, a.dtype))
+
+
+def keynet_from_arrays(z, recalibrate=False):
+    """KeyedModel (public: no keys) from a neutral archive / golden file.  A layer saved with a DECIDED float-key contract comes back with
+    that decision and its calibration record (so replicas that load one file run the same kernels, and every forward keeps re-screening
+    against the recorded max |x|); `recalibrate=True` returns such layers to their declared contract instead ('auto': decided again on the
+    first batch seen here)."""
     layers = OrderedDict()
     for name in [str(n) for n in z['layer_names']]:
         p = 'L.%s.' % name
         if str(z[p + 'kind']) == 'relu':
             layers[name] = nn.ReLU()
         else:
-            exact = None
+            exact = _contract_from_array(z[p + 'exact'], p + 'exact') if (p + 'exact') in z.files else None
+            decl = _contract_from_array(z[p + 'exact_decl'], p + 'exact_decl') if (p + 'exact_decl') in z.files else exact
+            c = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']), exact=decl if recalibrate else exact)
             if (p + 'exact') in z.files:
-                exact = 'auto' if z[p + 'exact'].dtype.kind in 'US' else bool(z[p + 'exact'])
-            layers[name] = KeyedLayer.fromoperator(operator_from_arrays(z, p), str(z[p + 'layertype']), exact=exact)
+                c._exact_decl = decl
+                if not recalibrate and (p + 'contract_record') in z.files:
+                    c._contract_record = json.loads(str(z[p + 'contract_record']))
+            layers[name] = c
     last = [l for l in layers.values() if isinstance(l, KeyedLayer)][-1]
     outshape = tuple(int(v) for v in z['outshape']) if 'outshape' in z.files else (last.W.shape[0] - 1, 1, 1)
     return KeyedModel.fromlayers(layers, outshape)
@@ -131,8 +155,13 @@ def save_keynet(knet, filename, sensor=None):
         if isinstance(c, KeyedLayer):
             operator_to_arrays(c.W, p, out)
             out[p + 'layertype'] = np.array(c._layertype)
-            decl = getattr(c, '_exact_decl', getattr(c, '_exact', True))          # the declared contract ('auto' stays 'auto': re-decided where it is loaded)
-            out[p + 'exact'] = np.array('auto') if decl == 'auto' else np.array(bool(decl))
+            # the contract in force (a decided 'auto' layer is saved WITH its decision and the evidence: every loader then runs the same
+            # kernels -- load_keynet(recalibrate=True) decides again instead) and the declared one
+            out[p + 'exact'] = np.array(contract_name(getattr(c, '_exact', True)))
+            out[p + 'exact_decl'] = np.array(contract_name(getattr(c, '_exact_decl', getattr(c, '_exact', True))))
+            rec = getattr(c, '_contract_record', None)
+            if rec is not None:
+                out[p + 'contract_record'] = np.array(json.dumps(rec))
         else:
             out[p + 'kind'] = np.array('relu')
     if sensor is not None:
@@ -145,11 +174,12 @@ def save_keynet(knet, filename, sensor=None):
     return filename
 
 
-def load_keynet(filename, with_sensor=False):
+def load_keynet(filename, with_sensor=False, recalibrate=False):
     """KeyedModel from an archive written by save_keynet (or by tests/golden/import_pickle.py); `with_sensor` also returns the
-    KeyedSensor when the archive holds the image keys: (sensor, model) like the reference's factories."""
+    KeyedSensor when the archive holds the image keys: (sensor, model) like the reference's factories.  `recalibrate`: see
+    keynet_from_arrays."""
     z = np.load(filename, allow_pickle=False)
-    knet = keynet_from_arrays(z)
+    knet = keynet_from_arrays(z, recalibrate=recalibrate)
     if not with_sensor:
         return knet
     return (sensor_from_arrays(z) if 'sensor.shape' in z.files and 'sensor.inshape' in z.files else None, knet)

@@ -70,18 +70,47 @@ def _linear_operator(m, A, Ainv):
 
 def _contract(exact, bit_exact_default):
     """Arithmetic contract of a layer: True (the reference's order and rounding), False (matrix cores, float-key tolerance) or 'auto'
-    (decided at the first forward, KeyedLayer._calibrate).  None = True for untiled layers, 'auto' for tiled ones."""
+    (decided at the first forward and re-screened on every later one, KeyedLayer._calibrate / rescreen).  None = the default: True for
+    untiled layers and for layers keyed by permutations only (north_star: "bit-exact for the permutation-only key"), 'auto' for tiled
+    layers whose keys carry float coefficients ("within 1e-5 for float keyed layers").  Strings 'exact' / 'mfma' name True / False."""
     if exact is None:
         return True if bit_exact_default else 'auto'
     if isinstance(exact, str):
-        assert exact in ('auto', 'bf16x3'), "exact must be True, False, None, 'auto' or 'bf16x3'"
-        return exact
+        assert exact in CONTRACTS, "exact must be True, False, None or one of %s" % str(CONTRACTS)
+        return {'exact': True, 'mfma': False}.get(exact, exact)
     return bool(exact)
+
+
+CONTRACTS = ('exact', 'mfma', 'auto', 'bf16x3')
+
+
+def contract_name(c):
+    """True / False / 'auto' / 'bf16x3' -> 'exact' / 'mfma' / 'auto' / 'bf16x3' (the on-disk and reporting vocabulary)."""
+    return c if isinstance(c, str) else ('exact' if c else 'mfma')
+
+
+def _is_permutation_key(M):
+    """Is this key (scipy sparse, or None = no key on that side) a permutation matrix: one entry per row and column, every value
+    exactly 1?  Such keys only move entries around: the keyed operator holds the source weights themselves, nothing is scaled or mixed."""
+    if M is None:
+        return True
+    if not scipy.sparse.issparse(M) or M.shape[0] != M.shape[1] or M.nnz != M.shape[0]:
+        return False
+    C = M.tocoo()
+    n = M.shape[0]
+    return bool(np.all(C.data == 1) and len(np.unique(C.row)) == n and len(np.unique(C.col)) == n)
 
 
 FLOAT_KEY_TOL = 1e-5          # BASELINE north_star: "within 1e-5 for float keyed layers" (test/test_keynet.py:196,218 use the same figure)
 EPS32 = float(np.finfo(np.float32).eps)
 _log = logging.getLogger('keynet_amd')
+
+
+def _absmax_into(yt, slot):
+    """Raise the one-element device tensor `slot` to max |yt| (kn_absmax: one pass over a feature-major block)."""
+    yt = yt if yt.is_contiguous() else yt.contiguous()
+    with torch.cuda.device(yt.device):
+        _capi.absmax(yt.data_ptr(), yt.shape[0], yt.shape[1], yt.shape[1], slot.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
 class KeyedLayer(nn.Module):
@@ -101,7 +130,8 @@ class KeyedLayer(nn.Module):
         super(KeyedLayer, self).__init__()
         self._layertype = str(type(module))
         (self._inshape, self._outshape, self._tileshape) = (inshape, outshape, tileshape)
-        self._exact = self._exact_decl = _contract(exact, tileshape is None)
+        # default contract: bit-exact unless the layer is tiled AND one of its keys carries float coefficients
+        self._exact = self._exact_decl = _contract(exact, tileshape is None or exact is not None or (_is_permutation_key(A) and _is_permutation_key(Ainv)))
         if isinstance(module, nn.Conv2d):
             self._repr = 'Conv2d %d->%d, k=%s, s=%s' % (module.in_channels, module.out_channels, str(module.kernel_size), str(module.stride))
             W = _conv_operator(module, inshape, outshape, A, Ainv, tileshape, direct)
@@ -127,7 +157,10 @@ class KeyedLayer(nn.Module):
         """Wrap an already keyed operator (a public key-net loaded from a neutral file, a fixture, a direct build)."""
         self = cls.__new__(cls)
         nn.Module.__init__(self)
-        self._exact = self._exact_decl = _contract(exact, not isinstance(W, ksp.Conv2dTiledMatrix))
+        # default contract of a loaded operator: bit-exact unless it is a conv operator with float coefficients (a factored operator without
+        # coefficient entries was keyed by permutations; a block/tile description does not say, so it gets the float-key contract)
+        coef_free = isinstance(W, ksp.Conv2dTiledMatrix) and W._taps is not None and W._taps['ent_coef'] is None
+        self._exact = self._exact_decl = _contract(exact, coef_free or not isinstance(W, ksp.Conv2dTiledMatrix))
         (self._layertype, self._tileshape, self._inshape, self._outshape) = (layertype, None, inshape, outshape)
         self._repr = repr_ if repr_ is not None else layertype
         self.W = W if isinstance(W, SparseMatrix) else SparseMatrix(W)
@@ -139,17 +172,42 @@ class KeyedLayer(nn.Module):
     def iskeyedrelu(self):
         return 'ReLU' in self._layertype
 
-    def forward(self, x_affine, fuse_relu=False):
+    def forward(self, x_affine, fuse_relu=False, absmax=None):
         """[N, Din+1] -> [N, Dout+1] (keynet/layer.py:88-93).  The result is a transposed view of the feature-major
         [Dout+1, N] block the kernel wrote, so the next layer's x.t() is free.  `fuse_relu` folds the unkeyed nn.ReLU
-        that follows this layer in the key-net (keynet/system.py:92) into the kernel epilogue."""
+        that follows this layer in the key-net (keynet/system.py:92) into the kernel epilogue.  `absmax`: a one-element device
+        f32 tensor raised to max |y| of this call (kn_spmm_screen; KeyedModel.forward_linear re-screens the next layer's contract with it).
+        A layer whose contract is still 'auto' decides it here, on this batch (blocking host reads, an extra order-preserving launch:
+        not capturable into a HIP graph -- KeyedModel.capture runs an eager forward first)."""
         if verbose():
             print('[keynet_amd.layer]: forward %s' % str(self))
         exact = getattr(self, '_exact', True)
         if exact == 'auto':
-            return self._calibrate(x_affine, fuse_relu or self.iskeyedrelu())
-        y = self.W.torchdot(x_affine.t(), relu=(fuse_relu or self.iskeyedrelu()), exact=exact).t()
+            if x_affine.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise _capi.KeynetHipError('keynet_amd: %s has not decided its arithmetic contract yet (exact=\'auto\' calibrates on the first batch, with host reads): '
+                                           'run one eager forward before capturing a HIP graph (KeyedModel.capture does), or declare exact=True / False' % self._repr)
+            y = self._calibrate(x_affine, fuse_relu or self.iskeyedrelu())
+            if absmax is not None:
+                _absmax_into(y.t(), absmax)
+            return y
+        y = self.W.torchdot(x_affine.t(), relu=(fuse_relu or self.iskeyedrelu()), exact=exact, absmax=absmax).t()
         return y
+
+    # -- float-key contract: decided by calibration, re-screened on every forward --------------------------------------
+    RESCREEN_FACTOR = 2.0        # a layer is re-calibrated when max |x| exceeds the calibrated value by more than this factor
+
+    def screened(self):
+        """Runs this layer on a re-ordering kernel (matrix cores) BY A CALIBRATION DECISION?  Then every forward must check that the
+        decision still covers its input (a layer forced there with exact_mode(False) / 'bf16x3' is the caller's responsibility)."""
+        rec = getattr(self, '_contract_record', None)
+        return getattr(self, '_exact', True) in (False, 'bf16x3') and rec is not None and rec.get('max_abs_x') is not None
+
+    def rescreen(self, xmax):
+        """max |x| of a later batch against the calibrated one: True = the decision does not cover this batch (re-calibrate).  The measured
+        difference of a re-ordered f32 sum scales with the activations while the tolerance 1e-5 max(1, |y|) has a floor, so a decision
+        taken with 2x headroom (accepted at <= 0.5 tol) is kept for inputs up to RESCREEN_FACTOR x the calibrated magnitude."""
+        cal = float(self._contract_record['max_abs_x'])
+        return not (xmax <= self.RESCREEN_FACTOR * cal)          # also True for NaN
 
     def mfma_capable(self, device=None):
         """Does tolerance mode run this layer on the matrix cores at all (conv-taps operator, or a large dense nn.Linear)?"""
@@ -183,7 +241,9 @@ class KeyedLayer(nn.Module):
         if getattr(self, '_allow_bf16x3', False) and isinstance(W, ksp.Conv2dTiledMatrix):
             cols = min(int(xt.shape[1]), 256)
             xs = xt[:, :cols] if cols % 128 == 0 else None
-            if xs is not None and 'bf16x3' in W._device_op(dev).plan(cols, _capi.KN_FLAG_BF16X3 | (_capi.KN_FLAG_RELU if relu else 0)):
+            with torch.cuda.device(xt.device):
+                eligible = xs is not None and 'bf16x3' in W._device_op(dev).plan(cols, _capi.KN_FLAG_BF16X3 | (_capi.KN_FLAG_RELU if relu else 0))
+            if eligible:
                 yb = W.torchdot(xs, relu=relu, exact='bf16x3')
                 ye = W.torchdot(xs, relu=relu, exact=True)
                 (meas, ymax_b) = (float((ye - yb).abs().max()), float(ye.abs().max()))
@@ -191,7 +251,8 @@ class KeyedLayer(nn.Module):
                 del yb, ye
                 if meas <= 0.25 * tol_b:
                     self._exact = 'bf16x3'
-                    self._contract_record = dict(layer=self._repr, decided='bf16x3', measured_bf16x3_vs_exact=meas, tol=tol_b, max_abs_y=ymax_b, measured_on_columns=cols)
+                    self._contract_record = dict(layer=self._repr, decided='bf16x3', measured_bf16x3_vs_exact=meas, tol=tol_b, max_abs_y=ymax_b, measured_on_columns=cols,
+                                                 max_abs_x=float(xt.detach().abs().max()))
                     return W.torchdot(xt, relu=relu, exact='bf16x3').t()
         y = W.torchdot(xt, relu=relu, exact=False)
         asum = getattr(self, '_abs_rowsum', None)
@@ -206,7 +267,8 @@ class KeyedLayer(nn.Module):
             ye = W.torchdot(xt[:, :cols], relu=relu, exact=True)
             measured = float((ye - y[:, :cols].to(ye.device)).abs().max())
             del ye
-        switch = measured is not None and (measured > 0.5 * tol or (bound > tol and measured > 0.25 * tol))
+        # (a difference that is not finite -- Inf / NaN activations -- cannot be bounded: the reference's order it is)
+        switch = measured is not None and not (measured <= 0.5 * tol and (bound <= tol or measured <= 0.25 * tol))
         rec = dict(layer=self._repr, decided='exact' if switch else 'mfma', max_abs_rowsum=asum, max_abs_x=xmax, max_abs_y=ymax, tol=tol, bound=bound,
                    measured_mfma_vs_exact=measured, measured_on_columns=None if measured is None else min(int(xt.shape[1]), 256))
         self._exact = bool(switch)

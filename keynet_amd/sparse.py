@@ -59,7 +59,7 @@ def _on_device(W, attr, make, device=None):
     return cache[idx]
 
 
-def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0):
+def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0, absmax=None):
     """Y = W.X on the GPU.  x: torch tensor [cols, N] (any device / strides); get_op(device) -> the operator handle resident
     on that device.  Returns [rows, N] on x's device."""
     assert shape[1] == x.shape[0], 'Non-conformal shape for W=%s, x=%s' % (str(shape), str(tuple(x.shape)))
@@ -77,7 +77,7 @@ def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0):
     y = torch.empty((shape[0], n), dtype=torch.float32, device=xd.device)
     flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if exact else 0) | int(extra_flags)
     with torch.cuda.device(xd.device):
-        get_op(xd.device).spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr())
+        get_op(xd.device).spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr(), absmax_ptr=None if absmax is None else absmax.data_ptr())
     return y if src_device.type == 'cuda' else y.to(src_device)
 
 
@@ -139,15 +139,16 @@ class SparseMatrix(object):
             return False
         return _on_device(self, '_op_dense', make, device) or None
 
-    def torchdot(self, x_torch, relu=False, exact=True):
+    def torchdot(self, x_torch, relu=False, exact=True, absmax=None):
         """W . x for x of shape [W.shape[1], N]: the hot path (keynet/sparse.py:488-492).  exact=True (default): bit-exact
         with scipy (order-preserving CSR kernels).  exact=False: a large dense operator (keyed nn.Linear) may run as a
-        split-K f32-MFMA GEMM instead (within 1e-5; used by the tiled key-nets whose conv layers are on MFMA anyway)."""
+        split-K f32-MFMA GEMM instead (within 1e-5; used by the tiled key-nets whose conv layers are on MFMA anyway).
+        `absmax`: one-element device f32 tensor raised to max |W . x| (kn_spmm_screen)."""
         if exact == 'bf16x3':
             exact = False            # a dense operator has no bf16x3 path (yet): f32 matrix cores
         if not exact and torch.cuda.is_available() and self._dense_device_op(x_torch.device if x_torch.is_cuda else None) is not None:
-            return _run_torchdot(self._dense_device_op, self.shape, x_torch, relu=relu, exact=False)
-        return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True)
+            return _run_torchdot(self._dense_device_op, self.shape, x_torch, relu=relu, exact=False, absmax=absmax)
+        return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True, absmax=absmax)
 
     def dot(self, x_numpy):
         assert isinstance(x_numpy, np.ndarray)
@@ -261,11 +262,11 @@ class TiledMatrix(SparseMatrix):
             return _capi.Operator.tiled(self.shape, np.array(list(self), dtype=np.int64).reshape(-1, 3), ptr, tr, tc, tv)
         return _on_device(self, '_op', make, device)
 
-    def torchdot(self, x, relu=False, exact=True):
+    def torchdot(self, x, relu=False, exact=True, absmax=None):
         """[cols, N] -> [rows, N] (keynet/sparse.py:603-612); always the order-preserving path (bit-exact)."""
         if isinstance(x, np.ndarray):
             x = torch.as_tensor(x)
-        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=True)
+        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=True, absmax=absmax)
 
     def dot(self, x):
         assert isinstance(x, np.ndarray)
@@ -490,7 +491,7 @@ class Conv2dTiledMatrix(TiledMatrix):
             return _capi.Operator.conv2dtiled(self.shape, self._inshape, self._outshape, bl, tk, ib, ch, bs)
         return _on_device(self, '_op', make, device)
 
-    def torchdot(self, x, relu=False, exact=False):
+    def torchdot(self, x, relu=False, exact=False, absmax=None):
         """[cols, N] -> [rows, N].  exact=False: f32 MFMA path (f32-input matrix instructions, exact f32 products); exact=True: the
         reference's accumulation order and rounding (order-preserving kernel on the factored operator); exact='bf16x3': f32 products
         emulated on the bf16 matrix pipe (three-way exact split, six of nine cross products, f32 accumulate: KN_FLAG_BF16X3) where the
@@ -499,8 +500,8 @@ class Conv2dTiledMatrix(TiledMatrix):
             x = torch.as_tensor(x)
         if isinstance(exact, str):
             assert exact == 'bf16x3', "exact must be True, False or 'bf16x3'"
-            return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=False, extra_flags=_capi.KN_FLAG_BF16X3)
-        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=exact)
+            return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=False, extra_flags=_capi.KN_FLAG_BF16X3, absmax=absmax)
+        return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=exact, absmax=absmax)
 
     def _expand_taps_host(self, pixels=None, channels=None):
         """Canonical CSR of a factored operator -- or of its output rows (co, o) for o in `pixels` only, numbered

@@ -75,6 +75,72 @@ def worker(rank, world_size, port, kind, n, q, backend='gloo'):
         dist.destroy_process_group()
 
 
+def contract_worker(rank, world_size, port, mode, q):
+    """Replicated key-nets whose calibration decisions differ between ranks (each rank calibrates on ITS batches) must end up running the
+    same kernels: KeyedModel.sync_contract (one all-reduce: the most conservative decision per layer wins).
+    mode 'host' (CPU box): the decisions are planted, no forward runs.  mode 'device' (two ranks sharing cuda:0, real kernels): a float-key
+    mini-net under the 'auto' contract; rank 1's images are 300x larger than rank 0's, so only ITS data can trip a layer's tolerance screen."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    try:
+        from keynet_amd import io as kio
+        from keynet_amd.layer import KeyedLayer
+        z = np.load(os.path.join(HERE, 'golden', 'mini_tiled_orthogonal.npz'), allow_pickle=False)
+        if mode == 'host':
+            knet = kio.keynet_from_arrays(z)
+            plant = [{'conv1': (False, {'decided': 'mfma', 'max_abs_x': 2.0}), 'conv2': ('bf16x3', {'decided': 'bf16x3', 'max_abs_x': 3.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)},
+                     {'conv1': (True, {'decided': 'exact', 'bound': 1.0}), 'conv2': (False, {'decided': 'mfma', 'max_abs_x': 9.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)}][rank]
+            for (n, c) in knet._keynet.named_children():
+                if isinstance(c, KeyedLayer):
+                    (c._exact, rec) = plant[n]
+                    if rec is not None:
+                        c._contract_record = rec
+            changed = knet.sync_contract()
+            state = {n: c._exact for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)}
+            again = knet.sync_contract()                       # agreed: a second round changes nothing anywhere
+            q.put((rank, changed, state, again, knet.conv1.screened(), knet.conv2.screened()))
+            return
+        import warnings
+        from keynet_amd import system as ksys
+        from nets import MiniNet, load_weights
+        net = load_weights(MiniNet(), z)
+        np.random.seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4)
+        dev = torch.device('cuda:0')
+        g = torch.Generator(device=dev).manual_seed(3)
+        x = torch.randn((16, 2, 16, 16), generator=g, device=dev)
+        x[8:] *= 300.0                                          # rank 1's half
+        xc = sensor.fromtensor(x).encrypt().astensor()
+        y = kdist.sharded_forward(knet, xc)                     # local forward (calibrates on this rank's shard) + sync_contract + all-gather
+        state = {n: c._exact for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)}
+        (lo, hi) = kdist.shard_bounds(16, rank, world_size)
+        mine = knet.forward_linear(xc[lo:hi])[:, :-1]           # this rank's shard again, under the agreed contracts
+        own = bool(torch.equal(y[lo:hi], mine))
+        # the peer's shard recomputed here (what bench.py's collective record does on rank 0): replicas are bit-identical
+        (plo, phi) = kdist.shard_bounds(16, 1 - rank, world_size)
+        peer = bool(torch.equal(y[plo:phi], knet.forward_linear(xc[plo:phi])[:, :-1]))
+        q.put((rank, state, own, peer, knet.contract_report()['switched']))
+    finally:
+        dist.destroy_process_group()
+
+
+def run_contract(mode, world_size=2, timeout=300):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=contract_worker, args=(r, world_size, port, mode, q)) for r in range(world_size)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=timeout) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
 def run(kind, n, world_size=2, timeout=300, backend='gloo'):
     ctx = mp.get_context('spawn')        # fresh processes: a forked child must never inherit an initialised GPU runtime
     q = ctx.Queue()

@@ -44,38 +44,97 @@ def test_max_abs_rowsum_equals_the_expanded_operator(golden, direct):
     assert n == 5
 
 
+def _float_mini(golden, **kw):
+    """The same mini-net under a key family WITH float coefficients (block permutation + photometric gain)."""
+    z = golden('mini_tiled_permutation.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    return ksys.Keynet((2, 16, 16), net, local_geometric='permutation', local_photometric='uniform_random_gain', beta=0.5, tileshape=(4, 4), blocksize=4, **kw)
+
+
 def test_contract_states_and_transitions(golden):
     assert _contract(None, True) is True and _contract(None, False) == 'auto'
     assert _contract(True, False) is True and _contract(False, True) is False and _contract('auto', True) == 'auto' and _contract('bf16x3', True) == 'bf16x3'
+    assert _contract('exact', False) is True and _contract('mfma', True) is False
     with pytest.raises(AssertionError):
         _contract('fast', True)
-    (sensor, knet) = _mini(golden)
+    # north_star: "bit-exact for the permutation-only key, within 1e-5 for float keyed layers" -- a tiled key-net whose keys are permutations
+    # (TiledPermutationKeynet, TiledIdentityKeynet) is bit-exact BY DEFAULT; the matrix cores are an explicit opt-in (exact='auto' / False)
+    for factory in (ksys.TiledPermutationKeynet, ksys.TiledIdentityKeynet):
+        (_, kperm) = _mini(golden, factory=factory)
+        assert all(c._exact is True for c in kperm._keynet.children() if isinstance(c, KeyedLayer)), factory.__name__
+        assert kperm.contract_report()['undecided'] == []
+    # float keys: decided per layer at the first forward
+    (sensor, knet) = _float_mini(golden)
     layers = [c for c in knet._keynet.children() if isinstance(c, KeyedLayer)]
-    assert all(c._exact == 'auto' for c in layers)                                 # tiled key-nets: decided at the first forward
+    assert all(c._exact == 'auto' for c in layers)
     assert set(knet.contract_report()['undecided']) == {'conv1', 'pool1', 'conv2', 'pool2', 'fc1'}
     knet.exact_mode(True)
     assert all(c._exact is True for c in layers)
     knet.exact_mode(False)
-    assert all(c._exact is False for c in layers)
+    assert all(c._exact is False for c in layers) and not any(c.screened() for c in layers)     # forced: the caller's responsibility, never screened
     knet.exact_mode('auto-bf16x3')
     assert all(c._exact == 'auto' and c._allow_bf16x3 for c in layers)
     knet.exact_mode(None)
     assert all(c._exact == 'auto' and not c._allow_bf16x3 for c in layers)
+    # the opt-in on a permutation-only key-net, and back
+    (_, kp4) = _mini(golden, exact='auto')
+    assert all(c._exact == 'auto' for c in kp4._keynet.children() if isinstance(c, KeyedLayer))
+    (_, kp5) = _mini(golden)
+    kp5.exact_mode('auto')
+    assert all(c._exact == 'auto' for c in kp5._keynet.children() if isinstance(c, KeyedLayer))
+    kp5.exact_mode(None)
+    assert all(c._exact is True for c in kp5._keynet.children() if isinstance(c, KeyedLayer))
     (_, kp) = ksys.PermutationKeynet((2, 16, 16), load_weights(MiniNet(), golden('mini_tiled_permutation.npz')))
     assert all(c._exact is True for c in kp._keynet.children() if isinstance(c, KeyedLayer))      # untiled: bit-exact by default
     (_, kf) = _mini(golden, exact=False)
     assert all(c._exact is False for c in kf._keynet.children() if isinstance(c, KeyedLayer))
 
 
+def test_rescreen_rule():
+    """KeyedLayer.rescreen: a calibrated decision covers inputs up to RESCREEN_FACTOR x the calibrated max |x|; NaN never passes."""
+    c = KeyedLayer.__new__(KeyedLayer)
+    torch.nn.Module.__init__(c)
+    (c._exact, c._contract_record) = (False, {'decided': 'mfma', 'max_abs_x': 4.0})
+    assert c.screened()
+    assert not c.rescreen(4.0) and not c.rescreen(7.9) and not c.rescreen(0.0)
+    assert c.rescreen(8.1) and c.rescreen(float('inf')) and c.rescreen(float('nan'))
+    c._exact = True
+    assert not c.screened()
+    (c._exact, c._contract_record) = (False, None)
+    assert not c.screened()                                        # forced onto the matrix cores: not a calibration decision
+
+
 def test_contract_survives_the_neutral_file_format(golden, tmp_path):
-    (sensor, knet) = _mini(golden)
-    knet.conv2._exact = False              # pretend calibration decided: the DECLARED contract ('auto') is what is saved
+    (sensor, knet) = _float_mini(golden)
+    # pretend calibration decided: the DECISION and its evidence are saved (replicas loading one file run the same kernels), the declared
+    # contract rides along, and recalibrate=True returns to it
+    (knet.conv2._exact, knet.conv2._contract_record) = (False, {'decided': 'mfma', 'max_abs_x': 3.5, 'measured_mfma_vs_exact': 1e-7, 'tol': 1e-5})
+    (knet.conv1._exact, knet.conv1._contract_record) = ('bf16x3', {'decided': 'bf16x3', 'max_abs_x': 2.0})
+    (knet.fc1._exact, knet.fc1._contract_record) = (True, {'decided': 'exact', 'bound': 1.0})
     f = kio.save_keynet(knet, str(tmp_path / 'k.npz'), sensor=sensor)
     k2 = kio.load_keynet(f)
-    assert k2.conv2._exact == 'auto' and k2.pool1._exact == 'auto'
+    assert k2.conv2._exact is False and k2.conv2.screened() and k2.conv2._contract_record['max_abs_x'] == 3.5
+    assert k2.conv1._exact == 'bf16x3' and k2.conv1.screened()
+    assert k2.fc1._exact is True and k2.pool1._exact == 'auto'
+    assert all(getattr(k2, n)._exact_decl == 'auto' for n in ('conv1', 'conv2', 'fc1', 'pool1'))
+    k2.exact_mode(None)
+    assert k2.conv2._exact == 'auto'
+    k2r = kio.load_keynet(f, recalibrate=True)
+    assert all(getattr(k2r, n)._exact == 'auto' for n in ('conv1', 'conv2', 'fc1', 'pool1')) and not k2r.conv2.screened()
     (_, kx) = _mini(golden, exact=True)
     k3 = kio.load_keynet(kio.save_keynet(kx, str(tmp_path / 'x.npz')))
     assert k3.conv1._exact is True
+    # older archives (a bool, or the string 'auto') still load; anything else is refused
+    z = dict(np.load(f, allow_pickle=False))
+    z['L.conv2.exact'] = np.array(True)
+    del z['L.conv2.exact_decl']
+    np.savez(str(tmp_path / 'old.npz'), **z)
+    assert kio.load_keynet(str(tmp_path / 'old.npz')).conv2._exact is True
+    z['L.conv2.exact'] = np.array('fastest')
+    np.savez(str(tmp_path / 'bad.npz'), **z)
+    with pytest.raises(ValueError, match='unknown arithmetic contract'):
+        kio.load_keynet(str(tmp_path / 'bad.npz'))
 
 
 def test_chain_and_plan_argument_validation():
@@ -98,5 +157,5 @@ def test_keyed_model_pickles_without_device_state(golden):
     knet.__dict__['_chain_ops'] = {0: ((), ctypes.c_void_p(1))}          # what a forward would have cached (not picklable)
     (s2, k2) = pickle.loads(pickle.dumps((sensor, knet)))
     assert '_chain_ops' not in k2.__dict__ and '_overlap_plans' not in k2.__dict__
-    assert k2.conv1._exact == 'auto' and tuple(k2.conv1.W.shape) == tuple(knet.conv1.W.shape) and k2._outshape == knet._outshape
+    assert k2.conv1._exact is True and tuple(k2.conv1.W.shape) == tuple(knet.conv1.W.shape) and k2._outshape == knet._outshape
     assert (s2._encryptkey != sensor._encryptkey).nnz == 0

@@ -21,3 +21,15 @@ def test_shard_bounds_cover_and_balance():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(ws - 1))
             sizes = [hi - lo for (lo, hi) in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_calibration_decisions_are_made_collective():
+    """Ranks that calibrated on different batches agree after KeyedModel.sync_contract: per layer the most conservative decision wins
+    (bf16x3 < mfma < exact), only the ranks whose decision was less conservative change, and a second round is a no-op."""
+    res = dist_harness.run_contract('host')
+    ((_, ch0, st0, again0, s1_0, s2_0), (_, ch1, st1, again1, s1_1, s2_1)) = res
+    assert st0 == st1 == {'conv1': True, 'pool1': True, 'conv2': False, 'pool2': True, 'fc1': True}
+    assert sorted(ch0) == ['conv1', 'conv2'] and ch1 == []
+    assert again0 == [] and again1 == []
+    assert not s1_0 and not s1_1                 # conv1 runs in the reference's order everywhere: nothing left to screen
+    assert s2_0 and s2_1                         # conv2 stays on the matrix cores, still screened against each rank's own calibration

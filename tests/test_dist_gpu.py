@@ -25,6 +25,17 @@ def test_real_keynet_sharded_over_two_ranks(kind, n):
     assert all(r[3][0] == n and r[4].startswith('cuda') for r in res)
 
 
+def test_one_ranks_data_trips_the_contract_for_all():
+    """Float-key mini-net under the 'auto' contract on two ranks; rank 1's images are 300x larger.  After sharded_forward both ranks run
+    every layer under the same contract, each rank's shard of the gathered logits equals its own forward under those contracts, and the
+    PEER's shard recomputed locally is bit-equal too (replicas stay bit-identical: what bench.py's collective record asserts)."""
+    res = dist_harness.run_contract('device')
+    ((_, st0, own0, peer0, sw0), (_, st1, own1, peer1, sw1)) = res
+    assert st0 == st1, (st0, st1)
+    assert all(v in (True, False) for v in st0.values())
+    assert own0 and own1 and peer0 and peer1, res
+
+
 def test_bench_starts_its_own_ranks():
     env = dict(os.environ, KN_BENCH_SHARE_GPU='1')
     env.pop('WORLD_SIZE', None)

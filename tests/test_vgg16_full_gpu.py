@@ -21,7 +21,9 @@ def vgg():
     torch.manual_seed(0)
     net = VGG16(num_classes=2622).eval()
     np.random.seed(0)
-    (sensor, knet) = ksys.TiledPermutationKeynet((3, 224, 224), net, 64)
+    # exact='auto': the explicit opt-in to the matrix cores (BASELINE configs[3]: "MFMA dense sub-tiles"); the default contract of a
+    # permutation-only key-net is bit-exact (tests/test_contract_gpu.py), and exact_mode(True) below exercises exactly those kernels
+    (sensor, knet) = ksys.TiledPermutationKeynet((3, 224, 224), net, 64, exact='auto')
     return (net, sensor, knet)
 
 
