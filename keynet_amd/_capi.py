@@ -41,10 +41,12 @@ def lib():
         # PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7, the same as /opt/rocm's).  It must be in the
         # process BEFORE this library is loaded so both bind to ONE HIP runtime; loaded the other way round the process
         # ends up with two runtimes and the second one sees no device.
-        import torch
-        hip_rt = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
-        if os.path.exists(hip_rt):
-            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
+        # (KEYNET_HIP_NO_TORCH=1: the host-only sanitizer build of tests/test_host_sanitize.py, which has no device side to share)
+        if os.environ.get('KEYNET_HIP_NO_TORCH') != '1':
+            import torch
+            hip_rt = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+            if os.path.exists(hip_rt):
+                ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         L = ctypes.CDLL(LIBPATH)
         (i64, p, u32, ci) = (ctypes.c_int64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int)
         L.kn_abi_version.restype = ci

@@ -16,15 +16,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, out=None, defines=()):
+def build(force=False, verbose=False, out=None, defines=(), extra=()):
     """hipcc --offload-arch=gfx950 ... -> keynet_amd/libkeynet_hip.so.  -ffp-contract=off: the order-preserving kernels
     must round the product and the sum separately (bit-exact with scipy's csr_matvecs).  `out` / `defines`: diagnostic variants
-    (tools/ablate_conv.sh builds one with -DKN_ABLATION next to the product library; nothing loads it by default)."""
+    (tools/ablate_conv.sh builds one with -DKN_ABLATION next to the product library; tests/test_host_sanitize.py builds the host side with
+    -DKN_HOST_PACK_ONLY and `extra` = the sanitizer flags; nothing loads either by default)."""
     if out is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get('HIPCC', 'hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-           '-Wall', '-Wextra', '-Wno-unused-parameter'] + ['-D' + d for d in defines] + ['-o', out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           '-Wall', '-Wextra', '-Wno-unused-parameter'] + list(extra) + ['-D' + d for d in defines] + ['-o', out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

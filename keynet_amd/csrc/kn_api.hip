@@ -360,7 +360,11 @@ int kn_conv2dtiled_create(int64_t rows, int64_t cols, const int64_t inshape[3], 
     return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
+    KN_REQUIRE(rows >= 0 && cols >= 0 && nblocks >= 0 && nent >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE(inshape && outshape && (nblocks == 0 || blocks) && (nent == 0 || (tile_keys && tile_isbias)), KN_ERR_INVALID, "NULL argument");
+    for (int k = 0; k < 3; k++)
+        KN_REQUIRE(inshape[k] > 0 && outshape[k] > 0 && inshape[k] < INT32_MAX && outshape[k] < INT32_MAX, KN_ERR_INVALID, "inshape / outshape entries must be positive");
+    KN_REQUIRE(rows < INT32_MAX && cols < INT32_MAX, KN_ERR_UNSUPPORTED, "int32 index range exceeded");
     const int64_t Cin = inshape[0], HiWi = inshape[1] * inshape[2], Cout = outshape[0], HoWo = outshape[1] * outshape[2];
     const bool has_last = (rows == Cout * HoWo + 1);
     KN_REQUIRE(rows == Cout * HoWo + (has_last ? 1 : 0) && cols == Cin * HiWi + (has_last ? 1 : 0), KN_ERR_SHAPE,
@@ -442,7 +446,9 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int6
         b.outshape[k] = outshape[k];
     }
     const int64_t Cout = outshape[0], Cin = inshape[0];
-    KN_REQUIRE(Cout > 0 && Cin > 0, KN_ERR_INVALID, "non-positive channels");
+    for (int k = 0; k < 3; k++)
+        KN_REQUIRE(inshape[k] > 0 && outshape[k] > 0 && inshape[k] < INT32_MAX && outshape[k] < INT32_MAX, KN_ERR_INVALID, "inshape / outshape entries must be positive");
+    KN_REQUIRE(Cout * outshape[1] * outshape[2] < INT32_MAX && Cin * inshape[1] * inshape[2] < INT32_MAX, KN_ERR_UNSUPPORTED, "int32 index range exceeded");
     b.taps.assign(taps, taps + (size_t)(ntaps * Cout * Cin));
     b.ent_out.assign(ent_out, ent_out + nent);
     b.ent_in.assign(ent_in, ent_in + nent);
@@ -659,6 +665,7 @@ static int dense_workspace(kn_handle_t h, hipStream_t s, int64_t n_vecs, float**
 // extra pass over Y behind every other kernel family.
 static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, float* absmax, void* stream) {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    if (plan_sink() == nullptr) KN_HOST_ONLY_GUARD();
     KN_REQUIRE(n_vecs >= 0, KN_ERR_INVALID, "negative n_vecs");
     if (n_vecs == 0 || h->rows == 0) return KN_OK;
     KN_REQUIRE(x_dev && y_dev, KN_ERR_INVALID, "NULL activation pointer");
@@ -713,6 +720,7 @@ int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vec
 
 int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax_dev, void* stream) {
     return guarded([&]() -> int {
+    KN_HOST_ONLY_GUARD();
     KN_REQUIRE(rows >= 0 && n_vecs >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE(absmax_dev != nullptr && (x_dev || rows * n_vecs == 0), KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ld >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
@@ -751,6 +759,7 @@ int kn_spmm_plan(kn_handle_t h, int64_t n_vecs, int64_t ldx, int64_t ldy, uint32
 
 int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream) {
     return guarded([&]() -> int {
+    KN_HOST_ONLY_GUARD();
     KN_REQUIRE(y_dev || rows * n_vecs == 0, KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ld >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
     return relu_inplace(y_dev, rows, ld, n_vecs, reinterpret_cast<hipStream_t>(stream));
@@ -759,6 +768,7 @@ int kn_relu(float* y_dev, int64_t rows, int64_t ld, int64_t n_vecs, void* stream
 
 int kn_affine_to_linear(const float* x_dev, int64_t n, int64_t d, float* out_dev, int64_t ldo, void* stream) {
     return guarded([&]() -> int {
+    KN_HOST_ONLY_GUARD();
     KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE((x_dev || n * d == 0) && (out_dev || n == 0), KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ldo >= n, KN_ERR_SHAPE, "leading dimension smaller than n");
@@ -768,6 +778,7 @@ int kn_affine_to_linear(const float* x_dev, int64_t n, int64_t d, float* out_dev
 
 int kn_linear_to_affine(const float* y_dev, int64_t ldy, int64_t n, int64_t d, float* out_dev, float* maxdev_dev, void* stream) {
     return guarded([&]() -> int {
+    KN_HOST_ONLY_GUARD();
     KN_REQUIRE(n >= 0 && d >= 0, KN_ERR_INVALID, "negative size");
     KN_REQUIRE((y_dev || n == 0) && (out_dev || n * d == 0), KN_ERR_INVALID, "NULL pointer");
     KN_REQUIRE(ldy >= n, KN_ERR_SHAPE, "leading dimension smaller than n");

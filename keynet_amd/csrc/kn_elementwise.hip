@@ -137,6 +137,25 @@ __global__ __launch_bounds__(256) void absmax_kernel_v4(const float4* __restrict
     kn_wave_absmax_commit(m, absmax, threadIdx.x & 63);
 }
 
+// a column window of a wider block (ld > n_vecs: the half-batch windows of the overlapped forward), 16 bytes per lane: `tpr` threads walk one
+// row's n_vecs / 4 quads, 256 / tpr rows per workgroup step -- one 32-bit division per thread, none per element
+__global__ __launch_bounds__(256) void absmax_kernel_win4(const float* __restrict__ y, int64_t rows, int64_t ld, int n4, int tpr, float* __restrict__ absmax) {
+    const int rpb = 256 / tpr;
+    const int tr = (int)threadIdx.x / tpr, tc = (int)threadIdx.x - tr * tpr;
+    float m = 0.0f;
+    if (tr < rpb) {
+        for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < rows; r += (int64_t)gridDim.x * rpb) {
+            const float4* row = reinterpret_cast<const float4*>(y + r * ld);
+            for (int c = tc; c < n4; c += tpr) {
+                const float4 v = row[c];
+                m = fmaxf(fmaxf(m, fabsf(v.x)), fabsf(v.y));
+                m = fmaxf(fmaxf(m, fabsf(v.z)), fabsf(v.w));
+            }
+        }
+    }
+    kn_wave_absmax_commit(m, absmax, threadIdx.x & 63);
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ y, int64_t rows, int64_t ld, int64_t n_vecs, float* __restrict__ absmax) {
     float m = 0.0f;
     const int64_t total = rows * n_vecs;
@@ -149,9 +168,16 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ y
 
 int absmax_pass(const float* y, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax, hipStream_t s) {
     if (rows <= 0 || n_vecs <= 0 || absmax == nullptr) return KN_OK;
-    if (ld == n_vecs && (rows * n_vecs) % 4 == 0 && ((uintptr_t)y) % 16 == 0) {
+    const bool a16 = ((uintptr_t)y) % 16 == 0;
+    if (ld == n_vecs && (rows * n_vecs) % 4 == 0 && a16) {
         const int64_t total4 = rows * n_vecs / 4;
         KN_LAUNCH("absmax_kernel_v4", absmax_kernel_v4, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 4096)), dim3(256), 0, s, reinterpret_cast<const float4*>(y), total4, absmax);
+    } else if (n_vecs % 4 == 0 && ld % 4 == 0 && a16) {
+        const int n4 = (int)(n_vecs / 4);
+        int tpr = 1;
+        while (tpr < n4 && tpr < 256) tpr <<= 1;                  // threads per row: a power of two >= the row's quads (<= 256)
+        const int rpb = 256 / tpr;
+        KN_LAUNCH("absmax_kernel_win4", absmax_kernel_win4, dim3((unsigned)std::min<int64_t>((rows + rpb - 1) / rpb, 8192)), dim3(256), 0, s, y, rows, ld, n4, tpr, absmax);
     } else {
         KN_LAUNCH("absmax_kernel", absmax_kernel, dim3((unsigned)std::min<int64_t>((rows * n_vecs + 255) / 256, 4096)), dim3(256), 0, s, y, rows, ld, n_vecs, absmax);
     }

@@ -11,6 +11,61 @@
 #include <memory>
 #include "../../include/keynet_hip.h"
 
+#ifdef KN_HOST_PACK_ONLY
+// DIAGNOSTIC BUILD ONLY (tests/test_host_sanitize.py; never the product library): the HOST side of this library -- validation of
+// caller-sized arrays, the std::vector index work that packs the reference's containers into the device formats, export, destroy --
+// compiled with -fsanitize=address,undefined and run on a box WITHOUT a GPU.  "Device" memory is host heap here, so every create path
+// runs to completion under the sanitizers (the packing loops, the copies INTO the packed buffers and the frees included); every compute
+// entry point returns KN_ERR_NODEVICE before touching anything.
+#include <cstdlib>
+#include <cstring>
+namespace kn {
+namespace hostonly {
+inline hipError_t Malloc(void** p, size_t n) {
+    *p = std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t Free(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+inline hipError_t Memcpy(void* d, const void* s, size_t n, hipMemcpyKind) {
+    std::memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t Memset(void* d, int v, size_t n) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t GetDeviceCount(int* n) {
+    *n = 1;
+    return hipSuccess;
+}
+inline hipError_t GetDevice(int* d) {
+    *d = 0;
+    return hipSuccess;
+}
+inline hipError_t DeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
+    *v = 160 * 1024;
+    return hipSuccess;
+}
+inline hipError_t Ok() { return hipSuccess; }
+}  // namespace hostonly
+}  // namespace kn
+#define hipMalloc(p, n) kn::hostonly::Malloc((void**)(p), (n))
+#define hipFree(p) kn::hostonly::Free((void*)(p))
+#define hipMemcpy(d, s, n, k) kn::hostonly::Memcpy((void*)(d), (const void*)(s), (n), (k))
+#define hipMemset(d, v, n) kn::hostonly::Memset((void*)(d), (v), (n))
+#define hipGetDeviceCount(n) kn::hostonly::GetDeviceCount(n)
+#define hipGetDevice(d) kn::hostonly::GetDevice(d)
+#define hipDeviceGetAttribute(v, a, d) kn::hostonly::DeviceGetAttribute((v), (a), (d))
+#define hipFuncSetAttribute(f, a, v) kn::hostonly::Ok()
+#define hipGetLastError() kn::hostonly::Ok()
+#define KN_HOST_ONLY_GUARD() return kn::fail(KN_ERR_NODEVICE, "KN_HOST_PACK_ONLY diagnostic build: no compute entry point runs")
+#else
+#define KN_HOST_ONLY_GUARD() do { } while (0)
+#endif
+
 namespace kn {
 
 void set_error(const std::string& msg);

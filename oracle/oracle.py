@@ -43,7 +43,7 @@ def build(force=False):
 def _lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        L = ctypes.CDLL(os.environ.get('KN_ORACLE_LIB') or build())     # KN_ORACLE_LIB: another BUILD of kn_oracle.c (tests/test_host_sanitize.py: ASan + UBSan)
         i64 = ctypes.c_int64
         p = ctypes.c_void_p
         L.kn_oracle_csr_matvecs_f32.argtypes = [i64, i64, i64, p, p, p, p, p]
