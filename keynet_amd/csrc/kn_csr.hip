@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 
 void csr_free(CsrDev& c) {
     void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
-                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows, c.patch_rows, c.patch_ptr, c.patch_cols};
+                    c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows, c.patch_rows, c.patch_ptr, c.patch_cols,
+                    c.mf_grp[0], c.mf_grp[1], c.mf_grp[2], c.mf_r0[0], c.mf_r0[1], c.mf_r0[2], c.ws_grp, c.ws_r0};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c = CsrDev();
@@ -588,7 +589,8 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         }
     }
     std::vector<int32_t> patch_rows, patch_ptr{0}, patch_cols;
-    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose;
+    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose, mfg[3], mfr[3], wsg, wsr;
+    int64_t mf_rows = 0;
     std::vector<int64_t> valptr{0};
     std::vector<float> vals;
     int64_t grouped_nnz = 0;
@@ -642,6 +644,22 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
                 wgrp.push_back(gid);
                 wr0.push_back((int32_t)r0);
             }
+            if (n_mem >= MF_MIN_MEMBERS) {
+                // matrix-pipe kernel: chunks of three 32-row blocks, the tail as 1 .. 3 blocks (a last block may be partly filled)
+                for (int64_t r0 = 0; r0 < n_mem;) {
+                    const int64_t left = n_mem - r0;
+                    const int nrb = left >= 96 ? 3 : (int)((left + 31) / 32);
+                    mfg[nrb - 1].push_back(gid);
+                    mfr[nrb - 1].push_back((int32_t)r0);
+                    r0 += 32 * nrb;
+                }
+                mf_rows += n_mem;
+            } else {
+                for (int64_t r0 = 0; r0 < n_mem; r0 += RB) {
+                    wsg.push_back(gid);
+                    wsr.push_back((int32_t)r0);
+                }
+            }
         }
         grouped_nnz += n_mem * ncol;
     }
@@ -674,7 +692,17 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     if ((rc = upload(&A.grp_rowptr, rowptr.data(), rowptr.size()))) return rc;
     if ((rc = upload(&A.grp_rows, grows.data(), grows.size()))) return rc;
     if ((rc = upload(&A.grp_valptr, valptr.data(), valptr.size()))) return rc;
+    vals.resize(vals.size() + 64, 0.0f);         // the matrix-pipe kernel reads whole 32-row blocks: a partly filled last block reads past its column's rpad values
     if ((rc = upload(&A.grp_vals, vals.data(), vals.size()))) return rc;
+    for (int k = 0; k < 3; k++) {
+        A.n_mf[k] = (int64_t)mfg[k].size();
+        if ((rc = upload(&A.mf_grp[k], mfg[k].data(), mfg[k].size()))) return rc;
+        if ((rc = upload(&A.mf_r0[k], mfr[k].data(), mfr[k].size()))) return rc;
+    }
+    A.mf_rows = mf_rows;
+    A.n_ws = (int64_t)wsg.size();
+    if ((rc = upload(&A.ws_grp, wsg.data(), wsg.size()))) return rc;
+    if ((rc = upload(&A.ws_r0, wsr.data(), wsr.size()))) return rc;
     if ((rc = upload(&A.work_grp, wgrp.data(), wgrp.size()))) return rc;
     if ((rc = upload(&A.work_r0, wr0.data(), wr0.size()))) return rc;
     if ((rc = upload(&A.big_grp, bgrp.data(), bgrp.size()))) return rc;
@@ -1019,6 +1047,24 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
         KN_HIP(hipGetLastError());
     }
     if ((A.n_big > 0 || A.n_long > 0) && A.n_work == 0 && A.n_loose == 0) return KN_OK;
+    // Pattern groups with >= MF_MIN_MEMBERS members on a wide batch: products on the matrix pipe, sums on the vector ALU (kn_csr_mfma.hip: same
+    // bits, twice the rate of the vector-ALU-only kernels below, an activation row fetched once per 96 member rows instead of once per 16).
+    // The remaining small groups and the loose rows go through the kernels below.  KN_NO_GROUP_MFMA = A/B switch (read per call).
+    {
+        const int64_t n_mf = A.n_mf[0] + A.n_mf[1] + A.n_mf[2];
+        if (n_mf > 0 && n_vecs >= 128 && n_mf * ((n_vecs + 255) / 256) * WAVES >= 2048 && getenv("KN_NO_GROUP_MFMA") == nullptr) {
+            int rc = csr_group_mfma_spmm(A, x, ldx, n_vecs, y, ldy, relu, s);
+            if (rc) return rc;
+            if (A.n_ws == 0 && A.n_loose == 0) return KN_OK;
+            CsrDev R = A;                                // (a view: same device arrays, the small groups' bundle list in place of all groups')
+            R.work_grp = A.ws_grp;
+            R.work_r0 = A.ws_r0;
+            R.n_work = A.n_ws;
+            R.n_mf[0] = R.n_mf[1] = R.n_mf[2] = 0;
+            R.n_big = R.n_long = 0;
+            return csr_spmm_groups(R, x, ldx, n_vecs, y, ldy, flags, s);
+        }
+    }
     // short loose rows over a batch window that fills only half of a 256-column wave tile: one row per half wavefront
     if (A.n_work == 0 && A.n_loose >= 4096 && A.nnz <= 32 * A.n_loose && n_vecs % 128 == 0 && (n_vecs / 128) % 2 == 1 && (ldx % 4 == 0) && (ldy % 4 == 0) &&
         (((uintptr_t)x) % 16 == 0) && (((uintptr_t)y) % 16 == 0)) {

@@ -1,0 +1,239 @@
+// kn_csr_mfma.hip -- grouped rows of an order-preserving CSR product with the MULTIPLIES on the matrix pipe (gfx950).
+//
+// The reference's arithmetic (scipy csr_matvecs behind keynet.sparse.SparseMatrix.torchdot, keynet/sparse.py:488-492) is, per output element,
+//     for jj in stored order:  y = fl(y + fl(a_jj * x_jj))          -- an f32 multiply rounded, then an f32 add rounded; never an FMA.
+// kn_csr.hip keeps that on the vector ALU: v_pk_mul_f32 + v_pk_add_f32, i.e. two vector instructions per two MACs -- the "no-FMA roof" of
+// 39.3 T MAC/s.  But a matrix instruction with K = 1 and a ZERO accumulator is exactly the rounded product:
+//     v_mfma_f32_32x32x1_2b_f32  D = 0 + a (x) b      =>      D[i][j] = fl(a_i * b_j)
+// (one product per output element, one rounding; verified bit for bit against v_mul_f32 on 33.5 M products incl. denormal operands and
+// results, overflow, Inf and NaN by tools/micro/mfma_product.hip -- the only difference is the SIGN OF A ZERO product, +0 from the matrix pipe
+// where v_mul_f32 gives -0, and a running sum that starts at +0.0 is never -0.0, so adding either zero leaves it unchanged bit for bit).
+// So the 32 x 64 products of one stored column -- 32 member rows of a pattern group x 64 batch columns -- come out of ONE matrix instruction
+// (64 cycles of the matrix pipe), and the vector ALU only adds them to the running sums, in stored order: 16 v_pk_add_f32 (64 cycles).  Both
+// pipes run side by side: 32 MACs per clock and SIMD instead of 16 -- the bit-exact contract at twice the old roof (78.6 T MAC/s).
+//
+// Tile: a 256-thread workgroup owns NRB <= 3 row blocks (32 member rows each) of ONE pattern group x 256 batch columns; wavefront w owns
+// columns 64w .. 64w+63 for all NRB row blocks (96 x 64 running sums = 96 VGPRs).  Per stored column j a wavefront loads its activation
+// row segment once (256 B, saddr-form dword load: the B operand, lane = batch column) and the NRB x 32 values of the column (128 B each:
+// the A operand, lane & 31 = member row; the four wavefronts of the workgroup read the same values: L1 hits), issues NRB matrix
+// instructions and adds each result block while the next one is computed.  Loads run PF = 6 columns ahead in a register ring (a gathered
+// row of a big operator misses L2), counted vmcnt waits, the column index one more step ahead through a scalar load.  Compared with the
+// 16-row x 256-column wavefront tiles of csr_group_pipe_kernel an activation row is fetched once per 96 member rows instead of once per 16.
+#include "kn_internal.h"
+#include <type_traits>
+#include <cstdlib>
+
+#pragma clang fp contract(off)
+
+namespace kn {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+static __device__ __forceinline__ float mfma_relu_f(float v) { return (v < 0.0f) ? 0.0f : v; }  // torch relu: NaN stays NaN
+
+template <int NRB>
+__global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
+                                                                const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
+                                                                const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
+                                                                const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
+                                                                const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+    constexpr int PF = 6;                                  // stored columns in flight per wavefront (ring of operand registers)
+    constexpr int LPS = NRB + 1;                           // vector loads per stored column
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    // item -> (column tile, work item): XCD x = blockIdx & 7 owns the contiguous item range [x * chunk, (x + 1) * chunk), work item fastest
+    const int64_t n_items = n_ct * n_work;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t item = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (item >= n_items || (blockIdx.x >> 3) >= chunk) return;
+    const int64_t ct = item / n_work;
+    const int64_t w = item - ct * n_work;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(work_grp[w]);
+    const int r0 = __builtin_amdgcn_readfirstlane(work_r0[w]);
+    const int cbeg = __builtin_amdgcn_readfirstlane(grp_colptr[g]);
+    const int ncol = __builtin_amdgcn_readfirstlane(grp_colptr[g + 1]) - cbeg;
+    const int rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
+    const int nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
+    const int rpad = (nmem + 15) / 16 * 16;                // kn_csr.hip: values of one stored column = rpad floats (members padded to bundles of 16)
+    const int64_t c0 = ct * 256 + (int64_t)wave * 64;
+    if (c0 >= n_vecs) return;                              // (wave-uniform)
+    const int64_t c = c0 + lane;
+    const bool active = c < n_vecs;
+
+    // running sums as independent register PAIRS (element e of a row block's 32 = pair e / 2, half e % 2): a 32-register tuple per row block
+    // would have to be copied whenever the allocator cannot update it in place
+    f32x2 acc[NRB][16];
+#pragma unroll
+    for (int b = 0; b < NRB; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[b][q] = f32x2{0.0f, 0.0f};
+
+    if (ncol > 0) {
+        auto uni = [](const uint64_t v) {
+            return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        };
+        const uint64_t cbase = uni(reinterpret_cast<uint64_t>(grp_cols + cbeg));
+        const uint64_t xbase = uni(reinterpret_cast<uint64_t>(X));
+        const uint64_t vbase = uni(reinterpret_cast<uint64_t>(grp_vals + grp_valptr[g] + r0));
+        const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);                 // lane's byte offset inside an activation row (inactive lanes: a valid address, result unused)
+        const uint32_t a_off = 4u * (uint32_t)(lane & 31);                       // lane's byte offset inside a row block's 32 values
+        const uint64_t ldx_b = 4ull * (uint64_t)ldx;
+        const uint32_t vstep = 4u * (uint32_t)rpad;
+        auto clampj = [&](const int j) { return j < ncol ? j : ncol - 1; };      // past the end: the last column again (loaded, never used)
+        float xa[PF][3], xb[PF];                  // (row blocks beyond NRB: never loaded; their registers only appear in the waits' operand lists)
+#pragma unroll
+        for (int q = 0; q < PF; q++) xa[q][0] = xa[q][1] = xa[q][2] = xb[q] = 0.0f;
+        int col_nxt = 0;
+        auto fetch_col = [&](const int j) {                                     // scalar: index of stored column j
+            const uint64_t caddr = cbase + 4ull * (uint64_t)(uint32_t)clampj(j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(col_nxt) : "s"(caddr));
+        };
+        auto col_landed = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(col_nxt)); };
+        // (the operand registers are passed by reference: clang refuses a captured array element as an asm operand inside a generic lambda)
+        auto fetch = [&](float& rb, float& ra0, float& ra1, float& ra2, const int j, const int col) {   // the LPS vector loads of stored column j into one ring slot
+            const uint64_t xaddr = xbase + (uint64_t)(uint32_t)col * ldx_b;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(b_off), "s"(xaddr));
+            const uint64_t va = vbase + (uint64_t)(uint32_t)clampj(j) * (uint64_t)vstep;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra0) : "v"(a_off), "s"(va));
+            if (NRB > 1) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(ra1) : "v"(a_off), "s"(va));
+            if (NRB > 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(ra2) : "v"(a_off), "s"(va));
+        };
+        auto landed = [&](float& rb, float& ra0, float& ra1, float& ra2) {      // the oldest column in flight has landed (PF - 1 younger ones stay in flight)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rb), "+v"(ra0), "+v"(ra1), "+v"(ra2) : "n"(LPS * (PF - 1)));
+        };
+        // prologue: columns 0 .. PF-1 in flight, the index of column PF on its way
+        fetch_col(0);
+        col_landed();
+        {
+            int cj = col_nxt;
+            fetch_col(1);
+            fetch(xb[0], xa[0][0], xa[0][1], xa[0][2], 0, cj);
+            col_landed(); cj = col_nxt; fetch_col(2);
+            fetch(xb[1], xa[1][0], xa[1][1], xa[1][2], 1, cj);
+            col_landed(); cj = col_nxt; fetch_col(3);
+            fetch(xb[2], xa[2][0], xa[2][1], xa[2][2], 2, cj);
+            col_landed(); cj = col_nxt; fetch_col(4);
+            fetch(xb[3], xa[3][0], xa[3][1], xa[3][2], 3, cj);
+            col_landed(); cj = col_nxt; fetch_col(5);
+            fetch(xb[4], xa[4][0], xa[4][1], xa[4][2], 4, cj);
+            col_landed(); cj = col_nxt; fetch_col(6);
+            fetch(xb[5], xa[5][0], xa[5][1], xa[5][2], 5, cj);
+        }
+        f32x32 zero;
+#pragma unroll
+        for (int q = 0; q < 32; q++) zero[q] = 0.0f;
+        // running sums: acc += d, 16 packed adds (the products of a 32 x 64 block, one register pair per instruction)
+        auto add_into = [&](f32x2 (&a)[16], const f32x32& d) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {                                     // (asm: left alone, the compiler splits about half of the pairs into two v_add_f32)
+                const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                asm("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
+            }
+        };
+        // Products of one row block on the matrix pipe (zero accumulator: D = fl(a * x) exactly) into one of TWO result blocks, alternating;
+        // behind each matrix instruction the vector ALU adds the PREVIOUS instruction's block to its running sums -- so a wavefront keeps both
+        // pipes busy by itself (a single result block would put ~18 idle issue slots between every matrix instruction and its adds).  The
+        // block pending at the first instruction is all zeros: +0.0 added to sums that are still +0.0.
+        f32x32 d0 = zero, d1 = zero;
+        auto product = [&](auto T_, const float a, const float x, f32x2 (&pending_sum)[16]) {
+            constexpr int T = decltype(T_)::value;
+            if constexpr ((T & 1) == 0) {
+                d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(pending_sum, d1);
+            } else {
+                d1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(pending_sum, d0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto step = [&](auto slot, const int j) {
+            constexpr int S = decltype(slot)::value;
+            col_landed();
+            const int col_far = col_nxt;                                        // index of stored column j + PF
+            fetch_col(j + PF + 1);
+            landed(xb[S], xa[S][0], xa[S][1], xa[S][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            product(std::integral_constant<int, S * NRB>(), xa[S][0], xb[S], acc[NRB - 1]);
+            if constexpr (NRB > 1) product(std::integral_constant<int, S * NRB + 1>(), xa[S][1], xb[S], acc[0]);
+            if constexpr (NRB > 2) product(std::integral_constant<int, S * NRB + 2>(), xa[S][2], xb[S], acc[1]);
+            fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], j + PF, col_far);
+        };
+        int j = 0;
+        for (; j + PF <= ncol; j += PF) {
+            step(std::integral_constant<int, 0>(), j);
+            step(std::integral_constant<int, 1>(), j + 1);
+            step(std::integral_constant<int, 2>(), j + 2);
+            step(std::integral_constant<int, 3>(), j + 3);
+            step(std::integral_constant<int, 4>(), j + 4);
+            step(std::integral_constant<int, 5>(), j + 5);
+        }
+        add_into(acc[NRB - 1], d1);                                             // the block still pending (PF * NRB is even: the last one written is d1; zeros if the loop never ran)
+        // everything in flight lands (the ring holds the last ncol % PF stored columns and, behind them, harmless re-loads of the last column)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt));
+#pragma unroll
+        for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q][0]), "+v"(xa[q][1]), "+v"(xa[q][2]));
+        // the last ncol % PF stored columns, one result block (the compiler spaces each matrix instruction and its adds)
+        auto tail = [&](auto slot) {
+            constexpr int S = decltype(slot)::value;
+#pragma unroll
+            for (int b = 0; b < NRB; b++) {
+                const f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(xa[S][b], xb[S], zero, 0, 0, 0);
+                add_into(acc[b], d);
+            }
+        };
+        if (j < ncol) tail(std::integral_constant<int, 0>());
+        if (j + 1 < ncol) tail(std::integral_constant<int, 1>());
+        if (j + 2 < ncol) tail(std::integral_constant<int, 2>());
+        if (j + 3 < ncol) tail(std::integral_constant<int, 3>());
+        if (j + 4 < ncol) tail(std::integral_constant<int, 4>());
+    }
+    // D layout of v_mfma_f32_32x32x1_2b_f32: register 16 * blk + r of lane l = element (row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32) of block blk;
+    // block blk = batch columns 32 * blk .. 32 * blk + 31 of this wavefront's 64.  A store instruction writes two 128-byte row segments.
+    // (a lane stores the columns c0 + (lane & 31) + 32 * blk -- not the column it loaded its B operand for)
+    const int half = lane >> 5;
+    const int64_t colo = c0 + (lane & 31);
+#pragma unroll
+    for (int b = 0; b < NRB; b++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int mi = r0 + 32 * b + 8 * (r / 4) + 4 * half + (r % 4);
+            if (mi < nmem) {
+                const int64_t row = grp_rows[rbeg + mi];
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) {
+                    const int64_t cc = colo + 32 * blk;
+                    if (cc < n_vecs) {
+                        float v = acc[b][(16 * blk + r) / 2][(16 * blk + r) % 2];
+                        if (relu) v = mfma_relu_f(v);
+                        __builtin_nontemporal_store(v, Y + row * ldy + cc);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// work lists per NRB (CsrDev::mf_*): chunks of 32 * NRB member rows of the pattern groups with >= MF_MIN_MEMBERS members
+int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    for (int k = 0; k < 3; k++) {
+        if (A.n_mf[k] == 0) continue;
+        const int64_t items = n_ct * A.n_mf[k];
+        const int64_t grid = ((items + 7) / 8) * 8;
+        const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(k + 1) + "> (products on the matrix pipe, K = 1, zero accumulator)";
+        if (k == 0) KN_LAUNCH(d, csr_group_mfma_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+                              A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+        if (k == 1) KN_LAUNCH(d, csr_group_mfma_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+                              A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+        if (k == 2) KN_LAUNCH(d, csr_group_mfma_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+                              A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+    }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+}  // namespace kn

@@ -156,6 +156,15 @@ struct CsrDev {
     // PATCHED group members: rows whose stored column sequence is a group's sequence minus a few entries (a keyed conv row that lost a weight to an
     // exact zero) ride in the group with 0.0f at the missing positions; csr_patch_guard_kernel recomputes them in the reference's own sequence for
     // the batch columns whose activation at a missing position is not finite (see kn_csr.hip)
+    // matrix-pipe products (kn_csr_mfma.hip): pattern groups with >= MF_MIN_MEMBERS members cut into chunks of 32 * (k + 1) member rows, k = 0..2
+    // (list k holds the chunks of k + 1 row blocks); ws_* = the 16-row bundles of the REMAINING (small) groups for the vector-ALU kernels
+    int32_t* mf_grp[3] = {nullptr, nullptr, nullptr};
+    int32_t* mf_r0[3] = {nullptr, nullptr, nullptr};
+    int64_t n_mf[3] = {0, 0, 0};
+    int64_t mf_rows = 0;             // member rows covered by the mf_* lists
+    int32_t* ws_grp = nullptr;
+    int32_t* ws_r0 = nullptr;
+    int64_t n_ws = 0;
     int32_t* patch_rows = nullptr;   // [n_patch]
     int32_t* patch_ptr = nullptr;    // [n_patch+1] into patch_cols
     int32_t* patch_cols = nullptr;   // the missing column indices
@@ -229,6 +238,8 @@ namespace kn {
 // kernels (kn_csr.hip / kn_conv.hip / kn_elementwise.hip)
 int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
+static constexpr int MF_MIN_MEMBERS = 24;   // a pattern group takes the matrix-pipe kernel when its members fill >= 3/4 of a 32-row block
 // `absmax` (device float or null): when the launch takes a kernel whose epilogue can fold max |Y| into its stores, the slot is raised atomically
 // and *absmax_fused is set; otherwise the caller runs absmax_pass over Y afterwards (kn_spmm_screen)
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,

@@ -1,0 +1,140 @@
+"""The matrix-pipe grouped kernel (csrc/kn_csr_mfma.hip: products by v_mfma_f32_32x32x1_2b_f32 with a ZERO accumulator = the IEEE-rounded
+f32 product; running sums by v_pk_add_f32 in stored order) against the CPU oracle (scipy csr_matvecs restated), bit for bit, and against
+the vector-ALU kernels it replaces (KN_NO_GROUP_MFMA=1)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+import oracle
+from keynet_amd import sparse as ksp
+from keynet_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def grouped_operator(rng, n, members, n_groups, ncol_of, loose_every=5, dtype_scale=1.0):
+    rows = []
+    for g in range(n_groups):
+        pattern = rng.randint(0, n, ncol_of(g)).astype(np.int32)          # unsorted, duplicates allowed
+        for _ in range(members):
+            rows.append(pattern)
+        if loose_every and g % loose_every == 0:
+            rows.append(rng.randint(0, n, rng.randint(0, 12)).astype(np.int32))
+    indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+    indices = np.concatenate(rows).astype(np.int32)
+    data = (rng.randn(len(indices)) * dtype_scale).astype(np.float32)
+    return (len(rows), indptr, indices, data)
+
+
+@pytest.mark.parametrize('members,n_vecs', [(96, 512), (192, 256), (32, 1024), (24, 512), (40, 384), (100, 260), (70, 1000), (200, 128)])
+def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs):
+    """Groups of 24 .. 200 member rows (1, 2 and 3 row blocks per workgroup, partly filled last blocks), 1 .. 75 stored columns per group
+    (fewer than the six columns in flight, every remainder modulo six), batches that are not a multiple of 64 or 256, loose rows in
+    between, ReLU on and off."""
+    rng = np.random.RandomState(members * 1000 + n_vecs)
+    n = 1100
+    n_groups = max(600 * 96 // members, 40)
+    (m, indptr, indices, data) = grouped_operator(rng, n, members, n_groups, lambda g: 1 + (g * 7) % 75)
+    X = rng.randn(n, n_vecs).astype(np.float32)
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_group_mfma_kernel' in plan, plan
+    ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+    xd = torch.as_tensor(X).to(dev())
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu).cpu().numpy()
+        assert np.array_equal(y, np.maximum(ref, 0) if relu else ref), (members, n_vecs, relu, int(np.sum(y != (np.maximum(ref, 0) if relu else ref))))
+    os.environ['KN_NO_GROUP_MFMA'] = '1'
+    try:
+        with torch.cuda.device(dev()):
+            assert 'csr_group_mfma_kernel' not in W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        y2 = W.torchdot(xd).cpu().numpy()
+    finally:
+        del os.environ['KN_NO_GROUP_MFMA']
+    assert np.array_equal(y2, ref)
+
+
+def test_matrix_pipe_products_on_special_values():
+    """What could tell a matrix-pipe product from v_mul_f32: denormal operands and results, products that underflow to zero or overflow to
+    Inf, signed zeros (a -0 product comes back as +0: invisible in a sum that starts at +0.0), Inf and NaN activations (NaN / Inf reach exactly
+    the outputs whose rows hold that column; 0 * Inf = NaN like the reference).  Column windows (ldx = ldy > n_vecs) through the C ABI."""
+    rng = np.random.RandomState(5)
+    n = 400
+    (m, indptr, indices, data) = grouped_operator(rng, n, 96, 60, lambda g: 3 + (g * 5) % 40, loose_every=0)
+    spec = np.array([0.0, -0.0, 1e-30, -1e-30, 1e-38, 3e-39, 1e-45, 1e30, -3e38, 1.0, -1.0, 2.5e-20, 7e19], dtype=np.float32)
+    data[::7] = spec[np.arange(len(data[::7])) % len(spec)]
+    n_vecs = 256
+    X = rng.randn(n, n_vecs).astype(np.float32)
+    X[::3, ::5] = spec[(np.arange(len(X[::3, 0]))[:, None] + np.arange(len(X[0, ::5]))[None, :]) % len(spec)]
+    X[7, 3] = np.inf
+    X[11, 64] = -np.inf
+    X[13, 200] = np.nan
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    with np.errstate(all='ignore'):
+        ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+    y = W.torchdot(torch.as_tensor(X).to(dev())).cpu().numpy()
+    assert np.array_equal(y, ref, equal_nan=True), int(np.sum(~((y == ref) | (np.isnan(y) & np.isnan(ref)))))
+    assert np.isnan(ref).any() and np.isinf(ref).any() and (np.abs(ref[np.isfinite(ref) & (ref != 0)]) < 1.2e-38).any()      # the cases really occur
+    # a column window of a wider block
+    ld = 640
+    Xw = rng.randn(n, ld).astype(np.float32)
+    xd = torch.as_tensor(Xw).to(dev())
+    yd = torch.full((m, ld), 7.0, device=dev())
+    c0 = 256
+    with torch.cuda.device(dev()):
+        W._device_op(dev()).spmm(xd.data_ptr() + 4 * c0, ld, 320, yd.data_ptr() + 4 * c0, ld, _capi.KN_FLAG_EXACT | _capi.KN_FLAG_RELU, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    refw = np.maximum(oracle.csr_matvecs((m, n), indptr, indices, data, np.ascontiguousarray(Xw[:, c0:c0 + 320])), 0)
+    got = yd.cpu().numpy()
+    assert np.array_equal(got[:, c0:c0 + 320], refw) and np.all(got[:, :c0] == 7.0) and np.all(got[:, c0 + 320:] == 7.0)
+
+
+def test_matrix_pipe_with_patched_members():
+    """Patched group members (rows that lost an entry to an exact zero ride in the group with 0.0f; kn_csr.hip) through the matrix-pipe kernel,
+    incl. Inf / NaN at a missing position (the guard kernel restores the reference's result)."""
+    rng = np.random.RandomState(3)
+    (n_cols, n_groups, members, seq_len) = (900, 560, 96, 70)          # enough work items for the matrix-pipe dispatch
+    (ip, ix, dt) = ([0], [], [])
+    missing = []
+    for g in range(n_groups):
+        seq = rng.permutation(n_cols)[:seq_len]
+        for mm in range(members):
+            keep = np.ones(seq_len, bool)
+            if mm in (3, 50, 95):
+                lose = {3: [0], 50: [seq_len - 1, 5], 95: [1, 30, 31]}[mm]
+                keep[lose] = False
+                missing.append((len(ip) - 1, seq[lose]))
+            c = seq[keep]
+            ix.extend(int(v) for v in c)
+            dt.extend(rng.randn(len(c)).astype(np.float32))
+            ip.append(len(ix))
+    shape = (len(ip) - 1, n_cols)
+    (ip, ix, dt) = (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+    op = _capi.Operator.csr(shape, ip, ix, dt)
+    n_vecs = 256
+    with torch.cuda.device(dev()):
+        plan = op.plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_group_mfma_kernel' in plan and 'csr_patch_guard_kernel<%d patched rows>' % len(missing) in plan, plan
+    X = rng.randn(n_cols, n_vecs).astype(np.float32)
+    for poison in (False, True):
+        Xp = X.copy()
+        if poison:
+            Xp[missing[0][1][0], 1] = np.inf
+            Xp[missing[4][1][-1], 2] = np.nan
+        xd = torch.as_tensor(Xp).to(dev())
+        yd = torch.empty((shape[0], n_vecs), device=dev())
+        with torch.cuda.device(dev()):
+            op.spmm(xd.data_ptr(), n_vecs, n_vecs, yd.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        with np.errstate(invalid='ignore', over='ignore'):
+            ref = oracle.csr_matvecs(shape, ip, ix, dt, Xp)
+        got = yd.cpu().numpy()
+        assert np.array_equal(got, ref, equal_nan=True), poison
