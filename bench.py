@@ -90,6 +90,29 @@ def build_workload(name, rank, exact=None):
                                      local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='channel', exact=exact)
         (inshape, batch, desc) = ((3, 224, 224), 256, 'Keynet(givens_orthogonal alpha=2 + uniform_random_affine beta=gamma=1, tile=blocksize=14) VGG16(2622) 3x224x224: '
                                                        'the float-key configuration of test/test_keynet.py:133-151')
+    elif name == 'vgg16-givens28':
+        # test/test_keynet.py:155-173 (test_vgg16_orthogonal_8): the same float-key family with tile = blocksize = 224 // 8 = 28
+        torch.manual_seed(0)
+        net = VGG16(num_classes=2622).eval()
+        np.random.seed(0)
+        (sensor, knet) = ksys.Keynet((3, 224, 224), net, tileshape=(224 // 8, 224 // 8), global_geometric='identity', hierarchical_blockshape=(2, 2),
+                                     hierarchical_permute_at_level=(0, 1, 2), local_geometric='givens_orthogonal', alpha=2.0, blocksize=224 // 8,
+                                     local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='channel', exact=exact)
+        (inshape, batch, desc) = ((3, 224, 224), 256, 'Keynet(givens_orthogonal alpha=2 + uniform_random_affine beta=gamma=1, tile=blocksize=28) VGG16(2622) 3x224x224: '
+                                                       'the float-key configuration of test/test_keynet.py:155-173')
+    elif name == 'vgg16-stochastic':
+        # test/test_keynet.py:116-129 (test_vgg16_stochastic; the reference asserts 1e-5 there): hierarchical block permutation at levels 0, 1, 2 +
+        # block-local doubly-stochastic keys (alpha = 2) + affine photometric keys, tile = blocksize = 14.  The INVERSE of a doubly-stochastic block
+        # is dense, so every 14 x 14 block of a keyed operator fills in: ~490-560 (first layer of a stage: 1 700-5 400) slots per output pixel instead
+        # of 9 -- 60x the multiply-adds of the permutation key-net (0.9 T per image), which is why this workload runs 16 images per step.
+        torch.manual_seed(0)
+        net = VGG16(num_classes=2622).eval()
+        np.random.seed(0)
+        (sensor, knet) = ksys.Keynet((3, 224, 224), net, tileshape=(224 // 16, 224 // 16), global_geometric='hierarchical_permutation', hierarchical_blockshape=(2, 2),
+                                     hierarchical_permute_at_level=(0, 1, 2), local_geometric='doubly_stochastic', alpha=2.0, blocksize=224 // 16,
+                                     local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='channel', exact=exact)
+        (inshape, batch, desc) = ((3, 224, 224), 16, 'Keynet(hierarchical_permutation levels 0-2 + doubly_stochastic alpha=2 + uniform_random_affine, tile=blocksize=14) VGG16(2622) '
+                                                      '3x224x224: test/test_keynet.py:116-129')
     elif name == 'lenet':
         torch.manual_seed(0)
         net = LeNet_AvgPool().eval()
@@ -795,7 +818,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'lenet', 'allconv'])
+    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'vgg16-givens28', 'vgg16-stochastic', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=5)
@@ -841,7 +864,7 @@ def main():
         desc += ' [exact mode: order-preserving kernels, bit-exact with the reference algorithm]'
     batch = args.batch if args.batch is not None else batch
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and args.workload not in ('vgg16-gain', 'vgg16-givens'):      # (the scipy baseline is measured on the headline workload)
+    if world == 1 and not args.no_cpu_baseline and args.workload in ('vgg16', 'lenet', 'allconv'):      # (the scipy baseline is measured on the configs BASELINE.json quotes)
         t0 = time.time()
         cpu = cpu_baseline(knet, args.workload, budget_s=args.cpu_budget)
         log('[bench cpu] baseline section took %.1f s' % (time.time() - t0))
@@ -989,7 +1012,7 @@ def main():
                         note='one launch for the whole key-net, activations in LDS; launch_per_layer_ms = the seven separate kernels it replaces (KN_NO_CHAIN=1)')
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
-            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
+            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'vgg16-givens28': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, tile 28: the reference\'s test_vgg16_orthogonal_8)', 'vgg16-stochastic': 'VGG-16 224x224 (float keys: hierarchical permutation + doubly-stochastic blocks + affine photometric: the reference\'s test_vgg16_stochastic)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
             'value': batch * world * args.steps / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'mode': mode_desc, 'images_per_gpu': batch, 'global_batch': batch * world, 'nnz_per_image': nnz_img,
