@@ -131,7 +131,7 @@ struct ConvBuild {
     int64_t nnz_stored = 0;
 };
 
-static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
+static int convtaps_create_impl(ConvBuild& b, kn_operator** out, bool allow_split = true) {
     *out = nullptr;
     const int64_t Cin = b.inshape[0], Hin = b.inshape[1], Win = b.inshape[2];
     const int64_t Cout = b.outshape[0], Hout = b.outshape[1], Wout = b.outshape[2];
@@ -271,6 +271,36 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
         (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
         (rc = upload(&c.lastcol, lastcol.data(), lastcol.size())))
         return rc;
+    // Split-K twin (kn_internal.h: split_sub) for operators with few output pixels and a long contraction: VGG-16 conv5_x has 196 pixels x 4
+    // Cout tiles x 2 batch tiles = 6 tiles per CU at 256 images, all of them the same length -- the launch runs as two synchronised rounds.
+    // Each pixel's slots (ascending input pixel) are dealt to two pseudo-pixels, first half / second half.  KN_NO_SPLITK=1 at create time: none.
+    if (allow_split && b.has_last && !getenv("KN_NO_SPLITK") && HoWo * (c.cout_pad / MT) <= 2048 && Cin >= 64 && mx >= 2 && order.size() > 0) {
+        constexpr int64_t S = 2;
+        ConvBuild b2;
+        for (int k = 0; k < 3; k++) b2.inshape[k] = b.inshape[k];
+        b2.outshape[0] = Cout;
+        b2.outshape[1] = 1;
+        b2.outshape[2] = HoWo * S;
+        b2.has_last = false;
+        b2.taps = b.taps;
+        b2.ent_out.reserve(order.size());
+        b2.ent_in.reserve(order.size());
+        b2.ent_tap.reserve(order.size());
+        b2.ent_coef.reserve(order.size());
+        for (size_t k = 0; k < order.size(); k++) {
+            const size_t e = order[k];
+            const int64_t px = b.ent_out[e];
+            const int64_t r = (int64_t)k - pix_ptr[(size_t)px], n = pix_ptr[(size_t)px + 1] - pix_ptr[(size_t)px];
+            b2.ent_out.push_back((int32_t)(px * S + (r >= (n + 1) / 2 ? 1 : 0)));
+            b2.ent_in.push_back(b.ent_in[e]);
+            b2.ent_tap.push_back(b.ent_tap[e]);
+            b2.ent_coef.push_back(b.ent_coef[e]);
+        }
+        kn_operator* sub = nullptr;
+        if ((rc = convtaps_create_impl(b2, &sub, false))) return rc;
+        h->split_sub = sub;
+        h->split_S = S;
+    }
     *out = h.release();
     return KN_OK;
 }
@@ -549,6 +579,7 @@ int kn_destroy(kn_handle_t h) {
     if (h->chain) chain_free(h->chain);
     if (h->exact) kn_destroy(h->exact);
     if (h->dense_sub) kn_destroy(h->dense_sub);
+    if (h->split_sub) kn_destroy(h->split_sub);
     if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
     for (auto& kv : h->dense_ws)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -621,7 +652,7 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
 // split-K partial-sum workspace of a dense operator for stream `s`, grown to `n_vecs` batch columns on demand.  The growing call is not
 // capturable in a HIP graph: run one eager forward per stream and batch size first (KeyedModel.capture does), or kn_reserve_workspace.
 static int dense_workspace(kn_handle_t h, hipStream_t s, int64_t n_vecs, float** out) {
-    const int64_t outs = h->rows - 1, S = h->dense_splits;
+    const int64_t outs = h->rows - 1, S = h->kind == KIND_DENSE ? h->dense_splits : h->split_S;
     std::lock_guard<std::mutex> g(h->lazy_mu);
     kn_operator::DenseWs& w = h->dense_ws[s];
     if (w.vecs < n_vecs) {
@@ -682,7 +713,7 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
     int rc = KN_OK;
     bool fused = false;
     if (h->kind == KIND_CSR) {
-        rc = csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);
+        rc = csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
     } else if (h->kind == KIND_CHAIN) {
         rc = chain_forward(h->chain, x_dev, ldx, n_vecs, y_dev, ldy, s);   // order-preserving by construction; ReLU flags were fixed at create
     } else if (h->kind == KIND_DENSE) {
@@ -703,7 +734,26 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
             rc = convtaps_build_bf16(h->ct, h->h_taps);
             if (rc) return rc;
         }
-        rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
+        // split-K twin: launches with fewer than 8 equal-length tiles per CU (KN_SPLITK=0 / 1 overrides the rule per call: A/B switch)
+        bool split = false;
+        if (h->split_sub != nullptr && !(flags & (KN_FLAG_EXACT | KN_FLAG_BF16X3)) && n_vecs % 128 == 0) {
+            const char* force = getenv("KN_SPLITK");
+            const int64_t tiles = h->ct.Hout * h->ct.Wout * (h->ct.cout_pad / 128) * (n_vecs / 128);
+            split = force ? (force[0] == '1') : (tiles < 8 * 256);
+        }
+        if (split) {
+            const int64_t outs = h->rows - 1, S = h->split_S;
+            float* ws = nullptr;
+            if (plan_sink() == nullptr) {
+                rc = dense_workspace(h, s, n_vecs, &ws);
+                if (rc) return rc;
+            }
+            rc = convtaps_spmm(h->split_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, ws, n_vecs, 0, s);
+            if (rc) return rc;
+            rc = dense_reduce(ws, n_vecs, outs, S, h->ct.lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
+        } else {
+            rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
+        }
     }
     if (rc) return rc;
     if (absmax && !fused) return absmax_pass(y_dev, h->rows, ldy, n_vecs, absmax, s);
@@ -732,7 +782,7 @@ int kn_reserve_workspace(kn_handle_t h, int64_t n_vecs, void* stream) {
     return guarded([&]() -> int {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
     KN_REQUIRE(n_vecs >= 0 && n_vecs < INT32_MAX, KN_ERR_INVALID, "n_vecs out of range");
-    if (h->kind != KIND_DENSE || n_vecs == 0) return KN_OK;      // only a dense operator keeps per-call state (its split-K partial sums)
+    if ((h->kind != KIND_DENSE && h->split_sub == nullptr) || n_vecs == 0) return KN_OK;      // only split-K operators keep per-call state (their partial sums)
     int cur = -1;
     KN_HIP(hipGetDevice(&cur));
     KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one");

@@ -72,7 +72,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict__ row_list, int64_t n_rows,
                                                        const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                        const float* __restrict__ data, const float* __restrict__ X, int64_t ldx,
-                                                       float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu, int64_t n_rb) {
+                                                       float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu, int64_t n_rb, float* absmax = nullptr) {
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
     int64_t item;
     if (!decode_item(n_ct * n_rb, item)) return;
@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict
         }
         store_vec<VEC>(Y + (int64_t)row * ldy + c, acc);
     }
+    if (absmax) {                              // kn_spmm_screen on an operator of loose rows only (keyed pooling): max |y| rides along, no extra pass
+        float m = 0.0f;
+        if (active) {
+#pragma unroll
+            for (int v = 0; v < VEC; v++) m = fmaxf(m, fabsf(acc[v]));
+        }
+        kn_wave_absmax_commit(m, absmax, lane);
+    }
 }
 
 // Loose rows when the batch window is 128 columns wide (a half batch of the overlapped forward): one row per HALF wavefront, so
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict
 __global__ __launch_bounds__(256) void csr_rows_pair_kernel(const int32_t* __restrict__ row_list, int64_t n_rows, const int32_t* __restrict__ indptr,
                                                             const int32_t* __restrict__ indices, const float* __restrict__ data,
                                                             const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs,
-                                                            int relu, int64_t n_rb) {
+                                                            int relu, int64_t n_rb, float* absmax = nullptr) {
     const int64_t n_ct = (n_vecs + 127) / 128;
     int64_t item;
     if (!decode_item(n_ct * n_rb, item)) return;
@@ -157,11 +165,12 @@ __global__ __launch_bounds__(256) void csr_rows_pair_kernel(const int32_t* __res
     const int lane = threadIdx.x & 63;
     const int64_t ri = (rb * WAVES + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     const int64_t c = ct * 128 + (int64_t)(lane & 31) * 4;
-    if (ri >= n_rows || c >= n_vecs) return;                       // n_vecs % 4 == 0 is guaranteed by the launcher
-    const int row = row_list ? row_list[ri] : (int)ri;
-    const int start = indptr[row];
-    const int end = indptr[row + 1];
-    const float* xc = X + c;
+    const bool valid = ri < n_rows && c < n_vecs;                  // n_vecs % 4 == 0 is guaranteed by the launcher
+    if (!valid && absmax == nullptr) return;                       // (with a screen slot the lane stays for the wave-wide reduction, walking an empty row)
+    const int row = valid ? (row_list ? row_list[ri] : (int)ri) : 0;
+    const int start = valid ? indptr[row] : 0;
+    const int end = valid ? indptr[row + 1] : 0;
+    const float* xc = X + (valid ? c : 0);
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     int k = start;
     for (; k + 4 <= end; k += 4) {
@@ -197,7 +206,8 @@ __global__ __launch_bounds__(256) void csr_rows_pair_kernel(const int32_t* __res
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[v] = relu_f(acc[v]);
     }
-    store_vec<4>(Y + (int64_t)row * ldy + c, acc);
+    if (valid) store_vec<4>(Y + (int64_t)row * ldy + c, acc);
+    if (absmax) kn_wave_absmax_commit(valid ? fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3]))) : 0.0f, absmax, lane);
 }
 
 // Grouped rows: work item w = RB member rows [r0, r0+RB) of group g; all share the column sequence grp_cols[colptr[g]..].
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(256) void csr_group_pipe_kernel(int64_t n_work, con
 }
 
 template <int VEC, int RBK>
-static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s, float* absmax = nullptr) {
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
     if (A.n_work > 0) {
         const int64_t n_rb = (A.n_work * (RB / RBK) + WAVES - 1) / WAVES;
@@ -946,7 +956,7 @@ static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_ve
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
         KN_LAUNCH("csr_rows_kernel<vec=" + std::to_string(VEC) + ">", csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
-                           y, ldy, n_vecs, relu, n_rb);
+                           y, ldy, n_vecs, relu, n_rb, absmax);
     }
     KN_HIP(hipGetLastError());
     return KN_OK;
@@ -999,10 +1009,13 @@ __global__ __launch_bounds__(256) void csr_patch_guard_kernel(int64_t n_patch, c
     Y[(int64_t)r * ldy + c] = acc;
 }
 
-static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* rows_only_absmax = nullptr);
 
-int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
-    const int rc = csr_spmm_groups(A, x, ldx, n_vecs, y, ldy, flags, s);
+int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* absmax, bool* absmax_fused) {
+    // an operator of loose rows only (keyed pooling) is ONE launch of a row kernel: max |Y| (kn_spmm_screen) rides in its epilogue
+    const bool rows_only = A.n_work == 0 && A.n_big == 0 && A.n_long == 0 && A.n_patch == 0 && A.n_loose > 0;
+    if (absmax_fused) *absmax_fused = absmax != nullptr && rows_only;
+    const int rc = csr_spmm_groups(A, x, ldx, n_vecs, y, ldy, flags, s, rows_only ? absmax : nullptr);
     if (rc != KN_OK || A.n_patch == 0) return rc;
     const int64_t n_ct = (n_vecs + 255) / 256;
     KN_LAUNCH("csr_patch_guard_kernel<" + std::to_string(A.n_patch) + " patched rows>", csr_patch_guard_kernel, dim3((unsigned)(A.n_patch * n_ct)), dim3(256), 0, s, A.n_patch,
@@ -1011,7 +1024,7 @@ int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float
     return KN_OK;
 }
 
-static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s) {
+static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* rows_only_absmax) {
     const int relu = (flags & KN_FLAG_RELU) ? 1 : 0;
     // a vector width is usable when pointers / strides allow it AND it keeps the wavefronts filled (64 * v columns per wave): n_vecs = 128
     // (a half-batch column window) takes v = 2 with every lane active rather than v = 4 with lanes 32..63 idle
@@ -1071,7 +1084,7 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
         const int64_t n_rb = (A.n_loose + 2 * WAVES - 1) / (2 * WAVES);
         const int64_t items = ((n_vecs + 127) / 128) * n_rb;
         KN_LAUNCH("csr_rows_pair_kernel", csr_rows_pair_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx, y,
-                           ldy, n_vecs, relu, n_rb);
+                           ldy, n_vecs, relu, n_rb, rows_only_absmax);
         KN_HIP(hipGetLastError());
         return KN_OK;
     }
@@ -1079,7 +1092,7 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
     auto waves = [&](int v, int rbk) { return (A.n_work * (RB / rbk) + loose) * ((n_vecs + 64 * v - 1) / (64 * v)); };
     constexpr int64_t ENOUGH = 2048;
 #define KN_TRY(V, R) \
-    if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
     // wide case: the software-pipelined grouped kernel, 16 member rows per wavefront when the groups fill such bundles, else 8
     // (KN_NO_GROUP_PIPE = A/B switch, read per call)
     if (A.n_work > 0 && aligned(4) && A.cols * ldx < ((int64_t)1 << 31) && getenv("KN_NO_GROUP_PIPE") == nullptr) {
@@ -1095,11 +1108,11 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
     KN_TRY(1, 2)
 #undef KN_TRY
     if (A.n_work == 0) {   // loose rows only: the bundle height is irrelevant, take the widest aligned vector
-        if (aligned(4) && n_vecs >= 256) return launch_csr<4, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
-        if (aligned(2) && n_vecs >= 128) return launch_csr<2, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
-        return launch_csr<1, 8>(A, x, ldx, n_vecs, y, ldy, relu, s);
+        if (aligned(4) && n_vecs >= 256) return launch_csr<4, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
+        if (aligned(2) && n_vecs >= 128) return launch_csr<2, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
+        return launch_csr<1, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
     }
-    return launch_csr<1, 1>(A, x, ldx, n_vecs, y, ldy, relu, s);
+    return launch_csr<1, 1>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
 }
 
 }  // namespace kn

@@ -230,6 +230,11 @@ struct kn_operator {
         hipEvent_t done = nullptr;
     };
     std::vector<Retired> dense_ws_retired;
+    // split-K twin of a conv-taps operator whose launches have only a few tiles per CU (VGG conv5_x: 196 output pixels): every output pixel as
+    // split_S pseudo-pixels holding a share of its slots each; kn_spmm runs the twin into the per-stream workspace (dense_ws) and sums the shares
+    // in order + bias + ReLU (dense_reduce).  Matrix-core contract only (the summation order differs from the unsplit launch's by construction).
+    kn_operator* split_sub = nullptr;
+    int64_t split_S = 0;
     // a whole key-net of CSR operators as one launch (kn_chain.hip)
     kn::ChainDev* chain = nullptr;
 };
@@ -237,7 +242,8 @@ struct kn_operator {
 namespace kn {
 // kernels (kn_csr.hip / kn_conv.hip / kn_elementwise.hip)
 int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
-int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s);
+int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* absmax = nullptr,
+             bool* absmax_fused = nullptr);
 int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
 static constexpr int MF_MIN_MEMBERS = 24;   // a pattern group takes the matrix-pipe kernel when its members fill >= 3/4 of a 32-row block
 // `absmax` (device float or null): when the launch takes a kernel whose epilogue can fold max |Y| into its stores, the slot is raised atomically

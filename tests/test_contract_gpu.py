@@ -83,7 +83,7 @@ def test_permutation_only_tiled_keynet_is_bit_exact_by_default(golden):
     assert not rep['undecided'] and not rep['switched'] and any(r['screened'] for r in rep['layers'])      # conv layers on the matrix cores, screened
 
 
-@pytest.mark.parametrize('kind', ['csr', 'conv-mfma-256', 'conv-mfma-narrow', 'conv-exact', 'dense'])
+@pytest.mark.parametrize('kind', ['csr', 'csr-pool-256', 'csr-pool-half-wave', 'csr-grouped', 'conv-mfma-256', 'conv-mfma-narrow', 'conv-exact', 'dense'])
 def test_spmm_screen_reports_max_abs_output(kind):
     """kn_spmm_screen: same Y as kn_spmm bit for bit, and the slot holds max |Y| exactly -- folded into the tile stores of the matrix-core
     kernels (whole 256-column tiles), one reduction pass behind every other kernel; the slot is only ever raised."""
@@ -92,6 +92,22 @@ def test_spmm_screen_reports_max_abs_output(kind):
         import scipy.sparse
         M = scipy.sparse.random(300, 200, density=0.05, random_state=rng, format='csr', dtype=np.float32)
         (W, n, exact) = (ksp.SparseMatrix(M), 48, True)
+    elif kind in ('csr-pool-256', 'csr-pool-half-wave'):
+        # keyed-pooling shape: thousands of loose rows of ~9 entries (the row kernels fold max |y| into their epilogue: no extra pass)
+        import scipy.sparse
+        (m, nc) = (6000, 2500)
+        lens = rng.randint(6, 12, m)
+        lens[::97] = 0
+        ip = np.concatenate(([0], np.cumsum(lens))).astype(np.int32)
+        M = scipy.sparse.csr_matrix((rng.randn(int(ip[-1])).astype(np.float32), rng.randint(0, nc, int(ip[-1])).astype(np.int32), ip), shape=(m, nc))
+        (W, n, exact) = (ksp.SparseMatrix(M), 256 if kind == 'csr-pool-256' else 128, True)
+    elif kind == 'csr-grouped':
+        import scipy.sparse
+        pat = rng.randint(0, 500, 40).astype(np.int32)
+        rows_ = [pat] * 64 + [rng.randint(0, 500, 7).astype(np.int32) for _ in range(30)]
+        ip = np.concatenate(([0], np.cumsum([len(r) for r in rows_]))).astype(np.int32)
+        M = scipy.sparse.csr_matrix((rng.randn(int(ip[-1])).astype(np.float32), np.concatenate(rows_), ip), shape=(len(rows_), 500))
+        (W, n, exact) = (ksp.SparseMatrix(M), 256, True)
     elif kind == 'dense':
         D = rng.randn(1025, 1025).astype(np.float32)
         D[-1, :] = 0
@@ -126,6 +142,9 @@ def test_spmm_screen_reports_max_abs_output(kind):
     if kind == 'conv-mfma-256':
         with torch.cuda.device(dev()):
             assert 'absmax' not in W._device_op(dev()).plan(256, 0)       # folded into the store epilogue: no extra launch
+    if kind == 'csr-pool-half-wave':
+        with torch.cuda.device(dev()):
+            assert 'csr_rows_pair_kernel' in W._device_op(dev()).plan(128, 2)
 
 
 def test_absmax_ignores_nan_and_counts_inf():
