@@ -273,8 +273,11 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out, bool allow_spli
         return rc;
     // Split-K twin (kn_internal.h: split_sub) for operators with few output pixels and a long contraction: VGG-16 conv5_x has 196 pixels x 4
     // Cout tiles x 2 batch tiles = 6 tiles per CU at 256 images, all of them the same length -- the launch runs as two synchronised rounds.
-    // Each pixel's slots (ascending input pixel) are dealt to two pseudo-pixels, first half / second half.  KN_NO_SPLITK=1 at create time: none.
-    if (allow_split && b.has_last && !getenv("KN_NO_SPLITK") && HoWo * (c.cout_pad / MT) <= 2048 && Cin >= 64 && mx >= 2 && order.size() > 0) {
+    // Each pixel's slots (ascending input pixel) are dealt to two pseudo-pixels, first half / second half.  MEASURED SLOWER than the unsplit
+    // launch on every conv5_x layer (round 4, same-process A/B: 1.68 ms unsplit against 1.70 / 1.76 / 1.85 ms: half-length tiles pay the
+    // per-tile prologue and epilogue twice and write + re-read 0.2 GB of partial sums), so the twin is built only on request: KN_SPLITK=1 in
+    // the environment when the operator is created, and KN_SPLITK=1 per call to take it.
+    if (allow_split && b.has_last && getenv("KN_SPLITK") && getenv("KN_SPLITK")[0] == '1' && HoWo * (c.cout_pad / MT) <= 2048 && Cin >= 64 && mx >= 2 && order.size() > 0) {
         constexpr int64_t S = 2;
         ConvBuild b2;
         for (int k = 0; k < 3; k++) b2.inshape[k] = b.inshape[k];
@@ -734,12 +737,11 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
             rc = convtaps_build_bf16(h->ct, h->h_taps);
             if (rc) return rc;
         }
-        // split-K twin: launches with fewer than 8 equal-length tiles per CU (KN_SPLITK=0 / 1 overrides the rule per call: A/B switch)
+        // split-K twin (opt-in, measured slower: see convtaps_create_impl): taken only when it exists and KN_SPLITK=1 at this call
         bool split = false;
         if (h->split_sub != nullptr && !(flags & (KN_FLAG_EXACT | KN_FLAG_BF16X3)) && n_vecs % 128 == 0) {
             const char* force = getenv("KN_SPLITK");
-            const int64_t tiles = h->ct.Hout * h->ct.Wout * (h->ct.cout_pad / 128) * (n_vecs / 128);
-            split = force ? (force[0] == '1') : (tiles < 8 * 256);
+            split = force != nullptr && force[0] == '1';
         }
         if (split) {
             const int64_t outs = h->rows - 1, S = h->split_S;

@@ -20,7 +20,11 @@ CSRC = os.path.join(ROOT, 'keynet_amd', 'csrc')
 PIPELINED = {
     'kn_conv.hip': [r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn20convtaps_mfma_kernelILi\d+ELi\d+ELi16ELi\dELi\dELi2E'],
     'kn_csr.hip': [r'_ZN2kn21csr_group_pipe_kernel'],
+    'kn_csr_mfma.hip': [r'_ZN2kn21csr_group_mfma_kernel'],
 }
+
+# what an asm-issued load looks like per file (the compiler's own saddr-form dword loads in the other files are tracked by its waitcnt pass)
+ASM_LOAD = {'default': r'global_load_dwordx4 (v\[\d+:\d+\]), v\d+, s\[', 'kn_csr_mfma.hip': r'global_load_dword (v\d+), v\d+, s\['}
 
 
 def _isa(src, tmp_path):
@@ -56,7 +60,7 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
             lines = [l.split(';')[0].strip() for l in body.split('\n') if l.strip()]
             dests = set()
             for l in lines:
-                m = re.match(r'global_load_dwordx4 (v\[\d+:\d+\]), v\d+, s\[', l)       # saddr form = the asm-issued loads
+                m = re.match(ASM_LOAD.get(src, ASM_LOAD['default']), l)       # saddr form = the asm-issued loads
                 if m:
                     dests |= _regs(m.group(1), 'v')
             assert dests, name

@@ -1,5 +1,6 @@
 """Split-K twin of a conv-taps operator with few output pixels and a long contraction (VGG-16 conv5_x: 196 pixels): every pixel's slots dealt to
-two pseudo-pixels, the shares summed in order + bias + ReLU by dense_reduce_kernel.  Matrix-core contract only: against the order-preserving
+two pseudo-pixels, the shares summed in order + bias + ReLU by dense_reduce_kernel.  Opt-in (KN_SPLITK=1 when the operator is created AND per call): the
+same-process A/B on the real conv5_x layers measured it 1-10 % SLOWER than the unsplit launch, so nothing takes it by default.  Matrix-core contract only: against the order-preserving
 path within the float-key tolerance, against the unsplit launch (KN_SPLITK=0) likewise; KN_FLAG_EXACT never takes it (bit-equal to the oracle
 as before); kn_spmm_screen's max |Y| and concurrent use of one handle from two streams keep working."""
 import os
@@ -39,13 +40,13 @@ def conv_operator(cin, cout, hw, seed=0, gain=False):
 
 @pytest.mark.parametrize('cin,cout,hw,n_vecs,gain', [(64, 128, 14, 256, False), (128, 256, 7, 128, False), (64, 192, 10, 384, True)])
 def test_splitk_twin_within_tolerance_and_exact_path_untouched(cin, cout, hw, n_vecs, gain, monkeypatch):
+    monkeypatch.setenv('KN_SPLITK', '1')                                  # the twin is built only on request
     W = conv_operator(cin, cout, hw, seed=cin + hw, gain=gain)
     rng = np.random.RandomState(1)
     X = np.vstack((rng.randn(cin * hw * hw, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
     xd = torch.as_tensor(X).to(dev())
     with torch.cuda.device(dev()):
         op = W._device_op(dev())
-        monkeypatch.setenv('KN_SPLITK', '1')
         plan1 = op.plan(n_vecs, _capi.KN_FLAG_RELU)
         monkeypatch.setenv('KN_SPLITK', '0')
         plan0 = op.plan(n_vecs, _capi.KN_FLAG_RELU)
@@ -53,7 +54,7 @@ def test_splitk_twin_within_tolerance_and_exact_path_untouched(cin, cout, hw, n_
         plan_default = op.plan(n_vecs, 0)
         plan_exact = op.plan(n_vecs, _capi.KN_FLAG_EXACT)
     assert 'dense_reduce_kernel' in plan1 and 'dense_reduce_kernel' not in plan0 and 'dense_reduce_kernel' not in plan_exact, (plan1, plan0, plan_exact)
-    assert 'dense_reduce_kernel' in plan_default                        # a few hundred tiles: the rule takes the twin
+    assert 'dense_reduce_kernel' not in plan_default                    # never by default
     M = W.rows_csr()
     ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
     ye = W.torchdot(xd, relu=False, exact=True).cpu().numpy()
