@@ -1427,6 +1427,193 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     }
 }
 
+// ---- KN_FLAG_EXACT with the MULTIPLIES on the matrix pipe (round 4) ------------------------------------------------------------------
+// The order-preserving product of the factored operator, formulated like kn_csr_mfma.hip: v_mfma_f32_32x32x1_2b_f32 with a ZERO accumulator is
+// exactly the IEEE-rounded product (D[i][j] = fl(a_i * x_j): verified bit for bit against v_mul_f32, tools/micro/mfma_product.hip; a -0 product
+// comes back as +0, invisible in a sum that starts at +0.0), so per stored column -- (input channel ci, slot s) in the expansion's column order:
+// channel outer, the pixel's slots by ascending input pixel inner -- ONE matrix instruction forms the products of 32 output channels x 64 batch
+// columns and 16 v_pk_add_f32 add them to the running sums: separate rounding of product and sum, the reference's order, bit-exact.
+// Workgroup = one output pixel x NRB blocks of 32 output channels x 256 batch columns (wavefront w: columns 64w .. 64w+63); the A operand is
+// 128 contiguous bytes of tapsT[tap][ci][co0 + 32b ..] (lane & 31 = output channel), the B operand the wavefront's 256-byte piece of activation
+// row ci * HiWi + in(s) -- fetched once per 32 * NRB output channels (convtaps_exact_pipe_kernel: once per 16).  Operands run PF = 6 stored
+// columns ahead in a register ring (counted vmcnt); the walk over (slot, channel) stays on the scalar ALU, per-slot offsets live in lane s of
+// three VGPRs (v_readlane).  COEF: the reference's stored value is fl(coef * tap): one v_mul_f32 per A register.
+template <int NRB, bool COEF>
+__global__ __launch_bounds__(256, 2) void convtaps_exact_mfma_kernel(ConvArgs p, int n_cc) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x32 __attribute__((ext_vector_type(32)));
+    constexpr int PF = 6;
+    constexpr int LPS = NRB + 1;
+    const int64_t n_ct = (p.n_vecs + 255) / 256;
+    const int64_t n_items = n_ct * (int64_t)p.n_pix * n_cc;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t item = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (item >= n_items || (blockIdx.x >> 3) >= chunk) return;
+    const int64_t per_ct = (int64_t)p.n_pix * n_cc;
+    const int64_t ct = item / per_ct;
+    const int64_t w = item - ct * per_ct;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[w / n_cc]);
+    const int co0 = __builtin_amdgcn_readfirstlane((int)(w % n_cc) * (32 * NRB));
+    const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
+    const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
+    const int64_t c0 = ct * 256 + (int64_t)wave * 64;
+    if (c0 >= p.n_vecs) return;
+    const int64_t c = c0 + lane;
+    const bool active = c < p.n_vecs;
+
+    f32x2 acc[NRB][16];
+#pragma unroll
+    for (int b = 0; b < NRB; b++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[b][q] = f32x2{0.0f, 0.0f};
+
+    const int n_q = n_slots * p.Cin;
+    if (n_q > 0) {
+        int my_xoff = 0, my_aoff = 0;
+        float my_coef = 1.0f;
+        if (lane < n_slots) {
+            my_xoff = p.slot_in[s_beg + lane] * (int)p.ldx;
+            my_aoff = p.slot_tap[s_beg + lane] * (p.cin_pad * p.cout_pad);
+            if constexpr (COEF) my_coef = p.slot_coef[s_beg + lane];
+        }
+        const int ch_x = __builtin_amdgcn_readfirstlane(p.HiWi * (int)p.ldx);
+        const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);
+        const uint32_t a_off = 4u * (uint32_t)(lane & 31);
+        const float* a_base = p.tapsT + co0;
+        int s_f = 0, cix_f = 0, cia_f = 0, q_f = 0;              // fetch cursor (wave-uniform): slot inner, channel outer
+        float xa[PF][3], xb[PF], cfr[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            xa[q][0] = xa[q][1] = xa[q][2] = xb[q] = 0.0f;
+            cfr[q] = 1.0f;
+        }
+        auto fetch = [&](float& rb, float& ra0, float& ra1, float& ra2, float& cf) {
+            const int xo = __builtin_amdgcn_readlane(my_xoff, s_f) + cix_f;
+            const int ao = __builtin_amdgcn_readlane(my_aoff, s_f) + cia_f;
+            if constexpr (COEF) cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), s_f));
+            const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
+            const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(b_off), "s"(xaddr));
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra0) : "v"(a_off), "s"(aaddr));
+            if (NRB > 1) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(ra1) : "v"(a_off), "s"(aaddr));
+            if (NRB > 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(ra2) : "v"(a_off), "s"(aaddr));
+            // advance the cursor; past the end the last column again (loaded to valid addresses, never used)
+            q_f++;
+            const bool more = q_f < n_q;
+            const bool wrap = (s_f + 1 == n_slots);
+            s_f = more ? (wrap ? 0 : s_f + 1) : s_f;
+            cix_f = __builtin_amdgcn_readfirstlane(cix_f + ((more && wrap) ? ch_x : 0));
+            cia_f = cia_f + ((more && wrap) ? p.cout_pad : 0);
+        };
+        auto landed = [&](float& rb, float& ra0, float& ra1, float& ra2) {
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rb), "+v"(ra0), "+v"(ra1), "+v"(ra2) : "n"(LPS * (PF - 1)));
+        };
+        fetch(xb[0], xa[0][0], xa[0][1], xa[0][2], cfr[0]);
+        fetch(xb[1], xa[1][0], xa[1][1], xa[1][2], cfr[1]);
+        fetch(xb[2], xa[2][0], xa[2][1], xa[2][2], cfr[2]);
+        fetch(xb[3], xa[3][0], xa[3][1], xa[3][2], cfr[3]);
+        fetch(xb[4], xa[4][0], xa[4][1], xa[4][2], cfr[4]);
+        fetch(xb[5], xa[5][0], xa[5][1], xa[5][2], cfr[5]);
+        f32x32 zero;
+#pragma unroll
+        for (int q = 0; q < 32; q++) zero[q] = 0.0f;
+        auto add_into = [&](f32x2 (&a)[16], const f32x32& d) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                asm("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
+            }
+        };
+        // two result blocks alternate: behind each matrix instruction the vector ALU adds the PREVIOUS one's block (zeros at the very first)
+        f32x32 d0 = zero, d1 = zero;
+        auto product = [&](auto T_, const float a, const float x, f32x2 (&pending_sum)[16]) {
+            constexpr int T = decltype(T_)::value;
+            if constexpr ((T & 1) == 0) {
+                d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(pending_sum, d1);
+            } else {
+                d1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(pending_sum, d0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto scaled = [&](const float a, const float cf) { return COEF ? a * cf : a; };          // the reference's stored value: fl(coef * tap)
+        auto step = [&](auto slot) {
+            constexpr int S = decltype(slot)::value;
+            landed(xb[S], xa[S][0], xa[S][1], xa[S][2]);
+            __builtin_amdgcn_sched_barrier(0);
+            product(std::integral_constant<int, S * NRB>(), scaled(xa[S][0], cfr[S]), xb[S], acc[NRB - 1]);
+            if constexpr (NRB > 1) product(std::integral_constant<int, S * NRB + 1>(), scaled(xa[S][1], cfr[S]), xb[S], acc[0]);
+            if constexpr (NRB > 2) product(std::integral_constant<int, S * NRB + 2>(), scaled(xa[S][2], cfr[S]), xb[S], acc[1]);
+            fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], cfr[S]);
+        };
+        int j = 0;
+        for (; j + PF <= n_q; j += PF) {
+            step(std::integral_constant<int, 0>());
+            step(std::integral_constant<int, 1>());
+            step(std::integral_constant<int, 2>());
+            step(std::integral_constant<int, 3>());
+            step(std::integral_constant<int, 4>());
+            step(std::integral_constant<int, 5>());
+        }
+        add_into(acc[NRB - 1], d1);                              // the block still pending (zeros if the loop never ran)
+        asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q][0]), "+v"(xa[q][1]), "+v"(xa[q][2]));
+        auto tail = [&](auto slot) {                             // the last n_q % PF stored columns (already in the ring)
+            constexpr int S = decltype(slot)::value;
+#pragma unroll
+            for (int b = 0; b < NRB; b++) {
+                const f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(scaled(xa[S][b], cfr[S]), xb[S], zero, 0, 0, 0);
+                add_into(acc[b], d);
+            }
+        };
+        if (j < n_q) tail(std::integral_constant<int, 0>());
+        if (j + 1 < n_q) tail(std::integral_constant<int, 1>());
+        if (j + 2 < n_q) tail(std::integral_constant<int, 2>());
+        if (j + 3 < n_q) tail(std::integral_constant<int, 3>());
+        if (j + 4 < n_q) tail(std::integral_constant<int, 4>());
+    }
+    // epilogue: bias column last (separate multiply and add, skipped where the stored entry is absent: explicit zeros do not survive keying),
+    // ReLU, store.  D layout: register 16 * blk + r of lane l = (channel 8 * (r / 4) + 4 * (l / 32) + r % 4, column 32 * blk + l % 32).
+    const int half = lane >> 5;
+    const int64_t colo = c0 + (lane & 31);
+    float xl[2] = {0.0f, 0.0f};
+    if (p.lastcol) {
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+            if (colo + 32 * blk < p.n_vecs) xl[blk] = p.X[p.last_in_row * p.ldx + colo + 32 * blk];
+    }
+#pragma unroll
+    for (int b = 0; b < NRB; b++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = co0 + 32 * b + 8 * (r / 4) + 4 * half + (r % 4);
+            if (m < p.Cout) {
+                const int64_t row = (int64_t)m * p.HoWo + o;
+                const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) {
+                    const int64_t cc = colo + 32 * blk;
+                    if (cc < p.n_vecs) {
+                        float v = acc[b][(16 * blk + r) / 2][(16 * blk + r) % 2];
+                        if (lc != 0.0f) {
+                            const float bp = xl[blk] * lc;
+                            v = v + bp;
+                        }
+                        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+                        __builtin_nontemporal_store(v, p.Y + row * p.ldy + cc);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
 __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
                                                            float* __restrict__ ylast, int64_t n_vecs, int relu, float* absmax) {
@@ -1658,6 +1845,22 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
+        // products on the matrix pipe (convtaps_exact_mfma_kernel): whole 32-channel blocks, a batch of at least one wavefront's 64 columns.
+        // KN_NO_EXACT_MFMA=1 / KN_EXACT_MFMA_NRB=1|2|3: A/B switches (read per call).
+        const bool mf = pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_NO_EXACT_MFMA") == nullptr;
+        if (mf) {
+            int nrb = (A.Cout % 64 == 0) ? 2 : 1;
+            if (const char* e = getenv("KN_EXACT_MFMA_NRB")) nrb = atoi(e);
+            if (nrb < 1 || nrb > 3 || A.Cout % (32 * nrb) != 0) nrb = 1;
+            const int n_cc = (int)(A.Cout / (32 * nrb));
+            const int64_t gridm = (((int64_t)((n_vecs + 255) / 256) * a.n_pix * n_cc + 7) / 8) * 8;
+            const std::string d = "convtaps_exact_mfma_kernel<row blocks=" + std::to_string(nrb) + (A.unit_coef ? "" : ",coef") + "> (products on the matrix pipe, K = 1, zero accumulator)";
+#define KN_EXM(N, C) KN_LAUNCH(d, (convtaps_exact_mfma_kernel<N, C>), dim3((unsigned)gridm), dim3(256), 0, s, a, n_cc)
+            if (nrb == 1) { if (A.unit_coef) KN_EXM(1, false); else KN_EXM(1, true); }
+            else if (nrb == 2) { if (A.unit_coef) KN_EXM(2, false); else KN_EXM(2, true); }
+            else { if (A.unit_coef) KN_EXM(3, false); else KN_EXM(3, true); }
+#undef KN_EXM
+        } else
         if (pipe && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16>", (convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef>", (convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);

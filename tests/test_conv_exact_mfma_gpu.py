@@ -1,0 +1,67 @@
+"""KN_FLAG_EXACT on a factored conv operator with the products on the matrix pipe (convtaps_exact_mfma_kernel: K = 1 matrix instruction with a zero
+accumulator = the IEEE-rounded product; sums on the vector ALU in the expansion's column order) against the CPU oracle on the expanded operator,
+bit for bit, and against the vector-ALU pipeline it replaces (KN_NO_EXACT_MFMA=1): unit and coefficient entries, 1 / 2 / 3 channel blocks per
+workgroup, contractions shorter than the six columns in flight and every remainder modulo six, batches that are not a multiple of 64 or 256,
+explicit-zero bias entries, Inf / NaN activations."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from keynet_amd import _capi
+from test_splitk_gpu import conv_operator
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('cin,cout,hw,n_vecs,gain', [(16, 64, 10, 256, False), (3, 64, 12, 512, False), (20, 96, 8, 320, True), (32, 128, 7, 260, False),
+                                                      (1, 32, 9, 256, True), (64, 256, 5, 1000, False), (5, 160, 6, 256, True)])
+def test_exact_conv_on_the_matrix_pipe_vs_oracle(cin, cout, hw, n_vecs, gain, monkeypatch):
+    W = conv_operator(cin, cout, hw, seed=cin * 7 + cout, gain=gain)
+    W._taps['lastcol'][::5] = 0.0                                    # absent bias entries (explicit zeros do not survive keying)
+    rng = np.random.RandomState(2)
+    X = np.vstack((rng.randn(cin * hw * hw, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    X[3, 5] = np.inf
+    X[min(7, cin * hw * hw - 1), 70 % n_vecs] = np.nan
+    xd = torch.as_tensor(X).to(dev())
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'convtaps_exact_mfma_kernel' in plan, plan
+    M = W.rows_csr()
+    with np.errstate(all='ignore'):
+        ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    for nrb in ('1', '2', '3'):
+        monkeypatch.setenv('KN_EXACT_MFMA_NRB', nrb)
+        for relu in (False, True):
+            with np.errstate(all='ignore'):
+                r = np.where(ref < 0, np.float32(0), ref) if relu else ref
+            y = W.torchdot(xd, relu=relu, exact=True).cpu().numpy()
+            assert np.array_equal(y, r, equal_nan=True), (nrb, relu, int(np.sum(~((y == r) | (np.isnan(y) & np.isnan(r))))))
+    monkeypatch.delenv('KN_EXACT_MFMA_NRB')
+    monkeypatch.setenv('KN_NO_EXACT_MFMA', '1')
+    with torch.cuda.device(dev()):
+        assert 'convtaps_exact_mfma_kernel' not in W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    y0 = W.torchdot(xd, relu=False, exact=True).cpu().numpy()
+    assert np.array_equal(y0, ref, equal_nan=True)
+
+
+def test_exact_conv_matrix_pipe_on_a_column_window():
+    W = conv_operator(16, 64, 8, seed=4)
+    n = 16 * 64 + 1
+    ld = 512
+    x = torch.randn(n, ld, device=dev())
+    x[-1] = 1
+    y = torch.full((W.shape[0], ld), 7.0, device=dev())
+    with torch.cuda.device(dev()):
+        W._device_op(dev()).spmm(x.data_ptr() + 4 * 128, ld, 256, y.data_ptr() + 4 * 128, ld, _capi.KN_FLAG_EXACT | _capi.KN_FLAG_RELU, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    M = W.rows_csr()
+    ref = np.maximum(oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), np.ascontiguousarray(x[:, 128:384].cpu().numpy())), 0)
+    got = y.cpu().numpy()
+    assert np.array_equal(got[:, 128:384], ref) and np.all(got[:, :128] == 7.0) and np.all(got[:, 384:] == 7.0)
