@@ -1846,8 +1846,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
         // products on the matrix pipe (convtaps_exact_mfma_kernel): whole 32-channel blocks, a batch of at least one wavefront's 64 columns.
-        // KN_NO_EXACT_MFMA=1 / KN_EXACT_MFMA_NRB=1|2|3: A/B switches (read per call).
-        const bool mf = pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_NO_EXACT_MFMA") == nullptr;
+        // OPT-IN (KN_EXACT_MFMA=1, read per call; KN_EXACT_MFMA_NRB=1|2|3 picks the channel blocks per workgroup): bit-exact like the vector-ALU
+        // pipeline, but measured 4-8 % SLOWER than it on every keyed VGG-16 layer (round 4, same-process A/B: conv3_2 13.38 ms against 14.49; the
+        // f32 matrix instruction runs on the vector ALU's own FP32 lanes, so the two do not overlap, and the hand-scheduled pipeline already
+        // sits at 0.84-0.88 of the no-FMA roof with five wavefronts per SIMD against three here).
+        const bool mf = pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_EXACT_MFMA") != nullptr && getenv("KN_EXACT_MFMA")[0] == '1';
         if (mf) {
             int nrb = (A.Cout % 64 == 0) ? 2 : 1;
             if (const char* e = getenv("KN_EXACT_MFMA_NRB")) nrb = atoi(e);
