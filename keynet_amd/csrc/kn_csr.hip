@@ -600,7 +600,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     }
     std::vector<int32_t> patch_rows, patch_ptr{0}, patch_cols;
     std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose, mfg[3], mfr[3], wsg, wsr;
-    int64_t mf_rows = 0;
+    int64_t mf_rows = 0, mf_nnz = 0;
     std::vector<int64_t> valptr{0};
     std::vector<float> vals;
     int64_t grouped_nnz = 0;
@@ -656,14 +656,16 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             }
             if (n_mem >= MF_MIN_MEMBERS) {
                 // matrix-pipe kernel: chunks of three 32-row blocks, the tail as 1 .. 3 blocks (a last block may be partly filled)
+                const int nrb_max = getenv("KN_MF_NRB") ? std::max(1, std::min(3, atoi(getenv("KN_MF_NRB")))) : 3;     // A/B knob, read when the operator is created
                 for (int64_t r0 = 0; r0 < n_mem;) {
                     const int64_t left = n_mem - r0;
-                    const int nrb = left >= 96 ? 3 : (int)((left + 31) / 32);
+                    const int nrb = left >= 32 * nrb_max ? nrb_max : (int)((left + 31) / 32);
                     mfg[nrb - 1].push_back(gid);
                     mfr[nrb - 1].push_back((int32_t)r0);
                     r0 += 32 * nrb;
                 }
                 mf_rows += n_mem;
+                mf_nnz += n_mem * ncol;
             } else {
                 for (int64_t r0 = 0; r0 < n_mem; r0 += RB) {
                     wsg.push_back(gid);
@@ -710,6 +712,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         if ((rc = upload(&A.mf_r0[k], mfr[k].data(), mfr[k].size()))) return rc;
     }
     A.mf_rows = mf_rows;
+    A.mf_nnz = mf_nnz;
     A.n_ws = (int64_t)wsg.size();
     if ((rc = upload(&A.ws_grp, wsg.data(), wsg.size()))) return rc;
     if ((rc = upload(&A.ws_r0, wsr.data(), wsr.size()))) return rc;
@@ -1060,12 +1063,18 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
         KN_HIP(hipGetLastError());
     }
     if ((A.n_big > 0 || A.n_long > 0) && A.n_work == 0 && A.n_loose == 0) return KN_OK;
-    // Pattern groups with >= MF_MIN_MEMBERS members on a wide batch: products on the matrix pipe, sums on the vector ALU (kn_csr_mfma.hip: same
-    // bits, twice the rate of the vector-ALU-only kernels below, an activation row fetched once per 96 member rows instead of once per 16).
-    // The remaining small groups and the loose rows go through the kernels below.  KN_NO_GROUP_MFMA = A/B switch (read per call).
+    // Pattern groups with >= MF_MIN_MEMBERS members and long stored sequences on a wide batch: products on the matrix pipe, sums on the vector
+    // ALU (kn_csr_mfma.hip: same bits; an activation row is fetched once per 96 member rows instead of once per 16 -- AllConvNet conv2 reads
+    // 11.7 GB from the fabric per launch instead of 27.8).  Same-process A/B under sustained load (tools/ab_allconv.py): the two formulations
+    // take the same ALU time -- the f32 matrix instruction runs on the vector ALU's FP32 lanes -- so the long layers are within 0-2.5 % of each
+    // other, and layers with short sequences (AllConvNet conv1: 28 columns, conv8: 193) are faster on the vector-ALU pipeline, whose five
+    // wavefronts per SIMD hide the ring's start-up better: those stay there (mean stored columns per member row < 256).  The remaining small
+    // groups and the loose rows go through the kernels below.  KN_NO_GROUP_MFMA=1 / KN_GROUP_MFMA=1 (force) = A/B switches, read per call.
     {
         const int64_t n_mf = A.n_mf[0] + A.n_mf[1] + A.n_mf[2];
-        if (n_mf > 0 && n_vecs >= 128 && n_mf * ((n_vecs + 255) / 256) * WAVES >= 2048 && getenv("KN_NO_GROUP_MFMA") == nullptr) {
+        const bool long_rows = A.mf_rows > 0 && A.mf_nnz >= 256 * A.mf_rows;
+        const bool want = getenv("KN_GROUP_MFMA") ? getenv("KN_GROUP_MFMA")[0] == '1' : long_rows;
+        if (want && n_mf > 0 && n_vecs >= 128 && n_mf * ((n_vecs + 255) / 256) * WAVES >= 2048 && getenv("KN_NO_GROUP_MFMA") == nullptr) {
             int rc = csr_group_mfma_spmm(A, x, ldx, n_vecs, y, ldy, relu, s);
             if (rc) return rc;
             if (A.n_ws == 0 && A.n_loose == 0) return KN_OK;

@@ -162,6 +162,7 @@ struct CsrDev {
     int32_t* mf_r0[3] = {nullptr, nullptr, nullptr};
     int64_t n_mf[3] = {0, 0, 0};
     int64_t mf_rows = 0;             // member rows covered by the mf_* lists
+    int64_t mf_nnz = 0;              // their stored entries (mf_nnz / mf_rows = mean stored columns per row: the dispatch rule of csr_spmm_groups)
     int32_t* ws_grp = nullptr;
     int32_t* ws_r0 = nullptr;
     int64_t n_ws = 0;

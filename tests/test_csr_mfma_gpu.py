@@ -35,10 +35,11 @@ def grouped_operator(rng, n, members, n_groups, ncol_of, loose_every=5, dtype_sc
 
 
 @pytest.mark.parametrize('members,n_vecs', [(96, 512), (192, 256), (32, 1024), (24, 512), (40, 384), (100, 260), (70, 1000), (200, 128)])
-def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs):
+def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs, monkeypatch):
     """Groups of 24 .. 200 member rows (1, 2 and 3 row blocks per workgroup, partly filled last blocks), 1 .. 75 stored columns per group
     (fewer than the six columns in flight, every remainder modulo six), batches that are not a multiple of 64 or 256, loose rows in
     between, ReLU on and off."""
+    monkeypatch.setenv('KN_GROUP_MFMA', '1')                 # forced: by default only operators with long stored sequences (mean >= 256 columns) take it
     rng = np.random.RandomState(members * 1000 + n_vecs)
     n = 1100
     n_groups = max(600 * 96 // members, 40)
@@ -63,10 +64,11 @@ def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs):
     assert np.array_equal(y2, ref)
 
 
-def test_matrix_pipe_products_on_special_values():
+def test_matrix_pipe_products_on_special_values(monkeypatch):
     """What could tell a matrix-pipe product from v_mul_f32: denormal operands and results, products that underflow to zero or overflow to
     Inf, signed zeros (a -0 product comes back as +0: invisible in a sum that starts at +0.0), Inf and NaN activations (NaN / Inf reach exactly
     the outputs whose rows hold that column; 0 * Inf = NaN like the reference).  Column windows (ldx = ldy > n_vecs) through the C ABI."""
+    monkeypatch.setenv('KN_GROUP_MFMA', '1')
     rng = np.random.RandomState(5)
     n = 400
     (m, indptr, indices, data) = grouped_operator(rng, n, 96, 60, lambda g: 3 + (g * 5) % 40, loose_every=0)
@@ -98,9 +100,10 @@ def test_matrix_pipe_products_on_special_values():
     assert np.array_equal(got[:, c0:c0 + 320], refw) and np.all(got[:, :c0] == 7.0) and np.all(got[:, c0 + 320:] == 7.0)
 
 
-def test_matrix_pipe_with_patched_members():
+def test_matrix_pipe_with_patched_members(monkeypatch):
     """Patched group members (rows that lost an entry to an exact zero ride in the group with 0.0f; kn_csr.hip) through the matrix-pipe kernel,
     incl. Inf / NaN at a missing position (the guard kernel restores the reference's result)."""
+    monkeypatch.setenv('KN_GROUP_MFMA', '1')
     rng = np.random.RandomState(3)
     (n_cols, n_groups, members, seq_len) = (900, 560, 96, 70)          # enough work items for the matrix-pipe dispatch
     (ip, ix, dt) = ([0], [], [])
@@ -138,3 +141,21 @@ def test_matrix_pipe_with_patched_members():
             ref = oracle.csr_matvecs(shape, ip, ix, dt, Xp)
         got = yd.cpu().numpy()
         assert np.array_equal(got, ref, equal_nan=True), poison
+
+
+def test_default_dispatch_rule():
+    """By default the matrix-pipe kernel serves pattern groups with long stored sequences (mean >= 256 columns per member row: the 3x3 conv
+    layers of AllConvNet with 96 / 192 input channels); short sequences stay on the vector-ALU pipeline (same bits either way)."""
+    rng = np.random.RandomState(9)
+    for (ncol, expect) in ((300, True), (60, False)):
+        (m, indptr, indices, data) = grouped_operator(rng, 2000, 96, 560, lambda g: ncol, loose_every=0)
+        op = _capi.Operator.csr((m, 2000), indptr, indices, data)
+        with torch.cuda.device(dev()):
+            plan = op.plan(256, _capi.KN_FLAG_EXACT)
+        assert ('csr_group_mfma_kernel' in plan) == expect, (ncol, plan)
+        X = rng.randn(2000, 256).astype(np.float32)
+        y = torch.empty((m, 256), device=dev())
+        xd = torch.as_tensor(X).to(dev())
+        with torch.cuda.device(dev()):
+            op.spmm(xd.data_ptr(), 256, 256, y.data_ptr(), 256, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(y.cpu().numpy(), oracle.csr_matvecs((m, 2000), indptr, indices, data, X))
