@@ -53,7 +53,7 @@ __device__ __forceinline__ void kn_order() { __builtin_amdgcn_sched_barrier(0); 
 // that every row of the sub-tile exists (< Cout): the per-row test disappears for channel counts that fill the tile.
 template <int TM, int TN, bool ALL_ROWS = false>
 __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float* stage, const int lane, float* yp, const int64_t row_step_bytes,
-                                              const int m_first, const int Cout, const bool rows_ok, const int relu, float* absmax = nullptr) {
+                                              const int m_first, const int Cout, const bool rows_ok, const int relu, float* absmax = nullptr, float* carry = nullptr) {
     // ReLU without a branch: clamp from below at 0, or at -inf (a no-op; NaN stays NaN either way).  ALL_ROWS (compile time: the
     // tile lies inside Cout) additionally removes the per-row test, so the 16 stores are straight-line code and a caller that
     // keeps loads in flight across them gets an exact counted vmcnt from the compiler instead of a drain.
@@ -91,7 +91,8 @@ __device__ __forceinline__ void kn_store_tile(const f32x16 (&acc)[TM][TN], float
             kn_wave_sync();
         }
     }
-    if (absmax) kn_wave_absmax_commit(am, absmax, lane);      // wave-uniform branch; one relaxed load (+ rarely an atomic) per tile
+    if (carry) *carry = (am > *carry) ? am : *carry;          // a persistent caller commits once, after its last tile (kn_wave_absmax_commit: why)
+    else if (absmax) kn_wave_absmax_commit(am, absmax, lane);      // wave-uniform branch; one relaxed load (+ rarely an atomic) per tile
 }
 
 struct ConvArgs {
@@ -1078,6 +1079,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_smallk_pipe_kernel(ConvArgs p
     const int bcol = wave * (TN * 32) + (lane & 31);
     constexpr int COLS = TN * 32, LPR = COLS / 4;
     int buf = 0;
+    float am_carry = 0.0f;                                        // kn_spmm_screen: max |y| over this wavefront's pixels, committed once after the loop
     for (int64_t it = first; it <= last; it += step) {
         gather(nxt);                                              // rows of the NEXT pixel: issued before this pixel's stores
         Ctl nn = fetch_ctl(it + 2 * step);
@@ -1115,7 +1117,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_smallk_pipe_kernel(ConvArgs p
             const int o = __builtin_amdgcn_readlane(cur.x, 31);
             float* stage = lds + buf * KM * NB + wave * (8 * COLS);
             float* yp = p.Y + ((int64_t)(lane / LPR) * p.HoWo + o) * p.ldy + (cur.b0 + wave * COLS + (lane % LPR) * 4);
-            kn_store_tile<TM, TN, true>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, 0, p.Cout, true, p.relu, p.absmax);   // Cout == 64 on this path
+            kn_store_tile<TM, TN, true>(acc, stage, lane, yp, (int64_t)(64 / LPR) * p.HoWo * p.ldy * 4, 0, p.Cout, true, p.relu, p.absmax, p.absmax ? &am_carry : nullptr);   // Cout == 64 on this path
         }
         // ---- next pixel's rows -> the other buffer (their loads are older than the stores above: the wait leaves those in flight) ----
         stage_in(nxt, buf ^ 1);
@@ -1125,6 +1127,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_smallk_pipe_kernel(ConvArgs p
         __syncthreads();
         buf ^= 1;
     }
+    if (p.absmax) kn_wave_absmax_commit(am_carry, p.absmax, lane);       // kn_spmm_screen: ONE commit per wavefront, after its last pixel
 }
 
 // ---- order-preserving path on the factored operator (KN_FLAG_EXACT) ------------------------------------------------

@@ -9,6 +9,7 @@
 #include <new>
 #include <stdexcept>
 #include <memory>
+#include <type_traits>
 #include "../../include/keynet_hip.h"
 
 #ifdef KN_HOST_PACK_ONLY
@@ -254,14 +255,24 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
 int absmax_pass(const float* y, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax, hipStream_t s);
 
 // Raise *slot (a non-negative f32 kept as its bit pattern: for such values unsigned order == float order) to the wavefront's max of `m`.
-// One relaxed load first: after the first few tiles of a launch almost no wavefront still has to issue the atomic.
+// The slot is READ first and the atomic issued only when it would raise it -- after the first few tiles of a launch almost never.  Both
+// alternatives were measured on the keyed VGG-16 forward (tools/ab_rescreen.py): an unconditional fire-and-forget atomic per tile (atomics on
+// ONE address serialise at ~50 ns each: +20 ms per forward) and a scalar GLC load as the filter (same-address scalar loads serialise even
+// harder: +54 ms).  The vector load's wait (vmcnt) also drains the wavefront's own stores, which is free where a workgroup ends with its tile
+// and costly in the persistent first-layer kernel: that one carries its maximum across its pixels and commits once (kn_store_tile's `carry`).
 __device__ __forceinline__ void kn_wave_absmax_commit(float m, float* slot, int lane) {
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        const float o = __shfl_xor(m, sft, 64);
+    auto step = [&](auto ctrl, auto row_mask) {               // DPP row shifts / broadcasts: vector ALU only, no LDS permute
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, m), __builtin_bit_cast(int, m), decltype(ctrl)::value,
+                                                                              decltype(row_mask)::value, 0xf, false));
         m = (o > m) ? o : m;
-    }
-    if (lane == 0) {
+    };
+    step(std::integral_constant<int, 0x111>(), std::integral_constant<int, 0xf>());     // row_shr:1   lane i <- max(i, i-1)       (lanes without a source keep their own value)
+    step(std::integral_constant<int, 0x112>(), std::integral_constant<int, 0xf>());     // row_shr:2
+    step(std::integral_constant<int, 0x114>(), std::integral_constant<int, 0xf>());     // row_shr:4
+    step(std::integral_constant<int, 0x118>(), std::integral_constant<int, 0xf>());     // row_shr:8   lane 15 of each row of 16 = the row's max
+    step(std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());     // row_bcast:15 into rows 1, 3
+    step(std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());     // row_bcast:31 into rows 2, 3: lane 63 = the wavefront's max
+    if (lane == 63) {
         const unsigned bits = __float_as_uint(m);
         unsigned* u = reinterpret_cast<unsigned*>(slot);
         if (bits > __atomic_load_n(u, __ATOMIC_RELAXED)) atomicMax(u, bits);

@@ -207,6 +207,8 @@ class KeyedLayer(nn.Module):
         difference of a re-ordered f32 sum scales with the activations while the tolerance 1e-5 max(1, |y|) has a floor, so a decision
         taken with 2x headroom (accepted at <= 0.5 tol) is kept for inputs up to RESCREEN_FACTOR x the calibrated magnitude."""
         cal = float(self._contract_record['max_abs_x'])
+        if not np.isfinite(cal):
+            return False                                          # calibrated on non-finite activations: there is no larger batch to learn from
         return not (xmax <= self.RESCREEN_FACTOR * cal)          # also True for NaN
 
     def mfma_capable(self, device=None):

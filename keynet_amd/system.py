@@ -170,6 +170,8 @@ class KeyedModel(object):
                 if _slots_out is not None:
                     _slots_out.append((slots, screened))        # a graph replay checks them after the launch (KeyedModel.capture)
                 return y
+            if os.environ.get('KN_RESCREEN_NOREAD') == '1':      # DIAGNOSTIC (tools/ab_rescreen.py): gather the maxima but skip the host read -- what the read itself costs
+                return y
             if not self._rescreen(slots.tolist(), keyed, screened):
                 return y
         return y

@@ -29,16 +29,19 @@ def main():
             knet.forward_linear(xc)
         torch.cuda.synchronize()
         return 1e3 * (time.perf_counter() - t0) / n
-    res = {'screen': [], 'noscreen': []}
+    res = {'screen': [], 'noscreen': [], 'gather_only': []}
     for rnd in range(4):
-        for mode in ('noscreen', 'screen'):
+        for mode in ('noscreen', 'gather_only', 'screen'):
+            os.environ.pop('KN_NO_RESCREEN', None)
+            os.environ.pop('KN_RESCREEN_NOREAD', None)
             if mode == 'noscreen':
                 os.environ['KN_NO_RESCREEN'] = '1'
-            else:
-                os.environ.pop('KN_NO_RESCREEN', None)
+            elif mode == 'gather_only':
+                os.environ['KN_RESCREEN_NOREAD'] = '1'
             timed(2)
             res[mode].append(timed(10))
     os.environ.pop('KN_NO_RESCREEN', None)
+    os.environ.pop('KN_RESCREEN_NOREAD', None)
     for (k, v) in res.items():
         print('%-9s %s  median %.3f ms' % (k, ' '.join('%.3f' % t for t in v), float(np.median(v))))
     print('screen cost: %.3f ms per forward' % (float(np.median(res['screen'])) - float(np.median(res['noscreen']))))
