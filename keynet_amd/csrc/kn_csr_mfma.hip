@@ -17,7 +17,7 @@
 // row segment once (256 B, saddr-form dword load: the B operand, lane = batch column) and the NRB x 32 values of the column (128 B each:
 // the A operand, lane & 31 = member row; the four wavefronts of the workgroup read the same values: L1 hits), issues NRB matrix
 // instructions and adds each result block while the next one is computed.  Loads run PF = 6 columns ahead in a register ring (a gathered
-// row of a big operator misses L2), counted vmcnt waits, the column index one more step ahead through a scalar load.  Compared with the
+// row of a big operator misses L2; 8 columns ahead for the three-block instantiation), counted vmcnt waits, the column index one more step ahead through a scalar load.  Compared with the
 // 16-row x 256-column wavefront tiles of csr_group_pipe_kernel an activation row is fetched once per 96 member rows instead of once per 16.
 #include "kn_internal.h"
 #include <type_traits>
@@ -32,13 +32,21 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 static __device__ __forceinline__ float mfma_relu_f(float v) { return (v < 0.0f) ? 0.0f : v; }  // torch relu: NaN stays NaN
 
-template <int NRB>
+template <int I, int N, class F>
+static __device__ __forceinline__ void mfma_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        mfma_static_for<I + 1, N>(f);
+    }
+}
+
+template <int NRB, int PF>
 __global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                                 const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
                                                                 const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
                                                                 const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
                                                                 const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
-    constexpr int PF = 6;                                  // stored columns in flight per wavefront (ring of operand registers)
+    static_assert((PF * NRB) % 2 == 0, "two result blocks alternate: an even number of matrix instructions per unrolled loop body");   // PF = stored columns in flight per wavefront (ring of operand registers)
     constexpr int LPS = NRB + 1;                           // vector loads per stored column
     const int64_t n_ct = (n_vecs + 255) / 256;
     // item -> (column tile, work item): XCD x = blockIdx & 7 owns the contiguous item range [x * chunk, (x + 1) * chunk), work item fastest
@@ -105,22 +113,13 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, 
         };
         // prologue: columns 0 .. PF-1 in flight, the index of column PF on its way
         fetch_col(0);
-        col_landed();
-        {
-            int cj = col_nxt;
-            fetch_col(1);
-            fetch(xb[0], xa[0][0], xa[0][1], xa[0][2], 0, cj);
-            col_landed(); cj = col_nxt; fetch_col(2);
-            fetch(xb[1], xa[1][0], xa[1][1], xa[1][2], 1, cj);
-            col_landed(); cj = col_nxt; fetch_col(3);
-            fetch(xb[2], xa[2][0], xa[2][1], xa[2][2], 2, cj);
-            col_landed(); cj = col_nxt; fetch_col(4);
-            fetch(xb[3], xa[3][0], xa[3][1], xa[3][2], 3, cj);
-            col_landed(); cj = col_nxt; fetch_col(5);
-            fetch(xb[4], xa[4][0], xa[4][1], xa[4][2], 4, cj);
-            col_landed(); cj = col_nxt; fetch_col(6);
-            fetch(xb[5], xa[5][0], xa[5][1], xa[5][2], 5, cj);
-        }
+        mfma_static_for<0, PF>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            col_landed();
+            const int cj = col_nxt;
+            fetch_col(I + 1);
+            fetch(xb[I], xa[I][0], xa[I][1], xa[I][2], I, cj);
+        });
         f32x32 zero;
 #pragma unroll
         for (int q = 0; q < 32; q++) zero[q] = 0.0f;
@@ -163,14 +162,7 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, 
             fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], j + PF, col_far);
         };
         int j = 0;
-        for (; j + PF <= ncol; j += PF) {
-            step(std::integral_constant<int, 0>(), j);
-            step(std::integral_constant<int, 1>(), j + 1);
-            step(std::integral_constant<int, 2>(), j + 2);
-            step(std::integral_constant<int, 3>(), j + 3);
-            step(std::integral_constant<int, 4>(), j + 4);
-            step(std::integral_constant<int, 5>(), j + 5);
-        }
+        for (; j + PF <= ncol; j += PF) mfma_static_for<0, PF>([&](auto S_) { step(S_, j + decltype(S_)::value); });
         add_into(acc[NRB - 1], d1);                                             // the block still pending (PF * NRB is even: the last one written is d1; zeros if the loop never ran)
         // everything in flight lands (the ring holds the last ncol % PF stored columns and, behind them, harmless re-loads of the last column)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt));
@@ -185,11 +177,9 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, 
                 add_into(acc[b], d);
             }
         };
-        if (j < ncol) tail(std::integral_constant<int, 0>());
-        if (j + 1 < ncol) tail(std::integral_constant<int, 1>());
-        if (j + 2 < ncol) tail(std::integral_constant<int, 2>());
-        if (j + 3 < ncol) tail(std::integral_constant<int, 3>());
-        if (j + 4 < ncol) tail(std::integral_constant<int, 4>());
+        mfma_static_for<0, PF - 1>([&](auto S_) {
+            if (j + decltype(S_)::value < ncol) tail(S_);
+        });
     }
     // D layout of v_mfma_f32_32x32x1_2b_f32: register 16 * blk + r of lane l = element (row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32) of block blk;
     // block blk = batch columns 32 * blk .. 32 * blk + 31 of this wavefront's 64.  A store instruction writes two 128-byte row segments.
@@ -225,12 +215,19 @@ int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_
         const int64_t items = n_ct * A.n_mf[k];
         const int64_t grid = ((items + 7) / 8) * 8;
         const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(k + 1) + "> (products on the matrix pipe, K = 1, zero accumulator)";
-        if (k == 0) KN_LAUNCH(d, csr_group_mfma_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+        if (k == 0) KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
                               A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
-        if (k == 1) KN_LAUNCH(d, csr_group_mfma_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+        if (k == 1) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
                               A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
-        if (k == 2) KN_LAUNCH(d, csr_group_mfma_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
-                              A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+        if (k == 2) {
+            static const int pf = getenv("KN_MF_PF") ? atoi(getenv("KN_MF_PF")) : 8;      // A/B knob (read once): operand columns in flight (AllConvNet forward, same box: 33.79 / 33.38 / 33.53 ms at 6 / 8 / 10)
+            if (pf == 10) KN_LAUNCH(d + " pf=10", (csr_group_mfma_kernel<3, 10>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr,
+                                    A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+            else if (pf == 8) KN_LAUNCH(d + " pf=8", (csr_group_mfma_kernel<3, 8>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr,
+                                        A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+            else KN_LAUNCH(d, (csr_group_mfma_kernel<3, 6>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
+                           A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+        }
     }
     KN_HIP(hipGetLastError());
     return KN_OK;
