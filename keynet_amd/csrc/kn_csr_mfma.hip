@@ -40,15 +40,16 @@ static __device__ __forceinline__ void mfma_static_for(F&& f) {
     }
 }
 
-template <int NRB, int PF>
-__global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
+template <int NRB, int PF, int NW = 4>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
+                                            // re-reads but measured 8.5 % slower on the AllConvNet forward: 35.9 against 33.0 ms; not instantiated)
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                                 const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
                                                                 const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
                                                                 const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
                                                                 const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
     static_assert((PF * NRB) % 2 == 0, "two result blocks alternate: an even number of matrix instructions per unrolled loop body");   // PF = stored columns in flight per wavefront (ring of operand registers)
     constexpr int LPS = NRB + 1;                           // vector loads per stored column
-    const int64_t n_ct = (n_vecs + 255) / 256;
+    const int64_t n_ct = (n_vecs + 64 * NW - 1) / (64 * NW);
     // item -> (column tile, work item): XCD x = blockIdx & 7 owns the contiguous item range [x * chunk, (x + 1) * chunk), work item fastest
     const int64_t n_items = n_ct * n_work;
     const int64_t chunk = (n_items + 7) >> 3;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma_kernel(int64_t n_work, 
     const int rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
     const int nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
     const int rpad = (nmem + 15) / 16 * 16;                // kn_csr.hip: values of one stored column = rpad floats (members padded to bundles of 16)
-    const int64_t c0 = ct * 256 + (int64_t)wave * 64;
+    const int64_t c0 = ct * (64 * NW) + (int64_t)wave * 64;
     if (c0 >= n_vecs) return;                              // (wave-uniform)
     const int64_t c = c0 + lane;
     const bool active = c < n_vecs;
@@ -226,7 +227,7 @@ int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_
             else if (pf == 8) KN_LAUNCH(d + " pf=8", (csr_group_mfma_kernel<3, 8>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr,
                                         A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
             else KN_LAUNCH(d, (csr_group_mfma_kernel<3, 6>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
-                           A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
+                                        A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
         }
     }
     KN_HIP(hipGetLastError());
