@@ -154,6 +154,10 @@ class KeyedModel(object):
         Memory: the overlapped forward keeps two ping-pong workspaces of max_rows x N floats per (device, N) plan (VGG-16 at N = 256:
         2 x 3.3 GB) plus two side streams; at most OVERLAP_PLANS_KEPT plans are cached (least recently used dropped),
         release_workspace() drops them all."""
+        if not img_cipher.is_cuda and img_cipher.dim() == 2 and torch.cuda.is_available() and _slots_out is None:
+            # a host tensor (how the reference's users call it): ONE copy to the device here instead of one per layer, so that the layers
+            # chain on the device and the per-forward contract screen sees them; the result goes back where the input lives
+            return self.forward_linear(img_cipher.detach().float().cuda(), overlap=overlap).to(img_cipher.device)
         keyed = [c for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer)]
         on_dev = img_cipher.is_cuda and img_cipher.dim() == 2
         capturing = on_dev and torch.cuda.is_current_stream_capturing()

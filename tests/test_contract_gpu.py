@@ -221,6 +221,19 @@ def test_contract_holds_when_later_batches_are_larger(golden, family, batch, cap
     assert knet.contract_report()['recalibrations'] == n0
 
 
+def test_host_tensors_are_screened_too(golden):
+    """The reference's users hand host tensors over; the forward moves them to the device once, so the screen covers that route as well."""
+    (sensor, knet) = gain_keynet(golden)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn((8, 2, 16, 16), generator=g)
+    xc = sensor.fromtensor(x.to(dev())).encrypt().astensor().cpu()
+    y = knet.forward_linear(xc)
+    assert not y.is_cuda and knet.contract_report()['recalibrations'] == 0 and any(r['screened'] for r in knet.contract_report()['layers'])
+    yb = knet.forward_linear(200.0 * xc)
+    assert not yb.is_cuda and knet.contract_report()['recalibrations'] >= 1
+    assert torch.equal(yb, knet.forward_linear((200.0 * xc).to(dev())).cpu())
+
+
 def test_rescreen_switch_and_forced_modes(golden, monkeypatch):
     (sensor, knet) = gain_keynet(golden)
     g = torch.Generator(device=dev()).manual_seed(6)
