@@ -1260,8 +1260,15 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     if (w >= (int64_t)p.n_pix * n_cob) return;
     // wave-uniform by construction; pinned to SGPRs here so that the whole step-advance logic below stays on the scalar ALU (a value
     // that comes out of a vector-memory load counts as divergent for the compiler, and would drag the loop counters into VGPRs)
-    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[w / n_cob]);
-    const int co0 = __builtin_amdgcn_readfirstlane((int)(w % n_cob) * RBX);
+    // w -> (channel-bundle group, pixel, bundle inside the group), bundle fastest: the bundles of a pixel that run side by side share its gathered
+    // activation rows in L2.  G = p.tail_main bundles per group (0 = all n_cob: one group).  With G = n_cob / 8 every XCD's contiguous share of the
+    // items is ONE group over all pixels, so its slice of the taps (1/8 of 9.4 MB on the 512-channel layers) stays L2-resident for the scalar loads.
+    const int G = p.tail_main > 0 ? p.tail_main : n_cob;
+    const int64_t per_group = (int64_t)p.n_pix * G;
+    const int cg = (int)(w / per_group);
+    const int64_t rem = w - (int64_t)cg * per_group;
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[rem / G]);
+    const int co0 = __builtin_amdgcn_readfirstlane((cg * G + (int)(rem % G)) * RBX);
     const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
     const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
     const int64_t c = ct * 256 + (int64_t)lane * 4;
@@ -1847,6 +1854,20 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         const int rbx = (pipe && pipe_mode >= 16 && A.Cout % 16 == 0 && (int64_t)a.n_pix * (A.Cout / 16) * n_ct >= 4096) ? 16 : 8;
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
         const int64_t n_rb = ((int64_t)a.n_pix * n_cob + 3) / 4;
+        // Channel-bundle groups (convtaps_exact_pipe_kernel): with g groups every XCD works on 1/g (g = 8) or 2/g of the output channels for all
+        // pixels, so its share of the taps stays in its 4 MiB L2 for the scalar tap loads -- 9.4 MB of taps on the 512-channel layers of VGG-16.
+        // Same-process A/B, exact mode, ms at 1 / 4 / 8 groups: conv3_2 (2.4 MB of taps) 13.63 / 13.49 / 14.60, conv4_1 6.99 / 6.75 / 6.84,
+        // conv4_2 14.05 / 13.54 / 13.48, conv4_3 14.01 / 13.34 / 13.53, conv5_1 4.26 / 3.82 / 3.82, conv5_2 4.24 / 3.84 / 4.10; layers with small tap
+        // matrices lose 5 % (conv1_2, conv2_x: the bundles of a pixel no longer share its gathered rows in one XCD).  Rule: 4 groups when the taps exceed a
+        // quarter of the L2.  KN_EXACT_COB_GROUPS=g overrides (A/B knob, read per call).
+        a.tail_main = 0;
+        {
+            const int64_t tap_bytes = 4 * A.ntaps * A.cin_pad * A.cout_pad;
+            int g = tap_bytes > (1 << 20) ? 4 : 1;
+            if (const char* e = getenv("KN_EXACT_COB_GROUPS")) g = atoi(e);
+            while (g > 1 && n_cob % g != 0) g >>= 1;
+            if (g > 1) a.tail_main = n_cob / g;
+        }
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
         // products on the matrix pipe (convtaps_exact_mfma_kernel): whole 32-channel blocks, a batch of at least one wavefront's 64 columns.
         // OPT-IN (KN_EXACT_MFMA=1, read per call; KN_EXACT_MFMA_NRB=1|2|3 picks the channel blocks per workgroup): bit-exact like the vector-ALU
