@@ -68,3 +68,34 @@ def test_exact_conv_matrix_pipe_on_a_column_window(monkeypatch):
     ref = np.maximum(oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), np.ascontiguousarray(x[:, 128:384].cpu().numpy())), 0)
     got = y.cpu().numpy()
     assert np.array_equal(got[:, 128:384], ref) and np.all(got[:, :128] == 7.0) and np.all(got[:, 384:] == 7.0)
+
+
+@pytest.mark.parametrize('groups', ['1', '2', '4', '8'])
+def test_exact_pipeline_channel_bundle_groups(groups, monkeypatch):
+    """convtaps_exact_pipe_kernel deals (channel-bundle group, pixel, bundle) work items so that an XCD keeps its slice of the taps in L2 (the
+    default on operators with more than 1 MB of taps: VGG-16 conv3_x .. conv5_x); any grouping is the same arithmetic: bit-equal to the oracle."""
+    monkeypatch.setenv('KN_EXACT_COB_GROUPS', groups)
+    for (cin, cout, hw, gain) in ((16, 128, 9, False), (8, 256, 5, True)):
+        W = conv_operator(cin, cout, hw, seed=cin + int(groups), gain=gain)
+        rng = np.random.RandomState(3)
+        n_vecs = 512
+        X = np.vstack((rng.randn(cin * hw * hw, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+        xd = torch.as_tensor(X).to(dev())
+        with torch.cuda.device(dev()):
+            assert 'convtaps_exact_pipe_kernel' in W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        M = W.rows_csr()
+        ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+        y = W.torchdot(xd, relu=True, exact=True).cpu().numpy()
+        assert np.array_equal(y, np.maximum(ref, 0)), (groups, cin, cout)
+
+
+def test_exact_pipeline_default_grouping_on_a_large_tap_matrix():
+    """More than 1 MB of taps (here 256 x 256 channels x 9 taps = 2.4 MB): the default rule groups the channel bundles; bit-equal to the oracle."""
+    W = conv_operator(256, 256, 4, seed=11)
+    rng = np.random.RandomState(5)
+    n_vecs = 256
+    X = np.vstack((rng.randn(256 * 16, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    M = W.rows_csr()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    y = W.torchdot(torch.as_tensor(X).to(dev()), relu=False, exact=True).cpu().numpy()
+    assert np.array_equal(y, ref)
