@@ -335,6 +335,14 @@ def layer_table(knet, batch):
             nnz_exp = op.nnz_expanded()
             kind = 'convexact' if exact else ('smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps')
             wbytes = 4 * c.W.nnz()             # taps + entries + last column actually read
+        elif isinstance(c.W, ksp.FactoredSparseMatrix):
+            # an untiled keyed conv whose stored CSR is provably the expansion of its factored form: runs the order-preserving conv pipeline from
+            # the taps (sparse.py: FactoredSparseMatrix); algorithmic MACs = the stored non-zeros of the reference's CSR
+            op = c.W._device_op()
+            (r, cdim) = op.shape()
+            nnz_exp = int(c.W.nnz())
+            kind = 'convexact'
+            wbytes = 4 * c.W._factored.nnz()   # taps + entries + last column actually read
         else:
             op = c.W._device_op()
             (r, cdim) = op.shape()
@@ -548,7 +556,7 @@ def oracle_parity_csr(knet, x_cipher, logits, n_img=8):
     i = 0
     while i < len(children):
         (name, c) = children[i]
-        if not isinstance(c, KeyedLayer) or type(c.W) is not ksp.SparseMatrix:
+        if not isinstance(c, KeyedLayer) or not isinstance(c.W, ksp.SparseMatrix) or isinstance(c.W, ksp.TiledMatrix):
             return {'check': 'CPU oracle on every layer', 'ok': None, 'skipped': 'layer %s is not a plain stored-order CSR operator' % name}
         fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
         (ip, ix, dt) = ksp._stored_order_csr(c.W._matrix)

@@ -104,6 +104,16 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3],
                        const float* lastcol,
                        kn_handle_t* out);
 
+/* Declares that the ZERO-valued entries of a kn_convtaps_create operator's expansion are ABSENT from the reference operator it stands for.
+ * A tiled reference operator keeps the zeros of its dense channel matrices as explicit entries (keynet/sparse.py:802-812), and 0 * Inf = NaN
+ * reaches its output like any other entry; an UNTILED keyed conv layer is a scipy CSR (keynet/layer.py:24-41) from which the keying SpGEMM
+ * has dropped every exact zero (a filter weight the reference's value round trip turned into 0.0).  When such a CSR is stored in ascending
+ * column order -- identity / channel-replicated permutation keys on both sides -- its product in stored order IS the factored operator's
+ * order-preserving product (KN_FLAG_EXACT), entry for entry, and the host may hand over the 0.3 MB of taps instead of the CSR's hundreds of
+ * MB; after this call kn_spmm with KN_FLAG_EXACT additionally restores, for batch columns whose activation at such an absent position is not
+ * finite, exactly what the reference's row (without that entry) computes.  KN_ERR_UNSUPPORTED on other operator kinds. */
+int kn_convtaps_drop_zero_entries(kn_handle_t h);
+
 /* A DENSE operator (keyed nn.Linear: keynet/layer.py:67-70 stores it as a sparse matrix whose every entry is present)
  * for callers that accept the float-key tolerance (1e-5) instead of scipy's exact accumulation order -- i.e. the tiled
  * key-nets, whose conv layers already run on the matrix cores.  W is the full keyed matrix, HOST, row-major

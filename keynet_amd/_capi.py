@@ -20,7 +20,7 @@ KN_ABI_VERSION = 2
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
+           'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -57,6 +57,7 @@ def lib():
         L.kn_conv2dtiled_create.argtypes = [i64, i64, p, p, i64, p, i64, p, p, p, p, p]
         L.kn_convtaps_create.argtypes = [p, p, i64, p, i64, p, p, p, p, p, p]
         L.kn_dense_create.argtypes = [i64, i64, p, p]
+        L.kn_convtaps_drop_zero_entries.argtypes = [p]
         L.kn_chain_create.argtypes = [i64, p, p, p]
         L.kn_destroy.argtypes = [p]
         L.kn_nnz.argtypes = [p, p]
@@ -171,6 +172,11 @@ class Operator(object):
         h = ctypes.c_void_p()
         check(lib().kn_convtaps_create(insp, outsp, int(tp.shape[0]), tpp, int(len(eo)), eop, eip, etp, ecp, lcp, ctypes.byref(h)))
         return Operator(h)
+
+    def drop_zero_entries(self):
+        """kn_convtaps_drop_zero_entries: zero-valued entries of the expansion are absent from the reference operator (an untiled keyed conv CSR)."""
+        check(lib().kn_convtaps_drop_zero_entries(self._h))
+        return self
 
     @staticmethod
     def dense(W):

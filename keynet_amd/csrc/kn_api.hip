@@ -501,6 +501,36 @@ int kn_convtaps_create(const int64_t inshape[3], const int64_t outshape[3], int6
     });
 }
 
+int kn_convtaps_drop_zero_entries(kn_handle_t h) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    KN_REQUIRE(h->kind == KIND_CONVTAPS && h->dense_sub == nullptr, KN_ERR_UNSUPPORTED, "kn_convtaps_drop_zero_entries: not a conv-taps operator");
+    std::lock_guard<std::mutex> g(h->lazy_mu);
+    if (h->ct.zero_ent != nullptr) return KN_OK;
+    const ConvTapsDev& c = h->ct;
+    std::vector<int32_t> z;
+    for (int64_t t = 0; t < c.ntaps; t++) {
+        const float* T = h->h_taps.data() + (size_t)(t * c.Cout * c.Cin);
+        bool any = false;
+        for (int64_t k = 0; k < c.Cout * c.Cin && !any; k++) any = T[k] != 0.0f;
+        if (!any) continue;                                   // a tap that is zero altogether has no slots at all (convtaps_create_impl)
+        for (int64_t co = 0; co < c.Cout; co++)
+            for (int64_t ci = 0; ci < c.Cin; ci++)
+                if (T[co * c.Cin + ci] == 0.0f) {
+                    z.push_back((int32_t)t);
+                    z.push_back((int32_t)co);
+                    z.push_back((int32_t)ci);
+                }
+    }
+    int32_t* d = nullptr;
+    int rc = upload(&d, z.data(), z.size());
+    if (rc) return rc;
+    h->ct.zero_ent = d;
+    h->ct.n_zero = (int64_t)(z.size() / 3);
+    return KN_OK;
+    });
+}
+
 int kn_dense_create(int64_t rows, int64_t cols, const float* W, kn_handle_t* out) {
     return guarded([&]() -> int {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");

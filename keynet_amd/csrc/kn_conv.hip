@@ -1624,6 +1624,48 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_mfma_kernel(ConvArgs p,
     }
 }
 
+// kn_convtaps_drop_zero_entries: the reference's UNTILED keyed conv CSR has no entry where a tap value is exactly 0, the order-preserving kernels
+// above add fl(0 * x) there -- the same bits while x is finite (+-0 added to a sum that is never -0), a NaN the reference does not have when it
+// is not.  One thread per (zero entry z = (tap, co, ci), output pixel o, batch column b): if the pixel has a slot with that tap and the activation
+// it would have read is not finite, output (co, o, b) is recomputed in the reference's own sequence -- every stored entry except the zero-valued
+// ones, channel outer, slots by ascending input pixel inner, bias last -- with separate multiply and add.  Nothing to do otherwise (the usual case).
+__global__ __launch_bounds__(256) void convtaps_zero_guard_kernel(ConvArgs p, const int32_t* __restrict__ zero_ent, int64_t n_zero) {
+    const int64_t n_ct = (p.n_vecs + 255) / 256;
+    const int64_t blk = blockIdx.x;
+    const int64_t zo = blk / n_ct;                                   // (zero entry, pixel) pair
+    const int64_t b = (blk - zo * n_ct) * 256 + threadIdx.x;
+    if (zo >= n_zero * p.HoWo || b >= p.n_vecs) return;
+    const int z = (int)(zo / p.HoWo), o = (int)(zo % p.HoWo);
+    const int t = zero_ent[3 * z], co = zero_ent[3 * z + 1], ci = zero_ent[3 * z + 2];
+    const int s0 = p.pix_ptr[o], s1 = p.pix_ptr[o + 1];
+    bool bad = false;
+    for (int s = s0; s < s1; s++)
+        if (p.slot_tap[s] == t) {
+            const float xv = p.X[((int64_t)ci * p.HiWi + p.slot_in[s]) * p.ldx + b];
+            bad = bad || !(__builtin_fabsf(xv) <= 3.4028234663852886e38f);
+        }
+    if (!bad) return;
+    float acc = 0.0f;
+    for (int c2 = 0; c2 < p.Cin; c2++)
+        for (int s = s0; s < s1; s++) {
+            float a = p.tapsT[((int64_t)p.slot_tap[s] * p.cin_pad + c2) * p.cout_pad + co];
+            if (!p.unit_coef) a = p.slot_coef[s] * a;               // the reference's stored value: fl(coef * tap)
+            if (a == 0.0f) continue;                                 // absent from the reference's row
+            const float pr = a * p.X[((int64_t)c2 * p.HiWi + p.slot_in[s]) * p.ldx + b];
+            acc = acc + pr;
+        }
+    const int64_t row = (int64_t)co * p.HoWo + o;
+    if (p.lastcol) {
+        const float lc = p.lastcol[row];
+        if (lc != 0.0f) {
+            const float bp = p.X[p.last_in_row * p.ldx + b] * lc;
+            acc = acc + bp;
+        }
+    }
+    if (p.relu) acc = (acc < 0.0f) ? 0.0f : acc;
+    p.Y[row * p.ldy + b] = acc;
+}
+
 // homogeneous row of the output:  Y[last, b] = lastcol[last] * X[last, b]
 __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restrict__ lastcol, int64_t out_last, const float* __restrict__ xlast,
                                                            float* __restrict__ ylast, int64_t n_vecs, int relu, float* absmax) {
@@ -1639,7 +1681,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();
@@ -1898,6 +1940,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
             const int64_t out_last = A.Cout * A.Hout * A.Wout;
             KN_LAUNCH("conv_lastrow_kernel", conv_lastrow_kernel, dim3((unsigned)std::min<int64_t>((n_vecs + 255) / 256, 256)), dim3(256), 0, s, A.lastcol, out_last,
                                x + a.last_in_row * ldx, y + out_last * ldy, n_vecs, a.relu, a.absmax);
+        }
+        if (A.n_zero > 0) {                                  // kn_convtaps_drop_zero_entries: behind the main kernel, on its stream
+            const int64_t gz = A.n_zero * a.HoWo * ((n_vecs + 255) / 256);
+            KN_REQUIRE(gz < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "too many zero-valued tap entries for the guard launch");
+            KN_LAUNCH("convtaps_zero_guard_kernel<" + std::to_string(A.n_zero) + " zero tap entries>", convtaps_zero_guard_kernel, dim3((unsigned)gz), dim3(256), 0, s, a, A.zero_ent, A.n_zero);
         }
         KN_HIP(hipGetLastError());
         return KN_OK;

@@ -194,6 +194,10 @@ struct ConvTapsDev {
     // processing order, or null when the operator is not eligible
     int32_t* sk_desc = nullptr;
     int64_t sk_stride = 0, sk_tab_rows = 0;
+    // kn_convtaps_drop_zero_entries: zero-valued tap entries (tap, co, ci) of taps that are not zero altogether -- absent from the reference's
+    // untiled CSR; convtaps_zero_guard_kernel re-walks the affected output rows for batch columns with a non-finite activation there
+    int32_t* zero_ent = nullptr;        // [n_zero][3]
+    int64_t n_zero = 0;
     // bf16x3 path (kn_conv.hip, convtaps_bf16x3_kernel): the taps as three bf16 planes, built at the first kn_spmm that asks for them
     uint16_t* tapsB = nullptr;
     int64_t tapsB_plane = 0;

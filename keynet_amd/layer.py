@@ -45,6 +45,16 @@ def _conv_operator(m, inshape, outshape, A, Ainv, tileshape, direct):
         return ksp.Conv2dTiledMatrix.fromtaps(tileshape=tileshape, **kdirect.keyed_conv_taps(w, b, inshape, outshape, stride, A, Ainv))
     W = _sandwich(A, sparse_toeplitz_conv2d(inshape, w, bias=b, stride=stride), Ainv)
     if tileshape is None:
+        # An untiled keyed conv whose stored CSR is, provably, the ascending-column expansion of its factored form (identity / channel-replicated
+        # permutation keys on both sides: every conv layer of PermutationKeynet AllConvNet but the first) is handed to the device in factored form:
+        # same bits (the proof is entry for entry, order included), 0.3 MB of taps instead of the CSR's hundreds of MB.  See FactoredSparseMatrix.
+        if W.nnz >= KeyedLayer.FACTOR_UNTILED_MIN_NNZ:
+            try:
+                F = ksp.Conv2dTiledMatrix.fromtaps(tileshape=None, **kdirect.keyed_conv_taps(w, b, inshape, outshape, stride, A, Ainv))
+                if ksp.FactoredSparseMatrix.proven(W.tocsr() if W.format != 'csr' else W, F):
+                    return ksp.FactoredSparseMatrix(W, F)
+            except (ValueError, AssertionError):
+                pass                                    # keys that are not channel-replicated (a global permutation): the CSR it is
         return W
     return ksp.Conv2dTiledMatrix(W, inshape, outshape, tileshape, bias=True, sanitycheck=False)
 
@@ -117,6 +127,7 @@ class KeyedLayer(nn.Module):
     """One keyed layer of a key-net: holds W_hat = A . W . A_prev^-1 as an HBM-resident operator and applies it."""
 
     DIRECT_THRESHOLD = 20000000   # Toeplitz entries above which tiled conv/pool layers are keyed in factored form
+    FACTOR_UNTILED_MIN_NNZ = 1000000     # untiled conv layers at least this large are checked for a factored device form (FactoredSparseMatrix)
 
     def __init__(self, module, inshape, outshape, A, Ainv, tileshape=None, direct=None, exact=None):
         """module: the source nn.Conv2d / nn.AvgPool2d / nn.Linear / nn.ReLU; A: this layer's output key (None = leave the

@@ -210,6 +210,57 @@ class SparseMatrix(object):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+class FactoredSparseMatrix(SparseMatrix):
+    """An UNTILED keyed conv layer (keynet/layer.py:24-41: a scipy CSR, `SparseMatrix`) whose stored CSR has been PROVEN, on the host, to be the
+    ascending-column expansion of a factored conv operator (taps x spatial entries, keynet_amd/direct.py) with the exact zeros dropped.  That is
+    what the keying SpGEMMs leave for identity / channel-replicated permutation keys on both sides -- every conv layer of PermutationKeynet
+    AllConvNet but the first.  scipy's product in stored order is then, entry for entry, the factored operator's order-preserving product
+    (KN_FLAG_EXACT: channel outer, the pixel's slots by ascending input pixel inner, bias last), so the device holds 0.3 MB of taps + the slot lists
+    instead of the CSR's hundreds of MB and runs the conv pipeline; kn_convtaps_drop_zero_entries covers the dropped zeros.  Everything on the
+    host (`_matrix`, nnz(), tocoo(), pickling, the neutral file format) is the plain CSR container's."""
+
+    def __init__(self, A, factored):
+        super(FactoredSparseMatrix, self).__init__(A)
+        self._factored = factored
+
+    def __repr__(self):
+        return str('<keynet_amd.SparseMatrix: H=%d, W=%d, backend=hip (factored on the device)>' % (self.shape[0], self.shape[1]))
+
+    def _device_op(self, device=None):
+        def make():
+            t = self._factored._taps
+            return _capi.Operator.convtaps(self._factored._inshape, self._factored._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'], t['ent_coef'],
+                                           t['lastcol']).drop_zero_entries()
+        return _on_device(self, '_op', make, device)
+
+    def _dense_device_op(self, device=None):
+        return None
+
+    def torchdot(self, x_torch, relu=False, exact=True, absmax=None):
+        return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True, absmax=absmax)       # always the reference's order
+
+    @staticmethod
+    def proven(M, factored, max_zero_fraction=0.01):
+        """Is the stored CSR `M` (scipy) exactly -- indptr, indices AND values, in stored order -- the canonical expansion of `factored` with its
+        zero-valued entries removed?  Also refuses operators with many exact zeros (a pruned filter): the device re-checks every such entry."""
+        t = factored._taps
+        if t is None or M.format != 'csr' or tuple(M.shape) != tuple(factored.shape):
+            return False
+        taps = t['taps']
+        live = taps[np.any(taps.reshape(taps.shape[0], -1) != 0, axis=1)]
+        if live.size and float(np.count_nonzero(live == 0)) > max_zero_fraction * live.size:
+            return False
+        E = factored.rows_csr()
+        keep = E.data != 0
+        if M.nnz != int(np.count_nonzero(keep)):
+            return False
+        counts = np.add.reduceat(keep, E.indptr[:-1].astype(np.int64)) if E.nnz else np.zeros(E.shape[0], np.int64)
+        counts[np.diff(E.indptr) == 0] = 0                                   # (reduceat on an empty row returns the next element)
+        (ip, ix, dt) = _stored_order_csr(M)
+        return bool(np.array_equal(np.concatenate(([0], np.cumsum(counts))).astype(np.int64), ip.astype(np.int64)) and
+                    np.array_equal(E.indices[keep].astype(np.int32), ix) and np.array_equal(E.data[keep].view(np.uint32), dt.view(np.uint32)))
+
+
 def _structure_preserving(vals64):
     """The reference stores tile values as ((v + off) - off) with off = |min v| + 1 computed in float64, then casts to
     float32 (keynet/sparse.py:562-566, 582): reproduced so tile contents match bit for bit."""

@@ -117,6 +117,10 @@ def main():
         assert L.kn_spmm_plan(op.handle, 256, 256, 256, 0, buf, 1024) == 0 and b'kernel' in buf.value       # the dispatch logic is host code too
         assert L.kn_spmm_plan(op.handle, 256, 256, 256, 2, buf, 1024) == 0
         assert L.kn_spmm_plan(op.handle, 256, 256, 256, 4, buf, 1024) == 0
+        taps[0, 0, 0] = 0.0
+        op2 = capi.Operator.convtaps((cin, hw, hw), (cout, hw, hw), taps, np.array(eo, np.int32), np.array(ei, np.int32), np.array(et, np.int32), ec, lc).drop_zero_entries()
+        assert L.kn_spmm_plan(op2.handle, 256, 256, 256, 2, buf, 1024) == 0 and (dup or b'convtaps_zero_guard_kernel<1 zero tap entries>' in buf.value)
+        del op2
         n_ops += 1
     # ---- dense (keyed nn.Linear on the split-K path): slicing into pseudo-pixels ----------------------------------------------------------------
     D = rng.randn(37, 513).astype(np.float32)
