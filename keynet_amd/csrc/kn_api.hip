@@ -527,6 +527,54 @@ int kn_convtaps_drop_zero_entries(kn_handle_t h) {
     if (rc) return rc;
     h->ct.zero_ent = d;
     h->ct.n_zero = (int64_t)(z.size() / 3);
+    // The stored-column table of the expansion for the matrix-pipe kernel (kn_csr_mfma.hip, TAPS): per output pixel, channel outer and the pixel's slots
+    // by ascending input pixel inner -- the order of convtaps_create_impl's slot lists -- each column as (activation row, value row of tapsT).  Unit
+    // coefficients only (a coefficient entry's stored value is fl(coef * tap): the conv pipeline handles those), no duplicate (pixel, pixel) pairs, and
+    // at most 64 M columns (512 MB); otherwise the operator simply has no table and KN_FLAG_EXACT takes the conv pipeline.
+    if (c.unit_coef && !c.has_dups && c.Cout % 32 == 0) {
+        const int64_t HoWo = c.Hout * c.Wout, HiWi = c.Hin * c.Win;
+        const size_t nent = h->h_ent_out.size();
+        std::vector<char> tap_zero((size_t)std::max<int64_t>(c.ntaps, 1), 1);
+        for (int64_t t = 0; t < c.ntaps; t++)
+            for (int64_t k = 0; k < c.Cout * c.Cin; k++)
+                if (h->h_taps[(size_t)(t * c.Cout * c.Cin + k)] != 0.0f) {
+                    tap_zero[(size_t)t] = 0;
+                    break;
+                }
+        std::vector<size_t> order;
+        order.reserve(nent);
+        for (size_t e = 0; e < nent; e++)
+            if (!tap_zero[(size_t)h->h_ent_tap[e]] && h->h_ent_coef[e] != 0.0f) order.push_back(e);
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            return h->h_ent_out[x] != h->h_ent_out[y] ? h->h_ent_out[x] < h->h_ent_out[y] : h->h_ent_in[x] < h->h_ent_in[y];
+        });
+        std::vector<int64_t> pp((size_t)HoWo + 1, 0);
+        for (size_t k = 0; k < order.size(); k++) pp[(size_t)h->h_ent_out[order[k]] + 1]++;
+        for (int64_t o = 0; o < HoWo; o++) pp[(size_t)o + 1] += pp[(size_t)o];
+        const int64_t total = (int64_t)order.size() * c.Cin;
+        if (total > 0 && total <= ((int64_t)64 << 20) && (c.Cin * HiWi + 1) < INT32_MAX && c.ntaps * c.cin_pad < INT32_MAX) {
+            std::vector<int32_t> ex_ptr((size_t)HoWo + 1), ex_tab((size_t)(2 * total));
+            for (int64_t o = 0; o <= HoWo; o++) ex_ptr[(size_t)o] = (int32_t)(pp[(size_t)o] * c.Cin);
+            for (int64_t o = 0; o < HoWo; o++) {
+                const int64_t s0 = pp[(size_t)o], ns = pp[(size_t)o + 1] - s0;
+                int32_t* out = ex_tab.data() + (size_t)(2 * s0 * c.Cin);
+                for (int64_t ci = 0; ci < c.Cin; ci++)
+                    for (int64_t sl = 0; sl < ns; sl++) {
+                        const size_t e = order[(size_t)(s0 + sl)];
+                        *out++ = (int32_t)(ci * HiWi + h->h_ent_in[e]);
+                        *out++ = (int32_t)(h->h_ent_tap[e] * c.cin_pad + ci);
+                    }
+            }
+            int32_t *dp = nullptr, *dt = nullptr;
+            if ((rc = upload(&dp, ex_ptr.data(), ex_ptr.size()))) return rc;
+            if ((rc = upload(&dt, ex_tab.data(), ex_tab.size()))) {
+                (void)hipFree(dp);
+                return rc;
+            }
+            h->ct.ex_ptr = dp;
+            h->ct.ex_tab = dt;
+        }
+    }
     return KN_OK;
     });
 }

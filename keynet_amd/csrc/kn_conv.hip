@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX, bool COEF = false>
+template <int RBX, bool COEF = false, int XD = 2>       // XD = activation rows in flight per wavefront (2, or 4 for wide batches: see the launcher)
 __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
     const int64_t n_ct = (p.n_vecs + 255) / 256;
     const int64_t n_items = n_ct * n_rb;
@@ -1292,35 +1292,38 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         const int ch_x = __builtin_amdgcn_readfirstlane(p.HiWi * (int)p.ldx);      // one input channel of X
         const float* a_base = p.tapsT + co0;
         const int n_q = n_slots * p.Cin;
-        int s = 0, ci_x = 0, ci_a = 0;                           // wave-uniform walk: slot inner, channel outer
-        int q_next = 0;                                          // step whose operands are fetched next
+        // two wave-uniform cursors over the steps (slot inner, channel outer): the activation rows may run further ahead than the tap values
+        int s = 0, ci_x = 0, q_next = 0;                         // cursor of the activation-row requests
+        int s_a = 0, ci_a = 0, q_a = 0;                          // cursor of the tap-value requests
         // Operand fetch of one step, written as inline asm so that both addresses stay scalar: the activation row is a saddr-form vector
         // load (wave-uniform 64-bit base in SGPRs + the lane's constant byte offset: no per-step vector address arithmetic), the step's
         // RBX tap values one s_load into an SGPR tuple that the packed multiplies read directly.  The compiler's waitcnt bookkeeping does
-        // not see these loads; the waits are written out below.
+        // not see these loads; the waits are written out below.  Each fetch advances its cursor, branch-free (selects on wave-uniform
+        // values, all on the scalar ALU); past the end the last step's operands are fetched again, so the waits stay counted ones.
         typedef float taps_t __attribute__((ext_vector_type(RBX)));
         auto fetch_x = [&](f32x4& xr) {
             const int xo = __builtin_amdgcn_readlane(my_xoff, s) + ci_x;
             const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
             asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
-        };
-        auto fetch_a = [&](taps_t& ar, float& cf) {
-            const int ao = __builtin_amdgcn_readlane(my_aoff, s) + ci_a;
-            const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
-            if constexpr (RBX == 16) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
-            else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
-            if constexpr (COEF) cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), s));
-        };
-        // Branch-free advance (selects on wave-uniform values, all on the scalar ALU).  Past the end the last step's operands are
-        // fetched again: exactly one activation row stays in flight and the wait is a counted one.
-        auto advance = [&]() {
             q_next++;
             const bool more = q_next < n_q;
             const bool wrap = (s + 1 == n_slots);
             s = more ? (wrap ? 0 : s + 1) : s;
             ci_x = __builtin_amdgcn_readfirstlane(ci_x + ((more && wrap) ? ch_x : 0));
+        };
+        auto fetch_a = [&](taps_t& ar, float& cf) {
+            const int ao = __builtin_amdgcn_readlane(my_aoff, s_a) + ci_a;
+            const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
+            if constexpr (RBX == 16) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
+            else asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(ar) : "s"(aaddr));
+            if constexpr (COEF) cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), s_a));
+            q_a++;
+            const bool more = q_a < n_q;
+            const bool wrap = (s_a + 1 == n_slots);
+            s_a = more ? (wrap ? 0 : s_a + 1) : s_a;
             ci_a = ci_a + ((more && wrap) ? p.cout_pad : 0);
         };
+        auto advance = [&]() {};                                 // (the fetches advance their own cursors)
         // the "+" operands make the multiplies that follow depend on the wait
         auto taps_landed = [&](taps_t& ar) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ar)); };
         auto row_landed = [&](f32x4& xr, auto younger) {                 // vector loads return in order
@@ -1381,6 +1384,35 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         // Two steps per trip, operands double-buffered.  Step q+1's tap load is issued right after step q's taps have landed (scalar
         // loads return out of order, so lgkmcnt can only be waited to zero) and its activation row right after that; both have step q's
         // 2*RBX packed multiplies / adds to land.  kn_order() keeps the compiler from moving the arithmetic across the fetches.
+        if constexpr (XD == 4) {
+            // FOUR activation rows in flight (wide batches: a gathered row of a [D, 4096] block misses L2 -- the grouped CSR pipeline's finding),
+            // tap values one step ahead as before.  One step: this step's taps have landed -> request the next step's -> wait for this step's
+            // row (three younger rows stay in flight) -> arithmetic -> request the row four steps ahead into the register just released.
+            f32x4 x0, x1, x2, x3;
+            taps_t a0, a1;
+            float c0 = 1.0f, c1 = 1.0f;
+            fetch_x(x0);
+            fetch_x(x1);
+            fetch_x(x2);
+            fetch_x(x3);
+            fetch_a(a0, c0);
+            auto step4 = [&](const int q, f32x4& xq, taps_t& aq, float& cq, taps_t& an, float& cn) {
+                taps_landed(aq);
+                fetch_a(an, cn);
+                row_landed(xq, std::integral_constant<int, 3>());
+                kn_order();
+                if (q < n_q) mac(xq, aq, cq);
+                kn_order();
+                fetch_x(xq);
+            };
+            for (int q = 0; q < n_q; q += 4) {
+                step4(q, x0, a0, c0, a1, c1);
+                step4(q + 1, x1, a1, c1, a0, c0);
+                step4(q + 2, x2, a0, c0, a1, c1);
+                step4(q + 3, x3, a1, c1, a0, c0);
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(a0));
+        } else {
         f32x4 x0, x1;
         taps_t a0, a1;
         float c0 = 1.0f, c1 = 1.0f;
@@ -1409,6 +1441,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         taps_landed(a0);
         row_landed(x0, std::integral_constant<int, 0>());
         if (q < n_q) mac(x0, a0, c0);
+        }
     }
     if (!active) return;
     const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
@@ -1681,7 +1714,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent, c.ex_ptr, c.ex_tab};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();
@@ -1900,24 +1933,37 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         // pixels, so its share of the taps stays in its 4 MiB L2 for the scalar tap loads -- 9.4 MB of taps on the 512-channel layers of VGG-16.
         // Same-process A/B, exact mode, ms at 1 / 4 / 8 groups: conv3_2 (2.4 MB of taps) 13.63 / 13.49 / 14.60, conv4_1 6.99 / 6.75 / 6.84,
         // conv4_2 14.05 / 13.54 / 13.48, conv4_3 14.01 / 13.34 / 13.53, conv5_1 4.26 / 3.82 / 3.82, conv5_2 4.24 / 3.84 / 4.10; layers with small tap
-        // matrices lose 5 % (conv1_2, conv2_x: the bundles of a pixel no longer share its gathered rows in one XCD).  Rule: 4 groups when the taps exceed a
-        // quarter of the L2.  KN_EXACT_COB_GROUPS=g overrides (A/B knob, read per call).
+        // matrices lose 5 % (conv1_2, conv2_x: the bundles of a pixel no longer share its gathered rows in one XCD).  Rule: 4 groups when the taps exceed half
+        // of the L2 (2 MB: VGG-16 conv3_x and up; AllConvNet's 192-channel layers, 1.3 MB at 16 column tiles per layer, lose 10 % when grouped).  KN_EXACT_COB_GROUPS=g overrides (A/B knob, read per call).
         a.tail_main = 0;
         {
             const int64_t tap_bytes = 4 * A.ntaps * A.cin_pad * A.cout_pad;
-            int g = tap_bytes > (1 << 20) ? 4 : 1;
+            int g = tap_bytes > (2 << 20) ? 4 : 1;
             if (const char* e = getenv("KN_EXACT_COB_GROUPS")) g = atoi(e);
             while (g > 1 && n_cob % g != 0) g >>= 1;
             if (g > 1) a.tail_main = n_cob / g;
         }
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
+        // a factored stand-in of an untiled CSR that carries the stored-column table (kn_convtaps_drop_zero_entries) on a wide batch: the matrix-pipe
+        // grouped kernel reads its values from the tap table (kn_csr_mfma.hip, TAPS).  KN_NO_EXACT_TABLE=1 = A/B switch (read per call).
+        const bool table = A.ex_tab != nullptr && n_vecs >= 128 && getenv("KN_NO_EXACT_TABLE") == nullptr;
+        if (table) {
+            int rc = convtaps_exact_table_spmm(A, x, ldx, n_vecs, y, ldy, a.relu, s);
+            if (rc) return rc;
+        }
+        // four activation rows in flight when the batch spans several 256-column tiles (the rows of a [D, 4096] block are L2 misses; at one tile --
+        // VGG-16 at 256 images -- three rows in flight measured 2-3 % slower than two).  KN_EXACT_XD=2|4 overrides (A/B knob, read per call).
+        bool xd4 = n_ct >= 4;
+        if (const char* e = getenv("KN_EXACT_XD")) xd4 = atoi(e) == 4;
         // products on the matrix pipe (convtaps_exact_mfma_kernel): whole 32-channel blocks, a batch of at least one wavefront's 64 columns.
         // OPT-IN (KN_EXACT_MFMA=1, read per call; KN_EXACT_MFMA_NRB=1|2|3 picks the channel blocks per workgroup): bit-exact like the vector-ALU
         // pipeline, but measured 4-8 % SLOWER than it on every keyed VGG-16 layer (round 4, same-process A/B: conv3_2 13.38 ms against 14.49; the
         // f32 matrix instruction runs on the vector ALU's own FP32 lanes, so the two do not overlap, and the hand-scheduled pipeline already
         // sits at 0.84-0.88 of the no-FMA roof with five wavefronts per SIMD against three here).
-        const bool mf = pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_EXACT_MFMA") != nullptr && getenv("KN_EXACT_MFMA")[0] == '1';
-        if (mf) {
+        const bool mf = !table && pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_EXACT_MFMA") != nullptr && getenv("KN_EXACT_MFMA")[0] == '1';
+        if (table) {
+            // (launched above)
+        } else if (mf) {
             int nrb = (A.Cout % 64 == 0) ? 2 : 1;
             if (const char* e = getenv("KN_EXACT_MFMA_NRB")) nrb = atoi(e);
             if (nrb < 1 || nrb > 3 || A.Cout % (32 * nrb) != 0) nrb = 1;
@@ -1930,7 +1976,9 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
             else { if (A.unit_coef) KN_EXM(3, false); else KN_EXM(3, true); }
 #undef KN_EXM
         } else
-        if (pipe && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16>", (convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe && rbx == 16 && A.unit_coef && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,rows in flight=4>", (convtaps_exact_pipe_kernel<16, false, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16 && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef,rows in flight=4>", (convtaps_exact_pipe_kernel<16, true, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16>", (convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef>", (convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef>", (convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);

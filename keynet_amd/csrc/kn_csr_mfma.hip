@@ -40,13 +40,28 @@ static __device__ __forceinline__ void mfma_static_for(F&& f) {
     }
 }
 
-template <int NRB, int PF, int NW = 4>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
+// TAPS: the same kernel on a FACTORED conv operator (kn_convtaps_drop_zero_entries: an untiled keyed conv CSR proven to be the ascending-column expansion
+// of taps x slots): group = output pixel, members = output channels, stored column j of pixel o = ex_tab[ex_ptr[o] + j] = (activation row, index of the
+// value row in tapsT) -- the A operand is 128 contiguous bytes of tapsT[tap][ci][co0 ..] instead of a slice of the CSR's per-row value copies (AllConvNet
+// conv2: 0.33 MB of taps, L2-resident, instead of 326 MB streamed once per column tile); the bias column is added last in the epilogue, like the conv kernels.
+struct MfTaps {
+    const int32_t* ex_ptr;        // [HoWo + 1]
+    const int32_t* ex_tab;        // [total][2] = (activation row, value row)
+    const float* tapsT;           // [value rows][cout_pad]
+    const float* lastcol;         // [Cout * HoWo + 1] or null
+    const int32_t* pix_order;     // [HoWo] processing order of the pixels
+    int64_t last_in_row;          // activation row of the homogeneous coordinate
+    int32_t cout_pad, HoWo, Cout, n_cc;   // n_cc = channel chunks (32 * NRB channels) per pixel
+};
+
+template <int NRB, int PF, int NW = 4, bool TAPS = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
                                             // re-reads but measured 8.5 % slower on the AllConvNet forward: 35.9 against 33.0 ms; not instantiated)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                                 const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
                                                                 const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
                                                                 const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
-                                                                const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+                                                                const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu,
+                                                                const MfTaps tp = MfTaps()) {
     static_assert((PF * NRB) % 2 == 0, "two result blocks alternate: an even number of matrix instructions per unrolled loop body");   // PF = stored columns in flight per wavefront (ring of operand registers)
     constexpr int LPS = NRB + 1;                           // vector loads per stored column
     const int64_t n_ct = (n_vecs + 64 * NW - 1) / (64 * NW);
@@ -59,13 +74,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
     const int64_t w = item - ct * n_work;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(work_grp[w]);
-    const int r0 = __builtin_amdgcn_readfirstlane(work_r0[w]);
-    const int cbeg = __builtin_amdgcn_readfirstlane(grp_colptr[g]);
-    const int ncol = __builtin_amdgcn_readfirstlane(grp_colptr[g + 1]) - cbeg;
-    const int rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
-    const int nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
-    const int rpad = (nmem + 15) / 16 * 16;                // kn_csr.hip: values of one stored column = rpad floats (members padded to bundles of 16)
+    int g, r0, cbeg, ncol, rbeg, nmem, rpad;
+    if constexpr (TAPS) {
+        g = __builtin_amdgcn_readfirstlane(tp.pix_order[w / tp.n_cc]);                   // the output pixel
+        r0 = __builtin_amdgcn_readfirstlane((int)(w % tp.n_cc) * (32 * NRB));            // first output channel of this chunk
+        cbeg = __builtin_amdgcn_readfirstlane(tp.ex_ptr[g]);
+        ncol = __builtin_amdgcn_readfirstlane(tp.ex_ptr[g + 1]) - cbeg;
+        rbeg = 0;
+        nmem = tp.Cout;
+        rpad = tp.cout_pad;
+    } else {
+        g = __builtin_amdgcn_readfirstlane(work_grp[w]);
+        r0 = __builtin_amdgcn_readfirstlane(work_r0[w]);
+        cbeg = __builtin_amdgcn_readfirstlane(grp_colptr[g]);
+        ncol = __builtin_amdgcn_readfirstlane(grp_colptr[g + 1]) - cbeg;
+        rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
+        nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
+        rpad = (nmem + 15) / 16 * 16;                      // kn_csr.hip: values of one stored column = rpad floats (members padded to bundles of 16)
+    }
     const int64_t c0 = ct * (64 * NW) + (int64_t)wave * 64;
     if (c0 >= n_vecs) return;                              // (wave-uniform)
     const int64_t c = c0 + lane;
@@ -83,28 +109,42 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
         auto uni = [](const uint64_t v) {
             return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
         };
-        const uint64_t cbase = uni(reinterpret_cast<uint64_t>(grp_cols + cbeg));
+        const uint64_t cbase = TAPS ? uni(reinterpret_cast<uint64_t>(tp.ex_tab + 2 * (int64_t)cbeg)) : uni(reinterpret_cast<uint64_t>(grp_cols + cbeg));
         const uint64_t xbase = uni(reinterpret_cast<uint64_t>(X));
-        const uint64_t vbase = uni(reinterpret_cast<uint64_t>(grp_vals + grp_valptr[g] + r0));
+        const uint64_t vbase = TAPS ? uni(reinterpret_cast<uint64_t>(tp.tapsT + r0)) : uni(reinterpret_cast<uint64_t>(grp_vals + grp_valptr[g] + r0));
         const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);                 // lane's byte offset inside an activation row (inactive lanes: a valid address, result unused)
         const uint32_t a_off = 4u * (uint32_t)(lane & 31);                       // lane's byte offset inside a row block's 32 values
         const uint64_t ldx_b = 4ull * (uint64_t)ldx;
-        const uint32_t vstep = 4u * (uint32_t)rpad;
+        const uint32_t vstep = 4u * (uint32_t)rpad;                              // (TAPS: rpad = cout_pad, one value row of tapsT)
         auto clampj = [&](const int j) { return j < ncol ? j : ncol - 1; };      // past the end: the last column again (loaded, never used)
         float xa[PF][3], xb[PF];                  // (row blocks beyond NRB: never loaded; their registers only appear in the waits' operand lists)
 #pragma unroll
         for (int q = 0; q < PF; q++) xa[q][0] = xa[q][1] = xa[q][2] = xb[q] = 0.0f;
+        typedef int i32x2 __attribute__((ext_vector_type(2)));
         int col_nxt = 0;
-        auto fetch_col = [&](const int j) {                                     // scalar: index of stored column j
-            const uint64_t caddr = cbase + 4ull * (uint64_t)(uint32_t)clampj(j);
-            asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(col_nxt) : "s"(caddr));
+        i32x2 cv_nxt = {0, 0};                                                  // TAPS: (activation row, value row) of the column whose index is on its way
+        auto fetch_col = [&](const int j) {                                     // scalar: index of stored column j (TAPS: and of its value row)
+            if constexpr (TAPS) {
+                const uint64_t caddr = cbase + 8ull * (uint64_t)(uint32_t)clampj(j);
+                asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(cv_nxt) : "s"(caddr));
+            } else {
+                const uint64_t caddr = cbase + 4ull * (uint64_t)(uint32_t)clampj(j);
+                asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(col_nxt) : "s"(caddr));
+            }
         };
-        auto col_landed = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(col_nxt)); };
+        auto col_landed = [&]() {
+            if constexpr (TAPS) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cv_nxt));
+                col_nxt = cv_nxt.x;
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(col_nxt));
+            }
+        };
         // (the operand registers are passed by reference: clang refuses a captured array element as an asm operand inside a generic lambda)
-        auto fetch = [&](float& rb, float& ra0, float& ra1, float& ra2, const int j, const int col) {   // the LPS vector loads of stored column j into one ring slot
+        auto fetch = [&](float& rb, float& ra0, float& ra1, float& ra2, const int vrow, const int col) {   // the LPS vector loads of one stored column (value row `vrow`) into one ring slot
             const uint64_t xaddr = xbase + (uint64_t)(uint32_t)col * ldx_b;
             asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(b_off), "s"(xaddr));
-            const uint64_t va = vbase + (uint64_t)(uint32_t)clampj(j) * (uint64_t)vstep;
+            const uint64_t va = vbase + (uint64_t)(uint32_t)vrow * (uint64_t)vstep;
             asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra0) : "v"(a_off), "s"(va));
             if (NRB > 1) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(ra1) : "v"(a_off), "s"(va));
             if (NRB > 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(ra2) : "v"(a_off), "s"(va));
@@ -118,8 +158,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
             constexpr int I = decltype(I_)::value;
             col_landed();
             const int cj = col_nxt;
+            const int vj = TAPS ? (int)cv_nxt.y : clampj(I);
             fetch_col(I + 1);
-            fetch(xb[I], xa[I][0], xa[I][1], xa[I][2], I, cj);
+            fetch(xb[I], xa[I][0], xa[I][1], xa[I][2], vj, cj);
         });
         f32x32 zero;
 #pragma unroll
@@ -154,19 +195,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
             constexpr int S = decltype(slot)::value;
             col_landed();
             const int col_far = col_nxt;                                        // index of stored column j + PF
+            const int vrow_far = TAPS ? (int)cv_nxt.y : clampj(j + PF);
             fetch_col(j + PF + 1);
             landed(xb[S], xa[S][0], xa[S][1], xa[S][2]);
             __builtin_amdgcn_sched_barrier(0);
             product(std::integral_constant<int, S * NRB>(), xa[S][0], xb[S], acc[NRB - 1]);
             if constexpr (NRB > 1) product(std::integral_constant<int, S * NRB + 1>(), xa[S][1], xb[S], acc[0]);
             if constexpr (NRB > 2) product(std::integral_constant<int, S * NRB + 2>(), xa[S][2], xb[S], acc[1]);
-            fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], j + PF, col_far);
+            fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], vrow_far, col_far);
         };
         int j = 0;
         for (; j + PF <= ncol; j += PF) mfma_static_for<0, PF>([&](auto S_) { step(S_, j + decltype(S_)::value); });
         add_into(acc[NRB - 1], d1);                                             // the block still pending (PF * NRB is even: the last one written is d1; zeros if the loop never ran)
         // everything in flight lands (the ring holds the last ncol % PF stored columns and, behind them, harmless re-loads of the last column)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt), "+s"(cv_nxt));
 #pragma unroll
         for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q][0]), "+v"(xa[q][1]), "+v"(xa[q][2]));
         // the last ncol % PF stored columns, one result block (the compiler spaces each matrix instruction and its adds)
@@ -187,18 +229,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
     // (a lane stores the columns c0 + (lane & 31) + 32 * blk -- not the column it loaded its B operand for)
     const int half = lane >> 5;
     const int64_t colo = c0 + (lane & 31);
+    float xl[2] = {0.0f, 0.0f};                                                  // TAPS: the homogeneous coordinate of this lane's two columns (bias last)
+    if constexpr (TAPS) {
+        if (tp.lastcol) {
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++)
+                if (colo + 32 * blk < n_vecs) xl[blk] = X[tp.last_in_row * ldx + colo + 32 * blk];
+        }
+    }
 #pragma unroll
     for (int b = 0; b < NRB; b++) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int mi = r0 + 32 * b + 8 * (r / 4) + 4 * half + (r % 4);
             if (mi < nmem) {
-                const int64_t row = grp_rows[rbeg + mi];
+                const int64_t row = TAPS ? ((int64_t)mi * tp.HoWo + g) : (int64_t)grp_rows[rbeg + mi];
+                float lc = 0.0f;
+                if constexpr (TAPS) lc = tp.lastcol ? tp.lastcol[row] : 0.0f;
 #pragma unroll
                 for (int blk = 0; blk < 2; blk++) {
                     const int64_t cc = colo + 32 * blk;
                     if (cc < n_vecs) {
                         float v = acc[b][(16 * blk + r) / 2][(16 * blk + r) % 2];
+                        if (TAPS && lc != 0.0f) {                                // the bias entry, where the reference stores one: separate multiply and add
+                            const float bp = xl[blk] * lc;
+                            v = v + bp;
+                        }
                         if (relu) v = mfma_relu_f(v);
                         __builtin_nontemporal_store(v, Y + row * ldy + cc);
                     }
@@ -206,6 +262,37 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
             }
         }
     }
+}
+
+// The order-preserving product of a factored conv operator through the kernel above (convtaps_spmm, KN_FLAG_EXACT, operators that carry the table).
+static int exact_table_launch(const MfTaps& tp, int64_t n_pix, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    const int nrb = tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1);
+    MfTaps t = tp;
+    t.n_cc = tp.Cout / (32 * nrb);
+    const int64_t n_work = n_pix * t.n_cc;
+    const int64_t items = ((n_vecs + 255) / 256) * n_work;
+    const int64_t grid = ((items + 7) / 8) * 8;
+    const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(nrb) + ",taps> (factored operator: products on the matrix pipe from the tap table)";
+    if (nrb == 3) KN_LAUNCH(d, (csr_group_mfma_kernel<3, 8, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else if (nrb == 2) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+int convtaps_exact_table_spmm(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    MfTaps t;
+    t.ex_ptr = A.ex_ptr;
+    t.ex_tab = A.ex_tab;
+    t.tapsT = A.tapsT;
+    t.lastcol = A.has_last ? A.lastcol : nullptr;
+    t.pix_order = A.pix_order;
+    t.last_in_row = A.Cin * A.Hin * A.Win;
+    t.cout_pad = (int32_t)A.cout_pad;
+    t.HoWo = (int32_t)(A.Hout * A.Wout);
+    t.Cout = (int32_t)A.Cout;
+    t.n_cc = 1;
+    return exact_table_launch(t, A.Hout * A.Wout, x, ldx, n_vecs, y, ldy, relu, s);
 }
 
 // work lists per NRB (CsrDev::mf_*): chunks of 32 * NRB member rows of the pattern groups with >= MF_MIN_MEMBERS members

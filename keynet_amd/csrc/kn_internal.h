@@ -198,6 +198,9 @@ struct ConvTapsDev {
     // untiled CSR; convtaps_zero_guard_kernel re-walks the affected output rows for batch columns with a non-finite activation there
     int32_t* zero_ent = nullptr;        // [n_zero][3]
     int64_t n_zero = 0;
+    // ... and the stored-column table of the expansion (kn_csr_mfma.hip, TAPS): pixel o's columns ex_ptr[o] .. ex_ptr[o + 1], each (activation row, value row of tapsT)
+    int32_t* ex_ptr = nullptr;          // [HoWo + 1]
+    int32_t* ex_tab = nullptr;          // [ex_ptr[HoWo]][2]
     // bf16x3 path (kn_conv.hip, convtaps_bf16x3_kernel): the taps as three bf16 planes, built at the first kn_spmm that asks for them
     uint16_t* tapsB = nullptr;
     int64_t tapsB_plane = 0;
@@ -257,6 +260,8 @@ static constexpr int MF_MIN_MEMBERS = 24;   // a pattern group takes the matrix-
 int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy,
                   uint32_t flags, hipStream_t s, float* absmax = nullptr, bool* absmax_fused = nullptr);
 int absmax_pass(const float* y, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax, hipStream_t s);
+struct MfTaps;
+int convtaps_exact_table_spmm(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
 
 // Raise *slot (a non-negative f32 kept as its bit pattern: for such values unsigned order == float order) to the wavefront's max of `m`.
 // The slot is READ first and the atomic issued only when it would raise it -- after the first few tiles of a launch almost never.  Both
