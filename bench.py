@@ -415,7 +415,7 @@ def committed_traffic(workload, mode):
         return (None, '%s is a %s-mode pass' % (rel, t.get('mode', 'tolerance')))
     if t.get('csrc_sha256') != kernel_sources_sha():
         return (None, '%s was taken on other kernel sources' % rel)
-    return (t.get('convtaps_hbm_bytes_per_forward'), rel)
+    return (t.get('convtaps_hbm_bytes_per_forward', t.get('dominant_hbm_bytes_per_forward')), rel)
 
 
 def roofline_of(table, workload, batch, mode):
@@ -442,15 +442,20 @@ def roofline_of(table, workload, batch, mode):
                     algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
     macs = sum(r['nnz'] for r in dom) * float(batch)
     intensity = 2.0 * macs / sum(r['bytes'] for r in dom)
-    names = {'convexact': 'convtaps_exact_pipe_kernel / convtaps_exact_kernel', 'csr': 'csr_group_kernel / csr_rows_kernel', 'smallk': 'convtaps_smallk_kernel'}[kind]
+    names = ' / '.join(sorted({w.split('<')[0] for r in dom for w in str(r.get('plan', '')).replace(',', ' ').split() if w.split('<')[0].endswith('_kernel')})) or \
+        {'convexact': 'convtaps_exact_pipe_kernel / convtaps_exact_kernel', 'csr': 'csr_group_kernel / csr_rows_kernel', 'smallk': 'convtaps_smallk_kernel'}[kind]
     if kind == 'smallk' or intensity < 2.0 * PEAK_VALU_NOFMA_TMACS * 1e3 / PEAK_HBM_GBS:      # below the balance point of the no-FMA VALU roof: HBM-bound
         ach = sum(r['bytes'] for r in dom) / dom_ms / 1e6
         return dict(bound='hbm', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
                     traffic=None, algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms)
     ach = macs / dom_ms / 1e9
+    (traffic, tsrc) = committed_traffic(workload, mode)
     return dict(bound='valu-nofma', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_VALU_NOFMA_TMACS, unit='T MAC/s',
-                frac=ach / PEAK_VALU_NOFMA_TMACS, traffic=None, algorithmic_macs=macs, algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
-                note='bit-exact contract: separate f32 multiply and add in the reference\'s order, so neither FMA nor MFMA may be used; roof = 157.3 TFLOP/s / 4')
+                frac=ach / PEAK_VALU_NOFMA_TMACS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc, algorithmic_macs=macs,
+                algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
+                note='bit-exact contract: a separately rounded f32 product and an f32 add per stored value, in the reference\'s order -- no fused multiply-add, no '
+                     'accumulating matrix instruction; roof = one product + one add per lane per 2 cycles = 157.3 TFLOP/s / 4 (kernels that take their products '
+                     'from K = 1 matrix instructions with a zero accumulator still pay the adds on the same lanes: DESIGN.md section 8)')
 
 
 def exact_parity(knet, x_cipher, n_img=8, n_pix=4):

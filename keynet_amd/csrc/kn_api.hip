@@ -565,14 +565,70 @@ int kn_convtaps_drop_zero_entries(kn_handle_t h) {
                         *out++ = (int32_t)(h->h_ent_tap[e] * c.cin_pad + ci);
                     }
             }
-            int32_t *dp = nullptr, *dt = nullptr;
+            // Processing order of the pixels for the table kernel.  Its workgroups (one output pixel x 32 * NRB channels x 256 batch columns) sweep the
+            // input channels in the same order but start as earlier ones retire, so the ~128 resident on an XCD sit at staggered phases of the sweep:
+            // an activation row is found in that XCD's L2 again only when the workgroup sharing it was dispatched a few places earlier (measured:
+            // row-major / ball orders keep the horizontal reuse only, ~1/3 of the gathers miss).  Strips of `w` pixels swept row by row put the vertical
+            // neighbour w places back: (w + 2) / w fetches per activation byte.  The candidates are scored on the operator's own structure (no
+            // knowledge of the key): visits of an input pixel not seen within the last `window` output pixels count as fetches.  Measured on the AllConvNet
+            // forward (FETCH_SIZE x 2 of the seven launches): ball order 15.7 GB, this choice 12.6 GB (conv2 takes w = 8, conv5 w = 2, each the best of
+            // {2, 4, 8} when forced); the times do not move (the kernel is bound by vector-ALU issue).
+            std::vector<int32_t> ex_order((size_t)HoWo);
+            {
+                auto fetches = [&](const std::vector<int32_t>& ord, int64_t window) {
+                    std::vector<int64_t> seen((size_t)HiWi, -((int64_t)1 << 40));
+                    int64_t n = 0;
+                    for (int64_t k = 0; k < HoWo; k++) {
+                        const int64_t o = ord[(size_t)k];
+                        for (int64_t sl = pp[(size_t)o]; sl < pp[(size_t)o + 1]; sl++) {
+                            const int64_t in = h->h_ent_in[order[(size_t)sl]];
+                            if (k - seen[(size_t)in] > window) n++;
+                            seen[(size_t)in] = k;
+                        }
+                    }
+                    return n;
+                };
+                auto strips = [&](int64_t w) {
+                    std::vector<int32_t> ord;
+                    ord.reserve((size_t)HoWo);
+                    for (int64_t x0 = 0; x0 < c.Wout; x0 += w)
+                        for (int64_t y = 0; y < c.Hout; y++)
+                            for (int64_t x = x0; x < std::min(x0 + w, c.Wout); x++) ord.push_back((int32_t)(y * c.Wout + x));
+                    return ord;
+                };
+                const int nrb = c.Cout % 96 == 0 ? 3 : (c.Cout % 64 == 0 ? 2 : 1);
+                const int64_t n_cc = c.Cout / (32 * nrb);
+                // places a sharer may lie back: the rows gathered meanwhile by the resident workgroups (~1.5 KB per place and input channel at 256 columns) within half an L2 slice
+                static const int64_t env_window = getenv("KN_TABLE_WINDOW") ? atoll(getenv("KN_TABLE_WINDOW")) : 0;
+                static const int64_t env_strip = getenv("KN_TABLE_STRIP") ? atoll(getenv("KN_TABLE_STRIP")) : -1;      // A/B knobs (read once)
+                const int64_t window = env_window > 0 ? env_window : std::max<int64_t>(2, std::min<int64_t>(64, (2048 * 2) / (3 * c.Cin * n_cc)));
+                std::vector<int32_t> best((size_t)HoWo);
+                KN_HIP(hipMemcpy(best.data(), c.pix_order, (size_t)HoWo * sizeof(int32_t), hipMemcpyDeviceToHost));
+                int64_t best_n = fetches(best, window);
+                if (env_strip > 0) {
+                    best = strips(env_strip);
+                } else if (env_strip < 0) {
+                    for (int64_t w = 2; w <= c.Wout; w *= 2) {
+                        std::vector<int32_t> cand = strips(w);
+                        const int64_t n = fetches(cand, window);
+                        if (n < best_n) {
+                            best_n = n;
+                            best.swap(cand);
+                        }
+                    }
+                }
+                ex_order = best;
+            }
+            int32_t *dp = nullptr, *dt = nullptr, *dord = nullptr;
             if ((rc = upload(&dp, ex_ptr.data(), ex_ptr.size()))) return rc;
-            if ((rc = upload(&dt, ex_tab.data(), ex_tab.size()))) {
+            if ((rc = upload(&dt, ex_tab.data(), ex_tab.size())) || (rc = upload(&dord, ex_order.data(), ex_order.size()))) {
                 (void)hipFree(dp);
+                if (dt) (void)hipFree(dt);
                 return rc;
             }
             h->ct.ex_ptr = dp;
             h->ct.ex_tab = dt;
+            h->ct.ex_order = dord;
         }
     }
     return KN_OK;

@@ -1714,7 +1714,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent, c.ex_ptr, c.ex_tab};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent, c.ex_ptr, c.ex_tab, c.ex_order};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();

@@ -54,6 +54,9 @@ struct MfTaps {
     int32_t cout_pad, HoWo, Cout, n_cc;   // n_cc = channel chunks (32 * NRB channels) per pixel
 };
 
+// (TAPS, measured and dropped: the four wavefronts of a workgroup on four pixels of a 2 x 2 block x the same 64 batch columns, so that the block's 16 input
+// pixels would be shared through the CU's vector cache -- HBM fetch of the AllConvNet forward 12.6 -> 19.5 GB and 2 % slower: the 256-byte row segments
+// cut the reuse between workgroups in L2 by more than the vector cache gives back.)
 template <int NRB, int PF, int NW = 4, bool TAPS = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
                                             // re-reads but measured 8.5 % slower on the AllConvNet forward: 35.9 against 33.0 ms; not instantiated)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
@@ -286,7 +289,7 @@ int convtaps_exact_table_spmm(const ConvTapsDev& A, const float* x, int64_t ldx,
     t.ex_tab = A.ex_tab;
     t.tapsT = A.tapsT;
     t.lastcol = A.has_last ? A.lastcol : nullptr;
-    t.pix_order = A.pix_order;
+    t.pix_order = A.ex_order ? A.ex_order : A.pix_order;
     t.last_in_row = A.Cin * A.Hin * A.Win;
     t.cout_pad = (int32_t)A.cout_pad;
     t.HoWo = (int32_t)(A.Hout * A.Wout);

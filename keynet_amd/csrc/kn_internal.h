@@ -201,6 +201,7 @@ struct ConvTapsDev {
     // ... and the stored-column table of the expansion (kn_csr_mfma.hip, TAPS): pixel o's columns ex_ptr[o] .. ex_ptr[o + 1], each (activation row, value row of tapsT)
     int32_t* ex_ptr = nullptr;          // [HoWo + 1]
     int32_t* ex_tab = nullptr;          // [ex_ptr[HoWo]][2]
+    int32_t* ex_order = nullptr;        // [HoWo] processing order of the pixels for the table kernel (strips, kn_convtaps_drop_zero_entries)
     // bf16x3 path (kn_conv.hip, convtaps_bf16x3_kernel): the taps as three bf16 planes, built at the first kn_spmm that asks for them
     uint16_t* tapsB = nullptr;
     int64_t tapsB_plane = 0;

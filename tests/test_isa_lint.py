@@ -56,7 +56,7 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
         assert names, 'no kernel matches %s in %s' % (pat, src)
         for name in names:
             body = s[s.index(name + ':'):]
-            body = body[:body.index('s_endpgm')]
+            body = body[:body.index('.Lfunc_end')]                # (not the first s_endpgm: an early wave-uniform return may be laid out ahead of the loops)
             lines = [l.split(';')[0].strip() for l in body.split('\n') if l.strip()]
             # In program order: the destinations of the asm-issued loads of a loop body are "owned" from the body's first such load until its
             # epilogue begins (= the first global store behind it: the loops themselves store nothing, and every operand has landed and been
