@@ -89,3 +89,22 @@ def test_factored_device_form_is_bit_equal_to_the_stored_csr(small_threshold, n_
         if poison:
             # the zero weight (co = 3, ci = 2, centre tap): output pixel 45 of channel 3 must NOT see the Inf at input pixel 45 of channel 2 through it
             assert np.isinf(Xp[245, 1]) and not np.isnan(ref[3 * 100 + 45, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cin,cout,hw,stride,n_vecs', [(4, 64, 9, 1, 192), (8, 96, 12, 2, 300), (5, 32, 7, 1, 128), (3, 192, 6, 1, 256)])
+def test_factored_table_kernel_odd_shapes(small_threshold, cin, cout, hw, stride, n_vecs):
+    """Image sides that are not powers of two (ragged last strip of the pixel order), a strided conv, 1 / 2 / 3 row blocks per workgroup, ragged batches:
+    the tap-table kernel against the oracle on the stored CSR, bit for bit."""
+    dev = torch.device('cuda:0')
+    layer = conv_layer(cin, cout, hw, stride=stride, zeros=[(1, 0, 0, 1)], seed=hw)
+    W = layer.W
+    assert isinstance(W, ksp.FactoredSparseMatrix)
+    (ip, ix, dt) = ksp._stored_order_csr(W._matrix)
+    rng = np.random.RandomState(hw)
+    X = np.vstack((rng.randn(cin * hw * hw, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+    with torch.cuda.device(dev):
+        assert 'taps> (factored operator' in W._device_op(dev).plan(n_vecs, 2)
+    ref = oracle.csr_matvecs(W.shape, ip, ix, dt, X)
+    y = W.torchdot(torch.as_tensor(X).to(dev), relu=False).cpu().numpy()
+    assert np.array_equal(y, ref)
