@@ -442,7 +442,12 @@ def roofline_of(table, workload, batch, mode):
                     algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
     macs = sum(r['nnz'] for r in dom) * float(batch)
     intensity = 2.0 * macs / sum(r['bytes'] for r in dom)
-    names = ' / '.join(sorted({w.split('<')[0] for r in dom for w in str(r.get('plan', '')).replace(',', ' ').split() if w.split('<')[0].endswith('_kernel')})) or \
+    mains = []                                            # the first kernel of each layer's plan (kn_spmm_plan lists the main launch first, guards / last-row helpers behind it)
+    for r in dom:
+        k = [w.split('<')[0] for w in str(r.get('plan', '')).replace(',', ' ').split() if w.split('<')[0].endswith('_kernel')]
+        if k and k[0] not in mains:
+            mains.append(k[0])
+    names = ' / '.join(mains) or \
         {'convexact': 'convtaps_exact_pipe_kernel / convtaps_exact_kernel', 'csr': 'csr_group_kernel / csr_rows_kernel', 'smallk': 'convtaps_smallk_kernel'}[kind]
     if kind == 'smallk' or intensity < 2.0 * PEAK_VALU_NOFMA_TMACS * 1e3 / PEAK_HBM_GBS:      # below the balance point of the no-FMA VALU roof: HBM-bound
         ach = sum(r['bytes'] for r in dom) / dom_ms / 1e6

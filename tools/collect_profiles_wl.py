@@ -17,6 +17,8 @@ for spec in sys.argv[2:]:
     pre = 'profiles/%s_%s_' % (tag, name)
     shutil.copy(d + '/bench.json', pre + 'bench.json')
     shutil.copy(d + '/per_layer_trace.csv', pre + 'per_layer_trace.csv')
+    if os.path.exists(d + '/bench_detail.json'):
+        shutil.copy(d + '/bench_detail.json', pre + 'bench_detail.json')
     open(pre + 'layers.log', 'w').write(''.join(l for l in open(d + '/bench.log') if 'bench' in l))
     # PMC table: keep kn:: compute kernels, at most the first 3 occurrences of each (kernel, grid) -- the passes repeat every layer several times
     rows = list(csv.reader(open(d + '/pmc.csv')))

@@ -51,6 +51,8 @@ def main(R, tag, out='profiles', forwards=None):
             n = r['Name']
             w.writerow([n if len(n) < 150 else n[:147] + '...', r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']])
     shutil.copy(R + '/bench.json', pre + 'bench.json')
+    if os.path.exists(R + '/bench_detail.json'):
+        shutil.copy(R + '/bench_detail.json', pre + 'bench_detail.json')
     shutil.copy(R + '/stats_bench.json', pre + 'bench_under_rocprof.json')
     open(pre + 'layers.log', 'w').write(''.join(l for l in open(R + '/bench.log') if 'bench' in l))
     (fe, wr) = (per_kernel(R + '/pmc_fetch', 'FETCH_SIZE'), per_kernel(R + '/pmc_write', 'WRITE_SIZE'))

@@ -9,7 +9,7 @@ REPO=$(pwd)
 mkdir -p "$REPO/$R"
 R="$REPO/$R"
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 5 > "$R/bench.json" 2> "$R/bench.log"
+python3 bench.py --steps 20 --warmup 5 --detail "$R/bench_detail.json" > "$R/bench.json" 2> "$R/bench.log"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$R/stats_bench.json" 2> "$R/stats_bench.log"
 rocprofv3 --kernel-trace --output-format csv -d "$R/trace" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-secondary --trace-layers "$R/layers.json" > /dev/null 2> "$R/trace.log"

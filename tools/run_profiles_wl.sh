@@ -11,7 +11,7 @@ REPO=$(pwd)
 mkdir -p "$REPO/$R"
 R="$REPO/$R"
 export TMPDIR=/tmp
-python3 bench.py --workload $WL --steps 20 --warmup 5 --no-secondary $EXTRA > "$R/bench.json" 2> "$R/bench.log"
+python3 bench.py --workload $WL --steps 20 --warmup 5 --no-secondary --detail "$R/bench_detail.json" $EXTRA > "$R/bench.json" 2> "$R/bench.log"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-exact-leg $EXTRA > "$R/stats_bench.json" 2> "$R/stats_bench.log"
 rocprofv3 --kernel-trace --output-format csv -d "$R/trace" -- python3 "$REPO/bench.py" --workload $WL --no-cpu-baseline --no-secondary --trace-layers "$R/layers.json" $EXTRA > /dev/null 2> "$R/trace.log"
