@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 void csr_free(CsrDev& c) {
     void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
                     c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows, c.patch_rows, c.patch_ptr, c.patch_cols,
-                    c.mf_grp[0], c.mf_grp[1], c.mf_grp[2], c.mf_r0[0], c.mf_r0[1], c.mf_r0[2], c.ws_grp, c.ws_r0};
+                    c.mf_grp[0], c.mf_grp[1], c.mf_grp[2], c.mf_r0[0], c.mf_r0[1], c.mf_r0[2], c.ws_grp, c.ws_r0, c.mf16_grp, c.mf16_r0};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c = CsrDev();
@@ -599,7 +599,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         }
     }
     std::vector<int32_t> patch_rows, patch_ptr{0}, patch_cols;
-    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose, mfg[3], mfr[3], wsg, wsr;
+    std::vector<int32_t> colptr{0}, cols, rowptr{0}, grows, wgrp, wr0, bgrp, br0, loose, mfg[3], mfr[3], wsg, wsr, m16g, m16r;
     int64_t mf_rows = 0, mf_nnz = 0;
     std::vector<int64_t> valptr{0};
     std::vector<float> vals;
@@ -648,6 +648,10 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             for (int64_t r0 = 0; r0 < n_mem; r0 += BIG_ROWS) {
                 bgrp.push_back(gid);
                 br0.push_back((int32_t)r0);
+            }
+            for (int64_t r0 = 0; r0 < n_mem; r0 += 16) {                       // the same group for the 16-row matrix-pipe kernel (narrow batches)
+                m16g.push_back(gid);
+                m16r.push_back((int32_t)r0);
             }
         } else {
             for (int64_t r0 = 0; r0 < n_mem; r0 += RB) {
@@ -713,6 +717,9 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     }
     A.mf_rows = mf_rows;
     A.mf_nnz = mf_nnz;
+    A.n_mf16 = (int64_t)m16g.size();
+    if ((rc = upload(&A.mf16_grp, m16g.data(), m16g.size()))) return rc;
+    if ((rc = upload(&A.mf16_r0, m16r.data(), m16r.size()))) return rc;
     A.n_ws = (int64_t)wsg.size();
     if ((rc = upload(&A.ws_grp, wsg.data(), wsg.size()))) return rc;
     if ((rc = upload(&A.ws_r0, wsr.data(), wsr.size()))) return rc;
@@ -1054,11 +1061,23 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
                   A.data, x, ldx, y, ldy, n_vecs, relu, n_rb);
         KN_HIP(hipGetLastError());
     }
-    if (A.n_big > 0 || n_long_deep > 0) {
+    // Big pattern groups (a keyed Linear in the reference's order): 16-row chunks with their products on the matrix pipe, one wavefront per chunk and 64 batch
+    // columns, when that gives every SIMD two wavefronts (>= 2048 of them).  Same-process A/B against the LDS-staged kernel below (ms, 4096 x 25088 at 512 /
+    // 1024 / 2048 columns: 3.38 / 5.85 / 11.17 against 2.68 / 4.37 / 8.17; 4096 x 4096 at 512 / 1024: 0.59 / 1.02 against 0.49 / 0.77); with ONE wavefront per
+    // SIMD (VGG-16 fc6 at 256 images: 1 024 chunks) it loses -- 2.16 against 1.74 ms, a lone wavefront pays ~9 cycles per instruction -- and the LDS-staged
+    // kernel stays.  KN_BIG_MFMA16=1 (force) / KN_NO_BIG_MFMA16=1 = A/B switches, read per call.
+    bool big_done = false;
+    if (A.n_big > 0 && A.n_mf16 > 0 && n_vecs >= 64 && (getenv("KN_BIG_MFMA16") || A.n_mf16 * ((n_vecs + 63) / 64) >= 2048) && getenv("KN_NO_BIG_MFMA16") == nullptr) {
+        const int rc = csr_group_mfma16_spmm(A, x, ldx, n_vecs, y, ldy, relu, s);
+        if (rc) return rc;
+        big_done = true;
+    }
+    if ((A.n_big > 0 && !big_done) || n_long_deep > 0) {
         const int64_t n_ct = (n_vecs + 63) / 64;
-        const int64_t grid_big = ((n_ct * A.n_big + 7) / 8) * 8;
+        const int64_t n_big = big_done ? 0 : A.n_big;
+        const int64_t grid_big = ((n_ct * n_big + 7) / 8) * 8;
         const int64_t grid_long = n_long_deep * ((n_ct + 3) / 4);
-        KN_LAUNCH("csr_big_group_kernel", csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, A.n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
+        KN_LAUNCH("csr_big_group_kernel", csr_big_group_kernel, dim3((unsigned)(grid_big + grid_long)), dim3(256), 0, s, n_big, A.big_grp, A.big_r0, A.grp_colptr, A.grp_cols,
                            A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, grid_big, A.long_rows, n_long_deep, A.indptr, A.indices, A.data);
         KN_HIP(hipGetLastError());
     }

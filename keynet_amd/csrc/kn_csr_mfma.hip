@@ -28,6 +28,7 @@
 namespace kn {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 static __device__ __forceinline__ float mfma_relu_f(float v) { return (v < 0.0f) ? 0.0f : v; }  // torch relu: NaN stays NaN
@@ -267,6 +268,140 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
     }
 }
 
+// The 16-row form for BIG pattern groups (a keyed nn.Linear in the reference's order: 4 096 rows x 25 089 stored columns): the walk over a row's stored columns
+// is serial by contract, so parallelism can only come from rows x batch columns.  v_mfma_f32_16x16x1_4b_f32 with a zero accumulator = the rounded products of
+// 16 member rows x 4 blocks of 16 batch columns (lane l supplies ITS OWN column as the B operand and value l % 16 as the A operand; bit-identical to v_mul_f32:
+// tools/micro/mfma16_product.hip), 8 packed adds per stored column.  Taken when it puts two wavefronts on every SIMD (csr_spmm_groups: 21-27 % faster than the
+// LDS-staged big-group kernel there; slower with one).
+// One wavefront = 16 rows x 64 columns; a workgroup = four 64-column blocks of the same 16 rows.  Same operand ring as above (2 loads per stored column).
+template <int PF>
+__global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
+                                                                  const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
+                                                                  const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
+                                                                  const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
+                                                                  const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu) {
+    static_assert(PF % 2 == 0, "two result blocks alternate");
+    const int64_t n_ct = (n_vecs + 255) / 256;
+    const int64_t n_items = n_ct * n_work;
+    const int64_t chunk = (n_items + 7) >> 3;
+    const int64_t item = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (item >= n_items || (blockIdx.x >> 3) >= chunk) return;
+    const int64_t ct = item / n_work;
+    const int64_t w = item - ct * n_work;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(work_grp[w]);
+    const int r0 = __builtin_amdgcn_readfirstlane(work_r0[w]);
+    const int cbeg = __builtin_amdgcn_readfirstlane(grp_colptr[g]);
+    const int ncol = __builtin_amdgcn_readfirstlane(grp_colptr[g + 1]) - cbeg;
+    const int rbeg = __builtin_amdgcn_readfirstlane(grp_rowptr[g]);
+    const int nmem = __builtin_amdgcn_readfirstlane(grp_rowptr[g + 1]) - rbeg;
+    const int rpad = (nmem + 15) / 16 * 16;
+    const int64_t c0 = ct * 256 + (int64_t)wave * 64;
+    if (c0 >= n_vecs) return;                              // (wave-uniform; no barriers in this kernel)
+    const int64_t c = c0 + lane;
+    const bool active = c < n_vecs;
+    f32x2 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = f32x2{0.0f, 0.0f};
+    if (ncol > 0) {
+        auto uni = [](const uint64_t v) {
+            return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        };
+        const uint64_t cbase = uni(reinterpret_cast<uint64_t>(grp_cols + cbeg));
+        const uint64_t xbase = uni(reinterpret_cast<uint64_t>(X));
+        const uint64_t vbase = uni(reinterpret_cast<uint64_t>(grp_vals + grp_valptr[g] + r0));
+        const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);
+        const uint32_t a_off = 4u * (uint32_t)(lane & 15);
+        const uint64_t ldx_b = 4ull * (uint64_t)ldx;
+        const uint64_t vstep = 4ull * (uint64_t)(uint32_t)rpad;
+        auto clampj = [&](const int j) { return j < ncol ? j : ncol - 1; };
+        float xa[PF], xb[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) xa[q] = xb[q] = 0.0f;
+        int col_nxt = 0;
+        auto fetch_col = [&](const int j) {
+            const uint64_t caddr = cbase + 4ull * (uint64_t)(uint32_t)clampj(j);
+            asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(col_nxt) : "s"(caddr));
+        };
+        auto col_landed = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(col_nxt)); };
+        auto fetch = [&](float& rb, float& ra, const int vrow, const int col) {
+            const uint64_t xaddr = xbase + (uint64_t)(uint32_t)col * ldx_b;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(b_off), "s"(xaddr));
+            const uint64_t va = vbase + (uint64_t)(uint32_t)vrow * vstep;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra) : "v"(a_off), "s"(va));
+        };
+        auto landed = [&](float& rb, float& ra) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb), "+v"(ra) : "n"(2 * (PF - 1))); };
+        fetch_col(0);
+        mfma_static_for<0, PF>([&](auto I_) {
+            constexpr int I = decltype(I_)::value;
+            col_landed();
+            const int cj = col_nxt;
+            fetch_col(I + 1);
+            fetch(xb[I], xa[I], clampj(I), cj);
+        });
+        f32x16 zero;
+#pragma unroll
+        for (int q = 0; q < 16; q++) zero[q] = 0.0f;
+        auto add_into = [&](const f32x16& d) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                asm("v_pk_add_f32 %0, %1, %0" : "+v"(acc[q]) : "v"(p2));
+            }
+        };
+        f32x16 d0 = zero, d1 = zero;                        // two result blocks alternate: the adds of one run behind the matrix instruction of the other
+        auto step = [&](auto slot, const int j) {
+            constexpr int S = decltype(slot)::value;
+            col_landed();
+            const int col_far = col_nxt;
+            fetch_col(j + PF + 1);
+            landed(xb[S], xa[S]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((S & 1) == 0) {
+                d0 = __builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(d1);
+            } else {
+                d1 = __builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(d0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(xb[S], xa[S], clampj(j + PF), col_far);
+        };
+        int j = 0;
+        for (; j + PF <= ncol; j += PF) mfma_static_for<0, PF>([&](auto S_) { step(S_, j + decltype(S_)::value); });
+        add_into(d1);                                       // the block still pending (PF is even: the last one written is d1; zeros if the loop never ran)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt));
+#pragma unroll
+        for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q]));
+        mfma_static_for<0, PF - 1>([&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            if (j + S < ncol) add_into(__builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0));
+        });
+    }
+    // D layout: register 4 * blk + r of lane l = element (row 4 * (l / 16) + r, column 16 * blk + l % 16)
+    const int quarter = lane >> 4;
+    const int64_t colo = c0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int mi = r0 + 4 * quarter + r;
+        if (mi < nmem) {
+            const int64_t row = (int64_t)grp_rows[rbeg + mi];
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                const int64_t cc = colo + 16 * blk;
+                if (cc < n_vecs) {
+                    float v = acc[(4 * blk + r) / 2][(4 * blk + r) % 2];
+                    if (relu) v = mfma_relu_f(v);
+                    Y[row * ldy + cc] = v;
+                }
+            }
+        }
+    }
+}
+
 // The order-preserving product of a factored conv operator through the kernel above (convtaps_spmm, KN_FLAG_EXACT, operators that carry the table).
 static int exact_table_launch(const MfTaps& tp, int64_t n_pix, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
     const int nrb = tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1);
@@ -320,6 +455,16 @@ int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_
                                         A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
         }
     }
+    KN_HIP(hipGetLastError());
+    return KN_OK;
+}
+
+// big pattern groups (CsrDev::mf16_*: chunks of 16 member rows)
+int csr_group_mfma16_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    const int64_t items = ((n_vecs + 255) / 256) * A.n_mf16;
+    const int64_t grid = ((items + 7) / 8) * 8;
+    KN_LAUNCH("csr_group_mfma16_kernel (big pattern groups: products of 16 rows x 64 columns on the matrix pipe, K = 1, zero accumulator)", (csr_group_mfma16_kernel<8>),
+              dim3((unsigned)grid), dim3(256), 0, s, A.n_mf16, A.mf16_grp, A.mf16_r0, A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
     KN_HIP(hipGetLastError());
     return KN_OK;
 }

@@ -164,6 +164,9 @@ struct CsrDev {
     int64_t n_mf[3] = {0, 0, 0};
     int64_t mf_rows = 0;             // member rows covered by the mf_* lists
     int64_t mf_nnz = 0;              // their stored entries (mf_nnz / mf_rows = mean stored columns per row: the dispatch rule of csr_spmm_groups)
+    int32_t* mf16_grp = nullptr;     // big pattern groups (a keyed Linear) in chunks of 16 member rows: csr_group_mfma16_kernel on narrow batches
+    int32_t* mf16_r0 = nullptr;
+    int64_t n_mf16 = 0;
     int32_t* ws_grp = nullptr;
     int32_t* ws_r0 = nullptr;
     int64_t n_ws = 0;
@@ -255,6 +258,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* absmax = nullptr,
              bool* absmax_fused = nullptr);
 int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
+int csr_group_mfma16_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
 static constexpr int MF_MIN_MEMBERS = 24;   // a pattern group takes the matrix-pipe kernel when its members fill >= 3/4 of a 32-row block
 // `absmax` (device float or null): when the launch takes a kernel whose epilogue can fold max |Y| into its stores, the slot is raised atomically
 // and *absmax_fused is set; otherwise the caller runs absmax_pass over Y afterwards (kn_spmm_screen)

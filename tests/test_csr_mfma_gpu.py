@@ -159,3 +159,42 @@ def test_default_dispatch_rule():
         with torch.cuda.device(dev()):
             op.spmm(xd.data_ptr(), 256, 256, y.data_ptr(), 256, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
         assert np.array_equal(y.cpu().numpy(), oracle.csr_matvecs((m, 2000), indptr, indices, data, X))
+
+
+@pytest.mark.parametrize('rows,cols,n_vecs,forced', [(300, 2500, 256, True), (257, 2048, 64, True), (520, 2100, 100, True), (1030, 2050, 2048, False)])
+def test_big_group_16_row_matrix_pipe_kernel_vs_oracle(rows, cols, n_vecs, forced, monkeypatch):
+    """A keyed nn.Linear in the reference's order (ONE pattern group: >= 256 member rows x >= 2048 stored columns, here in a scrambled stored order with
+    duplicate columns): csr_group_mfma16_kernel (v_mfma_f32_16x16x1_4b_f32 with a zero accumulator + packed adds) against the oracle and against the
+    LDS-staged big-group kernel (KN_NO_BIG_MFMA16=1), bit for bit; partly filled last 16-row chunk, ragged batches, loose rows beside the group, ReLU on
+    and off.  By default it is taken when its 16-row x 64-column wavefronts number >= 2048 (last case); the small cases force it."""
+    if forced:
+        monkeypatch.setenv('KN_BIG_MFMA16', '1')
+    rng = np.random.RandomState(rows + n_vecs)
+    pattern = rng.permutation(cols + 7)[:cols].astype(np.int32)
+    pattern[5] = pattern[900]                                              # a duplicate column: two stored entries, added in stored order
+    lists = [pattern] * rows + [rng.randint(0, cols + 7, 9).astype(np.int32) for _ in range(5)] + [np.zeros(0, np.int32)]
+    indptr = np.concatenate(([0], np.cumsum([len(r) for r in lists]))).astype(np.int32)
+    indices = np.concatenate(lists).astype(np.int32)
+    data = rng.randn(len(indices)).astype(np.float32)
+    (m, n) = (len(lists), cols + 7)
+    X = rng.randn(n, n_vecs).astype(np.float32)
+    W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_group_mfma16_kernel' in plan and 'csr_big_group_kernel' not in plan, plan
+    ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+    xd = torch.as_tensor(X).to(dev())
+    for relu in (False, True):
+        r = np.maximum(ref, 0) if relu else ref
+        y = W.torchdot(xd, relu=relu).cpu().numpy()
+        assert np.array_equal(y, r), (rows, cols, n_vecs, relu, int(np.sum(y != r)))
+    monkeypatch.delenv('KN_BIG_MFMA16', raising=False)
+    monkeypatch.setenv('KN_NO_BIG_MFMA16', '1')
+    with torch.cuda.device(dev()):
+        plan0 = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_group_mfma16_kernel' not in plan0 and 'csr_big_group_kernel' in plan0, plan0
+    assert np.array_equal(W.torchdot(xd, relu=False).cpu().numpy(), ref)
+    # few wavefronts (one per SIMD or less): the LDS-staged kernel by default
+    monkeypatch.delenv('KN_NO_BIG_MFMA16')
+    with torch.cuda.device(dev()):
+        assert 'csr_group_mfma16_kernel' not in W._device_op(dev()).plan(128, _capi.KN_FLAG_EXACT)

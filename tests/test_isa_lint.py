@@ -20,7 +20,7 @@ CSRC = os.path.join(ROOT, 'keynet_amd', 'csrc')
 PIPELINED = {
     'kn_conv.hip': [r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn20convtaps_mfma_kernelILi\d+ELi\d+ELi16ELi\dELi\dELi2E'],
     'kn_csr.hip': [r'_ZN2kn21csr_group_pipe_kernel'],
-    'kn_csr_mfma.hip': [r'_ZN2kn21csr_group_mfma_kernel'],
+    'kn_csr_mfma.hip': [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel'],
 }
 
 # what an asm-issued load looks like per file (the compiler's own saddr-form dword loads in the other files are tracked by its waitcnt pass)
