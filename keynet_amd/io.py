@@ -3,7 +3,7 @@
 
 Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_golden.py from the reference's objects):
     layer_names                      nn.Sequential order
-    L.<name>.kind                    'relu' | 'csr' | 'tiled' | 'diagtiled' | 'conv2dtiled' | 'convtaps'
+    L.<name>.kind                    'relu' | 'csr' (+ optional fact_* arrays: the factored device form of an untiled conv) | 'tiled' | 'diagtiled' | 'conv2dtiled' | 'convtaps'
     L.<name>.layertype               str(type(module)) of the source layer ('ReLU' in it => keyed ReLU)
     csr:          shape, indptr, indices, data           (STORED order)
     tiled:        shape, tileshape, blocks, tile_shapes, tile_ptr, tile_row, tile_col, tile_val
@@ -45,6 +45,14 @@ def operator_from_arrays(z, p):
     if kind == 'csr':
         data = z[p + 'data']
         M = scipy.sparse.csr_matrix((data.astype(np.float32) if data.dtype != np.float32 else data, z[p + 'indices'], z[p + 'indptr']), shape=shape)
+        if (p + 'fact_taps') in z.files:
+            # saved from a FactoredSparseMatrix: the factored device form travels with the CSR and is PROVEN again against it on load (a file edited in
+            # between simply loads as the plain CSR container)
+            g = (lambda k: z[p + 'fact_' + k] if (p + 'fact_' + k) in z.files and z[p + 'fact_' + k].size > 0 else None)
+            F = ksp.Conv2dTiledMatrix.fromtaps(tuple(int(v) for v in z[p + 'fact_inshape']), tuple(int(v) for v in z[p + 'fact_outshape']), z[p + 'fact_taps'],
+                                               z[p + 'fact_ent_out'], z[p + 'fact_ent_in'], z[p + 'fact_ent_tap'], g('ent_coef'), g('lastcol'))
+            if ksp.FactoredSparseMatrix.proven(M, F):
+                return ksp.FactoredSparseMatrix(M, F)
         return ksp.SparseMatrix(M)
     if kind in ('tiled', 'diagtiled'):
         W = ksp.TiledMatrix.__new__(ksp.TiledMatrix)
@@ -101,6 +109,11 @@ def operator_to_arrays(W, p, out):
         (ip, ix, dt) = ksp._stored_order_csr(W._matrix if ksp.is_scipy_sparse(W._matrix) else scipy.sparse.csr_matrix(W._matrix))
         for (k, v) in (('shape', np.array(W.shape, dtype=np.int64)), ('indptr', ip), ('indices', ix), ('data', dt)):
             out[p + k] = v
+        if isinstance(W, ksp.FactoredSparseMatrix):                  # + the factored device form (a few MB next to the CSR's hundreds)
+            F = W._factored
+            (out[p + 'fact_inshape'], out[p + 'fact_outshape']) = (np.array(F._inshape, dtype=np.int64), np.array(F._outshape, dtype=np.int64))
+            for (k, v) in F._taps.items():
+                out[p + 'fact_' + k] = v if v is not None else np.zeros(0, np.float32)
 
 
 def _contract_from_array(a, what):

@@ -215,8 +215,9 @@ class FactoredSparseMatrix(SparseMatrix):
     ascending-column expansion of a factored conv operator (taps x spatial entries, keynet_amd/direct.py) with the exact zeros dropped.  That is
     what the keying SpGEMMs leave for identity / channel-replicated permutation keys on both sides -- every conv layer of PermutationKeynet
     AllConvNet but the first.  scipy's product in stored order is then, entry for entry, the factored operator's order-preserving product
-    (KN_FLAG_EXACT: channel outer, the pixel's slots by ascending input pixel inner, bias last), so the device holds 0.3 MB of taps + the slot lists
-    instead of the CSR's hundreds of MB and runs the conv pipeline; kn_convtaps_drop_zero_entries covers the dropped zeros.  Everything on the
+    (KN_FLAG_EXACT: channel outer, the pixel's slots by ascending input pixel inner, bias last), so the device holds 0.3 MB of taps + the slot lists + a
+    stored-column table instead of the CSR's hundreds of MB and runs the matrix-pipe grouped kernel from that table (narrow batches: the conv pipeline);
+    kn_convtaps_drop_zero_entries covers the dropped zeros.  Everything on the
     host (`_matrix`, nnz(), tocoo(), pickling, the neutral file format) is the plain CSR container's."""
 
     def __init__(self, A, factored):

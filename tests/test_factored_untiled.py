@@ -108,3 +108,30 @@ def test_factored_table_kernel_odd_shapes(small_threshold, cin, cout, hw, stride
     ref = oracle.csr_matvecs(W.shape, ip, ix, dt, X)
     y = W.torchdot(torch.as_tensor(X).to(dev), relu=False).cpu().numpy()
     assert np.array_equal(y, ref)
+
+
+def test_factored_form_travels_with_saved_keynets(small_threshold, tmp_path):
+    """save_keynet writes the factored device form next to the CSR (fact_* arrays); load_keynet PROVES it against the stored CSR again and only then hands
+    it to the device -- a file whose CSR was edited loads as the plain container."""
+    from keynet_amd import io as kio
+    from keynet_amd import system as ksys
+    layer = conv_layer(4, 32, 8, zeros=[(1, 2, 0, 0)])
+    assert isinstance(layer.W, ksp.FactoredSparseMatrix)
+    knet = ksys.KeyedModel.fromlayers({'conv': layer}, (32, 8, 8))
+    f = str(tmp_path / 'k.npz')
+    kio.save_keynet(knet, f)
+    k2 = kio.load_keynet(f)
+    W2 = k2.conv.W
+    assert isinstance(W2, ksp.FactoredSparseMatrix) and W2.nnz() == layer.W.nnz()
+    (a, b) = (ksp._stored_order_csr(layer.W._matrix), ksp._stored_order_csr(W2._matrix))
+    assert all(np.array_equal(x, y) for (x, y) in zip(a, b))
+    for k in ('taps', 'ent_out', 'ent_in', 'ent_tap', 'lastcol'):
+        assert np.array_equal(layer.W._factored._taps[k], W2._factored._taps[k]), k
+    # tamper with one stored value: the proof fails, the operator is the reference's plain CSR container
+    z = dict(np.load(f, allow_pickle=False))
+    key = [k for k in z if k.endswith('conv.data')][0]
+    z[key] = z[key].copy()
+    z[key][3] += 1.0
+    f2 = str(tmp_path / 'k2.npz')
+    np.savez(f2, **z)
+    assert type(kio.load_keynet(f2).conv.W) is ksp.SparseMatrix
