@@ -51,7 +51,7 @@ for spec in sys.argv[2:]:
                    'dominant_hbm_bytes_per_forward': sum((float(r[ifx]) + float(r[iw])) * 1e9 for r in use),
                    'fetch_bytes_x2': sum(float(r[ifx]) * 1e9 for r in use), 'write_bytes': sum(float(r[iw]) * 1e9 for r in use),
                    'source': 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profiles_wl.sh), rows of %spmc.csv' % pre}, open(pre + 'traffic.json', 'w'), indent=1)
-    st = glob.glob(d + '/stats/**/*kernel_stats.csv', recursive=True)
+    st = sorted(glob.glob(d + '/stats/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime, reverse=True)      # newest first: gpurun merges runs into one directory
     if st:
         with open(pre + 'kernel_stats.csv', 'w') as f:
             w = csv.writer(f)

@@ -18,6 +18,11 @@ csv.field_size_limit(1 << 30)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    """The most recent match: gpurun merges a run's output INTO gpurun_out/, so a directory used twice holds files of both runs (other pids in the names)."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def kernel_sources_sha():
     """sha256 over keynet_amd/csrc/*.{hip,h} (same function as bench.py): ties a PMC pass to the kernel sources it was taken on."""
     h = hashlib.sha256()
@@ -29,7 +34,7 @@ def kernel_sources_sha():
 
 
 def per_kernel(d, counter):
-    f = glob.glob(d + '/runc/*counter_collection.csv')[0]
+    f = newest(d + '/runc/*counter_collection.csv')
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == counter:
@@ -43,7 +48,7 @@ def main(R, tag, out='profiles', forwards=None):
     for name in ('bench.json', 'bench_under_rocprof.json', 'kernel_stats.csv', 'layers.log', 'per_layer_pmc.csv', 'per_layer_trace.csv', 'traffic.json'):     # only what this script writes
         if os.path.exists(pre + name):
             os.remove(pre + name)
-    rows = list(csv.DictReader(open(glob.glob(R + '/stats/runc/*kernel_stats.csv')[0])))
+    rows = list(csv.DictReader(open(newest(R + '/stats/runc/*kernel_stats.csv'))))
     with open(pre + 'kernel_stats.csv', 'w') as f:
         w = csv.writer(f)
         w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
@@ -79,18 +84,18 @@ def main(R, tag, out='profiles', forwards=None):
     tr['convtaps_write_per_forward'] = tot_w
     pm = {}
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(glob.glob(R + '/pmc_mfma/runc/*counter_collection.csv')[0])):
+    for r in csv.DictReader(open(newest(R + '/pmc_mfma/runc/*counter_collection.csv'))):
         if 'convtaps' in r['Kernel_Name']:
             agg[r['Kernel_Name'][:70]][r['Counter_Name']] += float(r['Counter_Value'])
     dur = collections.defaultdict(float)
-    for r in csv.DictReader(open(glob.glob(R + '/pmc_mfma/runc/*kernel_trace.csv')[0])):
+    for r in csv.DictReader(open(newest(R + '/pmc_mfma/runc/*kernel_trace.csv'))):
         if 'convtaps' in r['Kernel_Name']:
             dur[r['Kernel_Name'][:70]] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-9
     for (k, v) in agg.items():
         pm[k] = {'effective_clock_ghz': v['GRBM_GUI_ACTIVE'] / 8 / dur[k] / 1e9, 'mfma_busy_fraction_of_simd_cycles': v['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * v['GRBM_GUI_ACTIVE'] / 8),
                  'lds_bank_conflict_cycles': v['SQ_LDS_BANK_CONFLICT'], 'duration_s_under_pmc': dur[k]}
     agg2 = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(glob.glob(R + '/pmc_l2/runc/*counter_collection.csv')[0])):
+    for r in csv.DictReader(open(newest(R + '/pmc_l2/runc/*counter_collection.csv'))):
         if 'convtaps' in r['Kernel_Name']:
             agg2[r['Kernel_Name'][:70]][r['Counter_Name']] += float(r['Counter_Value'])
     for (k, v) in agg2.items():
