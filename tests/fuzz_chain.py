@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off fuzz of the whole-net kernel and the bf16x3 kernel against the CPU oracle (random shapes, patterns, batch widths).
-    gpurun -- 'python3 tools/fuzz_chain.py 150'"""
+    gpurun -- 'python3 tests/fuzz_chain.py 150'   (checker script: lives under tests/ because it uses the oracle)"""
 import os
 import sys
 import numpy as np

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off fuzz of the factored untiled conv route (tap-table kernel / conv pipeline + zero guard) and of the 16-row big-group kernel against the CPU oracle
 on the STORED CSR: random channel counts, image sides, strides, exact-zero weights, Inf / NaN activations, batch widths.
-    gpurun -- 'python3 tools/fuzz_factored.py 60'"""
+    gpurun -- 'python3 tests/fuzz_factored.py 60'   (checker script: lives under tests/ because it uses the oracle)"""
 import os
 import sys
 import numpy as np
