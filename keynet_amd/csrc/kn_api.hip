@@ -596,7 +596,8 @@ int kn_convtaps_drop_zero_entries(kn_handle_t h) {
                             for (int64_t x = x0; x < std::min(x0 + w, c.Wout); x++) ord.push_back((int32_t)(y * c.Wout + x));
                     return ord;
                 };
-                const int nrb = c.Cout % 96 == 0 ? 3 : (c.Cout % 64 == 0 ? 2 : 1);
+                const int nrb = c.Cout % 96 == 0 ? 3 : (c.Cout % 64 == 0 ? 2 : 1);       // (the window below was tuned with three row blocks per workgroup; with one -- exact_table_launch -- its choices
+                                                                                     // still measured best: conv2 strips of 8 / 4 / 2 / 16 pixels 3.4 / 4.3 / 4.3 / 7.9 GB)
                 const int64_t n_cc = c.Cout / (32 * nrb);
                 // places a sharer may lie back: the rows gathered meanwhile by the resident workgroups (~1.5 KB per place and input channel at 256 columns) within half an L2 slice
                 static const int64_t env_window = getenv("KN_TABLE_WINDOW") ? atoll(getenv("KN_TABLE_WINDOW")) : 0;

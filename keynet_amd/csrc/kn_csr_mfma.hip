@@ -58,7 +58,7 @@ struct MfTaps {
 // (TAPS, measured and dropped: the four wavefronts of a workgroup on four pixels of a 2 x 2 block x the same 64 batch columns, so that the block's 16 input
 // pixels would be shared through the CU's vector cache -- HBM fetch of the AllConvNet forward 12.6 -> 19.5 GB and 2 % slower: the 256-byte row segments
 // cut the reuse between workgroups in L2 by more than the vector cache gives back.)
-template <int NRB, int PF, int NW = 4, bool TAPS = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
+template <int NRB, int PF, int NW = 4, bool TAPS = false, bool SB = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
                                             // re-reads but measured 8.5 % slower on the AllConvNet forward: 35.9 against 33.0 ms; not instantiated)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                                 const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
@@ -184,7 +184,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
         f32x32 d0 = zero, d1 = zero;
         auto product = [&](auto T_, const float a, const float x, f32x2 (&pending_sum)[16]) {
             constexpr int T = decltype(T_)::value;
-            if constexpr ((T & 1) == 0) {
+            if constexpr (SB) {                                                  // ONE result block (NRB = 1): 32 registers fewer, the other wavefronts of the SIMD fill the wait
+                static_assert(!SB || NRB == 1, "single result block: one row block per workgroup");
+                d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                add_into(acc[0], d0);
+            } else if constexpr ((T & 1) == 0) {
                 d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 add_into(pending_sum, d1);
@@ -403,8 +408,19 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work
 }
 
 // The order-preserving product of a factored conv operator through the kernel above (convtaps_spmm, KN_FLAG_EXACT, operators that carry the table).
-static int exact_table_launch(const MfTaps& tp, int64_t n_pix, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
-    const int nrb = tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1);
+static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+    // Row blocks (32 output channels each) per workgroup.  ONE: 123 registers, four wavefronts per SIMD instead of two with three blocks (227 registers) -- the
+    // matrix instruction and the packed adds behind it are dependent work of ONE wavefront, and the pair costs 145 cycles with four wavefronts interleaved
+    // against 155 with two (tools/micro/mfma_add_rate.hip).  Same-process A/B on the AllConvNet forward (tools/ab_allconv.py): 33.9 -> 31.3 ms, every
+    // layer faster (conv2 10.23 -> 9.60, conv5 9.81 -> 8.97 ms), bit-equal.  The price is paid in L2: the activation rows of a pixel are now requested by
+    // Cout / 32 workgroups instead of Cout / 96, and the siblings find each other's rows only while they stay within an XCD's 4 MB of each other: HBM reads
+    // of the seven launches 13.1 -> 21.3 GB.  Strided layers (neighbouring pixels share 3 of 9 input pixels instead of 6: conv3 +2.5 GB, conv6 +2.6 GB for
+    // 0.14 / 0.25 ms) keep three blocks.  KN_TABLE_NRB = A/B knob, read per call.
+    int nrb = strided ? (tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1)) : 1;
+    if (const char* e = getenv("KN_TABLE_NRB")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 3 && tp.Cout % (32 * v) == 0) nrb = v;
+    }
     MfTaps t = tp;
     t.n_cc = tp.Cout / (32 * nrb);
     const int64_t n_work = n_pix * t.n_cc;
@@ -413,7 +429,10 @@ static int exact_table_launch(const MfTaps& tp, int64_t n_pix, const float* x, i
     const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(nrb) + ",taps> (factored operator: products on the matrix pipe from the tap table)";
     if (nrb == 3) KN_LAUNCH(d, (csr_group_mfma_kernel<3, 8, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     else if (nrb == 2) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
-    else KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else if (getenv("KN_TABLE_1BLK") && atoi(getenv("KN_TABLE_1BLK")) == 0)      // A/B knob, read per call: the two-result-block form (123 registers, four wavefronts per SIMD)
+        KN_LAUNCH(d + " two result blocks", (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else      // one row block, ONE result block: 91 registers, five wavefronts per SIMD cover the matrix instruction's latency for each other (31.58 -> 31.42 ms per AllConvNet forward)
+        KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     KN_HIP(hipGetLastError());
     return KN_OK;
 }
@@ -430,7 +449,7 @@ int convtaps_exact_table_spmm(const ConvTapsDev& A, const float* x, int64_t ldx,
     t.HoWo = (int32_t)(A.Hout * A.Wout);
     t.Cout = (int32_t)A.Cout;
     t.n_cc = 1;
-    return exact_table_launch(t, A.Hout * A.Wout, x, ldx, n_vecs, y, ldy, relu, s);
+    return exact_table_launch(t, A.Hout * A.Wout, A.Hin * A.Win > A.Hout * A.Wout, x, ldx, n_vecs, y, ldy, relu, s);
 }
 
 // work lists per NRB (CsrDev::mf_*): chunks of 32 * NRB member rows of the pattern groups with >= MF_MIN_MEMBERS members

@@ -1,10 +1,12 @@
-"""Same-process, interleaved A/B of the grouped-row kernels on the whole PermutationKeynet AllConvNet forward (B = 4096): matrix-pipe products
-(default) against the vector-ALU pipeline (KN_NO_GROUP_MFMA=1, read per call); whole-forward time and per-layer times under each."""
+"""Same-process, interleaved A/B of per-call kernel switches on the whole PermutationKeynet AllConvNet forward (B = 4096): whole-forward time, per-layer
+times and bit-equality of the logits under each variant.
+    python3 tools/ab_allconv.py                                        # row blocks per workgroup of the tap-table kernel: default, 3, 2, 1
+    python3 tools/ab_allconv.py base KN_NO_EXACT_TABLE=1 KN_TABLE_NRB=3,KN_MF_PF=6
+A variant is a comma-separated list of NAME=value environment settings that the library reads per call ('base' = none)."""
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,40 +15,36 @@ import bench  # noqa: E402
 
 
 def main():
+    variants = sys.argv[1:] or ['base', 'KN_TABLE_NRB=3', 'KN_TABLE_NRB=2', 'KN_TABLE_NRB=1']
+    names = sorted({kv.split('=')[0] for v in variants if v != 'base' for kv in v.split(',')})
     (sensor, knet, inshape, batch, desc, net) = bench.build_workload('allconv', 0)
     dev = torch.device('cuda:0')
     g = torch.Generator(device=dev).manual_seed(1234)
     x = torch.randn((batch,) + tuple(inshape), generator=g, device=dev)
     xc = sensor.fromtensor(x).encrypt().astensor()
-    knet.forward_linear(xc)
+    for k in names:
+        os.environ.pop(k, None)
+    y0 = knet.forward_linear(xc).clone()
     torch.cuda.synchronize()
-
-    def setmode(m):
-        if m == 'valu':
-            os.environ['KN_NO_GROUP_MFMA'] = '1'
-        else:
-            os.environ.pop('KN_NO_GROUP_MFMA', None)
-
-    def timed(n):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            knet.forward_linear(xc)
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / n
-    res = {'mfma': [], 'valu': []}
-    for rnd in range(5):
-        for m in ('valu', 'mfma'):
-            setmode(m)
-            timed(3)
-            res[m].append(timed(15))
-    for (k, v) in res.items():
-        print('%-5s forward %s  median %.3f ms  %.0f images/s' % (k, ' '.join('%.2f' % t for t in v), float(np.median(v)), batch / float(np.median(v)) * 1e3))
-    for m in ('valu', 'mfma'):
-        setmode(m)
-        table = bench.time_layers(xc, bench.layer_table(knet, batch), 3)
-        print(m, 'per layer:', ' '.join('%s %.3f' % (r['name'], r['ms']) for r in table), ' sum %.3f' % sum(r['ms'] for r in table))
-    os.environ.pop('KN_NO_GROUP_MFMA', None)
+    for rnd in range(3):
+        for v in variants:
+            for k in names:
+                os.environ.pop(k, None)
+            if v != 'base':
+                for kv in v.split(','):
+                    (k, val) = kv.split('=')
+                    os.environ[k] = val
+            y = knet.forward_linear(xc)
+            torch.cuda.synchronize()
+            eq = torch.equal(y, y0)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                knet.forward_linear(xc)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) * 100
+            table = bench.time_layers(xc, bench.layer_table(knet, batch), 3)
+            print('%-28s forward %.3f ms (%.1f k images/s) bit-equal %s | ' % (v, ms, batch / ms, eq) +
+                  ' '.join('%s %.3f' % (r['name'], r['ms']) for r in table if r['name'].startswith('conv')), flush=True)
 
 
 if __name__ == '__main__':
