@@ -409,13 +409,13 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work
 
 // The order-preserving product of a factored conv operator through the kernel above (convtaps_spmm, KN_FLAG_EXACT, operators that carry the table).
 static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
-    // Row blocks (32 output channels each) per workgroup.  ONE: 123 registers, four wavefronts per SIMD instead of two with three blocks (227 registers) -- the
+    // Row blocks (32 output channels each) per workgroup.  ONE (two result blocks alternating): 123 registers, four wavefronts per SIMD instead of two with three blocks (227 registers) -- the
     // matrix instruction and the packed adds behind it are dependent work of ONE wavefront, and the pair costs 145 cycles with four wavefronts interleaved
-    // against 155 with two (tools/micro/mfma_add_rate.hip).  Same-process A/B on the AllConvNet forward (tools/ab_allconv.py): 33.9 -> 31.3 ms, every
+    // against 155 with two (tools/micro/mfma_add_rate.hip).  Same-process A/B on the AllConvNet forward (tools/ab_allconv.py): 33.9 -> 31.6 ms with the strided layers kept at three blocks, every
     // layer faster (conv2 10.23 -> 9.60, conv5 9.81 -> 8.97 ms), bit-equal.  The price is paid in L2: the activation rows of a pixel are now requested by
     // Cout / 32 workgroups instead of Cout / 96, and the siblings find each other's rows only while they stay within an XCD's 4 MB of each other: HBM reads
-    // of the seven launches 13.1 -> 21.3 GB.  Strided layers (neighbouring pixels share 3 of 9 input pixels instead of 6: conv3 +2.5 GB, conv6 +2.6 GB for
-    // 0.14 / 0.25 ms) keep three blocks.  KN_TABLE_NRB = A/B knob, read per call.
+    // of the seven launches 13.1 -> 21.3 GB with one block everywhere.  Strided layers (neighbouring pixels share 3 of 9 input pixels instead of 6: conv3 +2.5 GB, conv6 +2.6 GB for
+    // 0.14 / 0.25 ms) keep three blocks: 16.2 GB.  KN_TABLE_NRB = A/B knob, read per call.
     int nrb = strided ? (tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1)) : 1;
     if (const char* e = getenv("KN_TABLE_NRB")) {
         const int v = atoi(e);
@@ -429,10 +429,10 @@ static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, con
     const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(nrb) + ",taps> (factored operator: products on the matrix pipe from the tap table)";
     if (nrb == 3) KN_LAUNCH(d, (csr_group_mfma_kernel<3, 8, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     else if (nrb == 2) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
-    else if (getenv("KN_TABLE_1BLK") && atoi(getenv("KN_TABLE_1BLK")) == 0)      // A/B knob, read per call: the two-result-block form (123 registers, four wavefronts per SIMD)
-        KN_LAUNCH(d + " two result blocks", (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
-    else      // one row block, ONE result block: 91 registers, five wavefronts per SIMD cover the matrix instruction's latency for each other (31.58 -> 31.42 ms per AllConvNet forward)
-        KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else if (getenv("KN_TABLE_1BLK") && atoi(getenv("KN_TABLE_1BLK")) == 1)      // A/B knob, read per call: ONE result block (91 registers, five wavefronts per SIMD): 31.42 against 31.58 ms per
+        // AllConvNet forward, but 320 instead of 256 workgroups share an XCD's L2: HBM reads of the seven launches 16.2 -> 22.2 GB (conv5 6.1 -> 9.0): not the default
+        KN_LAUNCH(d + " one result block", (csr_group_mfma_kernel<1, 6, 4, true, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
+    else KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     KN_HIP(hipGetLastError());
     return KN_OK;
 }
