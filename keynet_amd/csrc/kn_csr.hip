@@ -659,8 +659,10 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
                 wr0.push_back((int32_t)r0);
             }
             if (n_mem >= MF_MIN_MEMBERS) {
-                // matrix-pipe kernel: chunks of three 32-row blocks, the tail as 1 .. 3 blocks (a last block may be partly filled)
-                const int nrb_max = getenv("KN_MF_NRB") ? std::max(1, std::min(3, atoi(getenv("KN_MF_NRB")))) : 3;     // A/B knob, read when the operator is created
+                // matrix-pipe kernel: chunks of ONE 32-row block (a last block may be partly filled): 125 registers, four wavefronts per SIMD -- the adds of a result
+                // block wait for its matrix instruction and only other wavefronts fill that wait.  AllConvNet kept in CSR form, whole forward, chunks of 3 / 2 / 1
+                // blocks (229 / 157 / 125 registers): 32.84 / 32.26 / 31.38 ms.  KN_MF_NRB = A/B knob, read when the operator is created.
+                const int nrb_max = getenv("KN_MF_NRB") ? std::max(1, std::min(3, atoi(getenv("KN_MF_NRB")))) : 1;
                 for (int64_t r0 = 0; r0 < n_mem;) {
                     const int64_t left = n_mem - r0;
                     const int nrb = left >= 32 * nrb_max ? nrb_max : (int)((left + 31) / 32);

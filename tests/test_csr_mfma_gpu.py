@@ -34,12 +34,15 @@ def grouped_operator(rng, n, members, n_groups, ncol_of, loose_every=5, dtype_sc
     return (len(rows), indptr, indices, data)
 
 
-@pytest.mark.parametrize('members,n_vecs', [(96, 512), (192, 256), (32, 1024), (24, 512), (40, 384), (100, 260), (70, 1000), (200, 128)])
-def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs, monkeypatch):
-    """Groups of 24 .. 200 member rows (1, 2 and 3 row blocks per workgroup, partly filled last blocks), 1 .. 75 stored columns per group
-    (fewer than the six columns in flight, every remainder modulo six), batches that are not a multiple of 64 or 256, loose rows in
-    between, ReLU on and off."""
+@pytest.mark.parametrize('members,n_vecs,nrb', [(96, 512, 1), (192, 256, 1), (32, 1024, 1), (24, 512, 1), (40, 384, 1), (100, 260, 1), (70, 1000, 1), (200, 128, 1),
+                                                (96, 512, 3), (192, 256, 3), (100, 260, 3), (70, 1000, 2), (200, 128, 3), (160, 384, 2)])
+def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs, nrb, monkeypatch):
+    """Groups of 24 .. 200 member rows, chunks of one (the default), two and three 32-row blocks per workgroup (KN_MF_NRB, read when the operator is
+    created) with partly filled last blocks, 1 .. 75 stored columns per group (fewer than the six columns in flight, every remainder modulo six),
+    batches that are not a multiple of 64 or 256, loose rows in between, ReLU on and off."""
     monkeypatch.setenv('KN_GROUP_MFMA', '1')                 # forced: by default only operators with long stored sequences (mean >= 256 columns) take it
+    if nrb != 1:
+        monkeypatch.setenv('KN_MF_NRB', str(nrb))
     rng = np.random.RandomState(members * 1000 + n_vecs)
     n = 1100
     n_groups = max(600 * 96 // members, 40)
@@ -48,7 +51,7 @@ def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs, monkeypatch):
     W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
     with torch.cuda.device(dev()):
         plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
-    assert 'csr_group_mfma_kernel' in plan, plan
+    assert 'csr_group_mfma_kernel' in plan and ('row blocks=%d' % nrb) in plan, plan
     ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
     xd = torch.as_tensor(X).to(dev())
     for relu in (False, True):
