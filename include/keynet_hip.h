@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KN_ABI_VERSION 2
+#define KN_ABI_VERSION 3
 
 enum kn_status {
     KN_OK = 0,
@@ -66,6 +66,16 @@ int         kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len)
 int kn_csr_create(int64_t rows, int64_t cols, int64_t nnz,
                   const int32_t* indptr, const int32_t* indices, const float* data,
                   kn_handle_t* out);
+
+/* The same container when its scipy matrix is FLOAT64 (SparseMatrix keeps `A.dtype`, keynet/sparse.py:423; the public challenge key-net the
+ * reference ships, demo/keynet_challenge_lenet_10AUG20.pkl + demo/challenge.ipynb cell 5, carries float64 conv / pool operators).  torchdot
+ * (keynet/sparse.py:488-492) coerces x to float32 and hands both to scipy: numpy up-casts, csr_matvecs runs in float64 (x up-cast element by
+ * element, f64 multiply then f64 add in stored order) and the layer returns a float64 block that the next layer's coercion rounds to f32.
+ * kn_spmm on such a handle writes that block rounded to f32 ONCE (what the next layer consumes); kn_spmm_f64 writes the float64 block itself
+ * (what the reference's torchdot returns).  Bit-exact with scipy either way; KN_FLAG_EXACT is implied, kn_chain_create refuses the handle. */
+int kn_csr_create_f64(int64_t rows, int64_t cols, int64_t nnz,
+                      const int32_t* indptr, const int32_t* indices, const double* data,
+                      kn_handle_t* out);
 
 /* Replaces keynet.sparse.TiledMatrix / DiagonalTiledMatrix (keynet/sparse.py:517-571, 657-687):
  * blocks[nblocks][3] = (row0, col0, k) as iterated by __iter__; tile k = COO entries tile_ptr[k]..tile_ptr[k+1] of
@@ -139,10 +149,14 @@ int kn_nnz(kn_handle_t h, int64_t* nnz);
 /* nnz of the expanded operator the reference applies (tocsr()), = the algorithmic MAC count per input vector */
 int kn_nnz_expanded(kn_handle_t h, int64_t* nnz);
 int kn_shape(kn_handle_t h, int64_t* rows, int64_t* cols);
+/* SparseMatrix.dtype (keynet/sparse.py:423) as a width: 64 for a kn_csr_create_f64 operator, 32 for every other handle */
+int kn_dtype_bits(kn_handle_t h, int* bits);
 
 /* tocsr()/tocoo() (keynet/sparse.py:502-507, 643-647, 816-835): expanded operator into HOST buffers sized by
  * kn_nnz_expanded (indptr[rows+1]).  CSR operators come back in stored order; tiled ones canonical (sorted). */
 int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data);
+/* the same for a kn_csr_create_f64 operator (stored order, float64 values); kn_export_csr refuses such a handle and vice versa */
+int kn_export_csr_f64(kn_handle_t h, int32_t* indptr, int32_t* indices, double* data);
 
 /* ---- the hot path -------------------------------------------------------------------------------------------- */
 
@@ -151,6 +165,13 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
  * x_dev/y_dev: device f32, feature-major, leading dimensions ldx/ldy >= n_vecs (floats).  x and y must not alias. */
 int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
             float* y_dev, int64_t ldy, uint32_t flags, void* stream);
+
+/* SparseMatrix.torchdot of a FLOAT64 operator (kn_csr_create_f64) with the result dtype the reference returns: Y[rows, n_vecs] float64 =
+ * W . (double)X, accumulated in float64 in stored order (+ ReLU when KN_FLAG_RELU: F.relu on the float64 block, keynet/layer.py:93).
+ * x_dev float32 as everywhere (keynet/sparse.py:489-491), y_dev device float64 with leading dimension ldy (doubles).  KN_ERR_UNSUPPORTED on
+ * any other handle: float32 operators return float32. */
+int kn_spmm_f64(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
+                double* y_dev, int64_t ldy, uint32_t flags, void* stream);
 
 /* kn_spmm that additionally raises *y_absmax_dev (device f32, caller-initialised, e.g. to 0) to max |Y[r, b]| over the block it wrote,
  * stream-ordered.  No reference counterpart: the reference applies ONE arithmetic on every call (keynet/sparse.py:488-492), so its 1e-5

@@ -16,10 +16,10 @@ KN_OK = 0
 KN_FLAG_RELU = 1
 KN_FLAG_EXACT = 2
 KN_FLAG_BF16X3 = 4
-KN_ABI_VERSION = 2
+KN_ABI_VERSION = 3
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
-SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_tiled_create', 'kn_conv2dtiled_create',
+SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_csr_create_f64', 'kn_dtype_bits', 'kn_export_csr_f64', 'kn_spmm_f64', 'kn_tiled_create', 'kn_conv2dtiled_create',
            'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
@@ -53,6 +53,10 @@ def lib():
         L.kn_last_error.restype = ctypes.c_char_p
         L.kn_device_info.argtypes = [p, p, i64]
         L.kn_csr_create.argtypes = [i64, i64, i64, p, p, p, p]
+        L.kn_csr_create_f64.argtypes = [i64, i64, i64, p, p, p, p]
+        L.kn_dtype_bits.argtypes = [p, p]
+        L.kn_export_csr_f64.argtypes = [p, p, p, p]
+        L.kn_spmm_f64.argtypes = [p, p, i64, i64, p, i64, u32, p]
         L.kn_tiled_create.argtypes = [i64, i64, i64, p, i64, p, p, p, p, p]
         L.kn_conv2dtiled_create.argtypes = [i64, i64, p, p, i64, p, i64, p, p, p, p, p]
         L.kn_convtaps_create.argtypes = [p, p, i64, p, i64, p, p, p, p, p, p]
@@ -120,11 +124,13 @@ class Operator(object):
 
     @staticmethod
     def csr(shape, indptr, indices, data):
+        """kn_csr_create, or kn_csr_create_f64 when `data` is a float64 array (the operator then computes in float64, as scipy does for it)."""
         (ip, ipp) = _np(indptr, np.int32)
         (ix, ixp) = _np(indices, np.int32)
-        (dt, dtp) = _np(data, np.float32)
+        f64 = np.asarray(data).dtype == np.float64
+        (dt, dtp) = _np(data, np.float64 if f64 else np.float32)
         h = ctypes.c_void_p()
-        check(lib().kn_csr_create(int(shape[0]), int(shape[1]), int(len(ix)), ipp, ixp, dtp, ctypes.byref(h)))
+        check((lib().kn_csr_create_f64 if f64 else lib().kn_csr_create)(int(shape[0]), int(shape[1]), int(len(ix)), ipp, ixp, dtp, ctypes.byref(h)))
         return Operator(h)
 
     @staticmethod
@@ -211,14 +217,25 @@ class Operator(object):
         check(lib().kn_shape(self._h, ctypes.byref(r), ctypes.byref(c)))
         return (r.value, c.value)
 
+    def dtype_bits(self):
+        b = ctypes.c_int(0)
+        check(lib().kn_dtype_bits(self._h, ctypes.byref(b)))
+        return b.value
+
     def export_csr(self):
         (rows, _) = self.shape()
         n = self.nnz_expanded()
+        f64 = self.dtype_bits() == 64
         indptr = np.zeros(rows + 1, dtype=np.int32)
         indices = np.zeros(max(n, 1), dtype=np.int32)
-        data = np.zeros(max(n, 1), dtype=np.float32)
-        check(lib().kn_export_csr(self._h, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p), data.ctypes.data_as(ctypes.c_void_p)))
+        data = np.zeros(max(n, 1), dtype=np.float64 if f64 else np.float32)
+        check((lib().kn_export_csr_f64 if f64 else lib().kn_export_csr)(self._h, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p),
+                                                                        data.ctypes.data_as(ctypes.c_void_p)))
         return (indptr, indices[:n], data[:n])
+
+    def spmm_f64(self, x_ptr, ldx, n_vecs, y_ptr, ldy, flags, stream):
+        """kn_spmm_f64: a float64 operator's product as the float64 block the reference returns."""
+        check(lib().kn_spmm_f64(self._h, x_ptr, int(ldx), int(n_vecs), y_ptr, int(ldy), int(flags), stream))
 
     def spmm(self, x_ptr, ldx, n_vecs, y_ptr, ldy, flags, stream, absmax_ptr=None):
         """kn_spmm, or kn_spmm_screen when `absmax_ptr` (device f32 raised to max |Y|) is given."""

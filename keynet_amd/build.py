@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['kn_api.hip', 'kn_csr.hip', 'kn_csr_mfma.hip', 'kn_conv.hip', 'kn_elementwise.hip', 'kn_chain.hip']
+SOURCES = ['kn_api.hip', 'kn_csr.hip', 'kn_csr_f64.hip', 'kn_csr_mfma.hip', 'kn_conv.hip', 'kn_elementwise.hip', 'kn_chain.hip']
 LIB = os.path.join(HERE, 'libkeynet_hip.so')
 
 

@@ -20,6 +20,47 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// The library's only look at the environment: called once per operator create, the result is recorded in the handle (kn_internal.h: Tuning).
+Tuning tuning_from_env() {
+    Tuning t;
+    struct Knob {
+        const char* name;
+        int Tuning::*field;
+    };
+    static const Knob knobs[] = {
+        {"KN_NO_SPTR", &Tuning::no_sptr}, {"KN_NO_SMALLK_PIPE", &Tuning::no_smallk_pipe}, {"KN_NO_GROUP_PIPE", &Tuning::no_group_pipe},
+        {"KN_NO_BIG_GROUPS", &Tuning::no_big_groups}, {"KN_NO_EXACT_TABLE", &Tuning::no_exact_table}, {"KN_GROUP_MFMA", &Tuning::group_mfma},
+        {"KN_BIG_MFMA16", &Tuning::big_mfma16}, {"KN_MF_NRB", &Tuning::mf_nrb}, {"KN_TABLE_NRB", &Tuning::table_nrb},
+#ifdef KN_ABLATION
+        {"KN_OCC", &Tuning::occ}, {"KN_NO_TAIL_SPLIT", &Tuning::no_tail_split}, {"KN_NO_SMALLK", &Tuning::no_smallk}, {"KN_EXACT_PIPE", &Tuning::exact_pipe},
+        {"KN_EXACT_COB_GROUPS", &Tuning::exact_cob_groups}, {"KN_EXACT_XD", &Tuning::exact_xd}, {"KN_MF_PF", &Tuning::mf_pf},
+        {"KN_TABLE_WINDOW", &Tuning::table_window}, {"KN_TABLE_STRIP", &Tuning::table_strip}, {"KN_NO_PATCH", &Tuning::no_patch},
+        {"KN_NO_ROW_ORDER", &Tuning::no_row_order}, {"KN_CHAIN_NO_CL", &Tuning::chain_no_cl}, {"KN_ABL", &Tuning::abl},
+#endif
+    };
+    for (const Knob& k : knobs)
+        if (const char* v = getenv(k.name)) t.*(k.field) = atoi(v);
+    t.mf_nrb = std::max(1, std::min(3, t.mf_nrb));
+    if (t.table_nrb < 0 || t.table_nrb > 3) t.table_nrb = 0;
+    return t;
+}
+
+std::string Tuning::describe() const {
+    static const Tuning d;
+    std::string o;
+    auto add = [&](const char* n, int v, int dv) {
+        if (v != dv) o += (o.empty() ? "" : ",") + std::string(n) + "=" + std::to_string(v);
+    };
+    add("no_sptr", no_sptr, d.no_sptr); add("no_smallk_pipe", no_smallk_pipe, d.no_smallk_pipe); add("no_group_pipe", no_group_pipe, d.no_group_pipe);
+    add("no_big_groups", no_big_groups, d.no_big_groups); add("no_exact_table", no_exact_table, d.no_exact_table); add("group_mfma", group_mfma, d.group_mfma);
+    add("big_mfma16", big_mfma16, d.big_mfma16); add("mf_nrb", mf_nrb, d.mf_nrb); add("table_nrb", table_nrb, d.table_nrb);
+    add("occ", occ, d.occ); add("no_tail_split", no_tail_split, d.no_tail_split); add("no_smallk", no_smallk, d.no_smallk); add("exact_pipe", exact_pipe, d.exact_pipe);
+    add("exact_cob_groups", exact_cob_groups, d.exact_cob_groups); add("exact_xd", exact_xd, d.exact_xd); add("mf_pf", mf_pf, d.mf_pf);
+    add("table_window", table_window, d.table_window); add("table_strip", table_strip, d.table_strip); add("no_patch", no_patch, d.no_patch);
+    add("no_row_order", no_row_order, d.no_row_order); add("chain_no_cl", chain_no_cl, d.chain_no_cl); add("abl", abl, d.abl);
+    return o.empty() ? o : " opts{" + o + "}";
+}
+
 static int ensure_device(int* dev) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -61,7 +102,8 @@ struct OperatorDeleter {
 };
 typedef std::unique_ptr<kn_operator, OperatorDeleter> OperatorPtr;   // a create that fails or throws half way frees its device memory
 
-static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data,
+template <typename TV>
+static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const TV* data,
                            kn_operator** out) {
     KN_REQUIRE(out != nullptr, KN_ERR_INVALID, "out handle is NULL");
     *out = nullptr;
@@ -75,18 +117,23 @@ static int csr_create_impl(int64_t rows, int64_t cols, int64_t nnz, const int32_
     int rc = ensure_device(&dev);
     if (rc) return rc;
     OperatorPtr h(new kn_operator());
-    h->kind = KIND_CSR;
+    h->kind = std::is_same<TV, double>::value ? KIND_CSR64 : KIND_CSR;
     h->device = dev;
     h->rows = rows;
     h->cols = cols;
     h->nnz_stored = nnz;
     h->nnz_expanded = nnz;
+    h->csr.tune = tuning_from_env();
     h->csr.rows = rows;
     h->csr.cols = cols;
     h->csr.nnz = nnz;
-    if ((rc = upload(&h->csr.indptr, indptr, (size_t)rows + 1)) || (rc = upload(&h->csr.indices, indices, (size_t)nnz)) ||
-        (rc = upload(&h->csr.data, data, (size_t)nnz)) || (rc = csr_build_groups(h.get(), indptr, indices, data)))
-        return rc;
+    if ((rc = upload(&h->csr.indptr, indptr, (size_t)rows + 1)) || (rc = upload(&h->csr.indices, indices, (size_t)nnz))) return rc;
+    if constexpr (std::is_same<TV, double>::value) {
+        // a float64 operator (kn_csr_create_f64): one row kernel in f64 arithmetic, no pattern groups (kn_csr_f64.hip)
+        if ((rc = upload(&h->csr.data64, data, (size_t)nnz))) return rc;
+    } else {
+        if ((rc = upload(&h->csr.data, data, (size_t)nnz)) || (rc = csr_build_groups(h.get(), indptr, indices, data))) return rc;
+    }
     *out = h.release();
     return KN_OK;
 }
@@ -131,7 +178,7 @@ struct ConvBuild {
     int64_t nnz_stored = 0;
 };
 
-static int convtaps_create_impl(ConvBuild& b, kn_operator** out, bool allow_split = true) {
+static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     *out = nullptr;
     const int64_t Cin = b.inshape[0], Hin = b.inshape[1], Win = b.inshape[2];
     const int64_t Cout = b.outshape[0], Hout = b.outshape[1], Wout = b.outshape[2];
@@ -157,6 +204,7 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out, bool allow_spli
     h->rows = rows;
     h->cols = cols;
     ConvTapsDev& c = h->ct;
+    c.tune = tuning_from_env();
     c.Cin = Cin; c.Hin = Hin; c.Win = Win; c.Cout = Cout; c.Hout = Hout; c.Wout = Wout;
     c.ntaps = ntaps;
     const int64_t KC = Cin >= 16 ? 16 : 4;
@@ -271,39 +319,6 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out, bool allow_spli
         (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
         (rc = upload(&c.lastcol, lastcol.data(), lastcol.size())))
         return rc;
-    // Split-K twin (kn_internal.h: split_sub) for operators with few output pixels and a long contraction: VGG-16 conv5_x has 196 pixels x 4
-    // Cout tiles x 2 batch tiles = 6 tiles per CU at 256 images, all of them the same length -- the launch runs as two synchronised rounds.
-    // Each pixel's slots (ascending input pixel) are dealt to two pseudo-pixels, first half / second half.  MEASURED SLOWER than the unsplit
-    // launch on every conv5_x layer (round 4, same-process A/B: 1.68 ms unsplit against 1.70 / 1.76 / 1.85 ms: half-length tiles pay the
-    // per-tile prologue and epilogue twice and write + re-read 0.2 GB of partial sums), so the twin is built only on request: KN_SPLITK=1 in
-    // the environment when the operator is created, and KN_SPLITK=1 per call to take it.
-    if (allow_split && b.has_last && getenv("KN_SPLITK") && getenv("KN_SPLITK")[0] == '1' && HoWo * (c.cout_pad / MT) <= 2048 && Cin >= 64 && mx >= 2 && order.size() > 0) {
-        constexpr int64_t S = 2;
-        ConvBuild b2;
-        for (int k = 0; k < 3; k++) b2.inshape[k] = b.inshape[k];
-        b2.outshape[0] = Cout;
-        b2.outshape[1] = 1;
-        b2.outshape[2] = HoWo * S;
-        b2.has_last = false;
-        b2.taps = b.taps;
-        b2.ent_out.reserve(order.size());
-        b2.ent_in.reserve(order.size());
-        b2.ent_tap.reserve(order.size());
-        b2.ent_coef.reserve(order.size());
-        for (size_t k = 0; k < order.size(); k++) {
-            const size_t e = order[k];
-            const int64_t px = b.ent_out[e];
-            const int64_t r = (int64_t)k - pix_ptr[(size_t)px], n = pix_ptr[(size_t)px + 1] - pix_ptr[(size_t)px];
-            b2.ent_out.push_back((int32_t)(px * S + (r >= (n + 1) / 2 ? 1 : 0)));
-            b2.ent_in.push_back(b.ent_in[e]);
-            b2.ent_tap.push_back(b.ent_tap[e]);
-            b2.ent_coef.push_back(b.ent_coef[e]);
-        }
-        kn_operator* sub = nullptr;
-        if ((rc = convtaps_create_impl(b2, &sub, false))) return rc;
-        h->split_sub = sub;
-        h->split_S = S;
-    }
     *out = h.release();
     return KN_OK;
 }
@@ -354,6 +369,20 @@ int kn_device_info(int* n_devices, char* arch_buf, int64_t arch_buf_len) {
 int kn_csr_create(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const float* data, kn_handle_t* out) {
     return guarded([&]() -> int {
     return csr_create_impl(rows, cols, nnz, indptr, indices, data, out);
+    });
+}
+
+int kn_csr_create_f64(int64_t rows, int64_t cols, int64_t nnz, const int32_t* indptr, const int32_t* indices, const double* data, kn_handle_t* out) {
+    return guarded([&]() -> int {
+    return csr_create_impl(rows, cols, nnz, indptr, indices, data, out);
+    });
+}
+
+int kn_dtype_bits(kn_handle_t h, int* bits) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h && bits, KN_ERR_INVALID, "NULL argument");
+    *bits = h->kind == KIND_CSR64 ? 64 : 32;
+    return KN_OK;
     });
 }
 
@@ -600,8 +629,7 @@ int kn_convtaps_drop_zero_entries(kn_handle_t h) {
                                                                                      // still measured best: conv2 strips of 8 / 4 / 2 / 16 pixels 3.4 / 4.3 / 4.3 / 7.9 GB)
                 const int64_t n_cc = c.Cout / (32 * nrb);
                 // places a sharer may lie back: the rows gathered meanwhile by the resident workgroups (~1.5 KB per place and input channel at 256 columns) within half an L2 slice
-                static const int64_t env_window = getenv("KN_TABLE_WINDOW") ? atoll(getenv("KN_TABLE_WINDOW")) : 0;
-                static const int64_t env_strip = getenv("KN_TABLE_STRIP") ? atoll(getenv("KN_TABLE_STRIP")) : -1;      // A/B knobs (read once)
+                const int64_t env_window = c.tune.table_window, env_strip = c.tune.table_strip;      // (diagnostic build: A/B knobs; product: the rule)
                 const int64_t window = env_window > 0 ? env_window : std::max<int64_t>(2, std::min<int64_t>(64, (2048 * 2) / (3 * c.Cin * n_cc)));
                 std::vector<int32_t> best((size_t)HoWo);
                 KN_HIP(hipMemcpy(best.data(), c.pix_order, (size_t)HoWo * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -717,7 +745,6 @@ int kn_destroy(kn_handle_t h) {
     if (h->chain) chain_free(h->chain);
     if (h->exact) kn_destroy(h->exact);
     if (h->dense_sub) kn_destroy(h->dense_sub);
-    if (h->split_sub) kn_destroy(h->split_sub);
     if (h->dense_lastcol) (void)hipFree(h->dense_lastcol);
     for (auto& kv : h->dense_ws)
         if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -769,6 +796,7 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
         }
         return KN_OK;
     }
+    KN_REQUIRE(h->kind != KIND_CSR64, KN_ERR_UNSUPPORTED, "kn_export_csr: a float64 operator is exported by kn_export_csr_f64");
     KN_REQUIRE(h->kind == KIND_CONVTAPS, KN_ERR_UNSUPPORTED, "kn_export_csr: dense operators and chains are exported by their creator (the host keeps the matrices)");
     std::vector<int32_t> ip, ix;
     std::vector<float> dt;
@@ -787,10 +815,24 @@ int kn_export_csr(kn_handle_t h, int32_t* indptr, int32_t* indices, float* data)
     });
 }
 
+int kn_export_csr_f64(kn_handle_t h, int32_t* indptr, int32_t* indices, double* data) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h && indptr, KN_ERR_INVALID, "NULL argument");
+    KN_REQUIRE(h->kind == KIND_CSR64, KN_ERR_UNSUPPORTED, "kn_export_csr_f64: not a float64 CSR operator (kn_csr_create_f64)");
+    KN_HIP(hipMemcpy(indptr, h->csr.indptr, sizeof(int32_t) * (size_t)(h->rows + 1), hipMemcpyDeviceToHost));
+    if (h->csr.nnz > 0) {
+        KN_REQUIRE(indices && data, KN_ERR_INVALID, "NULL argument");
+        KN_HIP(hipMemcpy(indices, h->csr.indices, sizeof(int32_t) * (size_t)h->csr.nnz, hipMemcpyDeviceToHost));
+        KN_HIP(hipMemcpy(data, h->csr.data64, sizeof(double) * (size_t)h->csr.nnz, hipMemcpyDeviceToHost));
+    }
+    return KN_OK;
+    });
+}
+
 // split-K partial-sum workspace of a dense operator for stream `s`, grown to `n_vecs` batch columns on demand.  The growing call is not
 // capturable in a HIP graph: run one eager forward per stream and batch size first (KeyedModel.capture does), or kn_reserve_workspace.
 static int dense_workspace(kn_handle_t h, hipStream_t s, int64_t n_vecs, float** out) {
-    const int64_t outs = h->rows - 1, S = h->kind == KIND_DENSE ? h->dense_splits : h->split_S;
+    const int64_t outs = h->rows - 1, S = h->dense_splits;
     std::lock_guard<std::mutex> g(h->lazy_mu);
     kn_operator::DenseWs& w = h->dense_ws[s];
     if (w.vecs < n_vecs) {
@@ -852,6 +894,8 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
     bool fused = false;
     if (h->kind == KIND_CSR) {
         rc = csr_spmm(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
+    } else if (h->kind == KIND_CSR64) {
+        rc = csr_f64_spmm<float>(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, s);      // the f64 result rounded to f32 once (what the next layer consumes)
     } else if (h->kind == KIND_CHAIN) {
         rc = chain_forward(h->chain, x_dev, ldx, n_vecs, y_dev, ldy, s);   // order-preserving by construction; ReLU flags were fixed at create
     } else if (h->kind == KIND_DENSE) {
@@ -872,25 +916,7 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
             rc = convtaps_build_bf16(h->ct, h->h_taps);
             if (rc) return rc;
         }
-        // split-K twin (opt-in, measured slower: see convtaps_create_impl): taken only when it exists and KN_SPLITK=1 at this call
-        bool split = false;
-        if (h->split_sub != nullptr && !(flags & (KN_FLAG_EXACT | KN_FLAG_BF16X3)) && n_vecs % 128 == 0) {
-            const char* force = getenv("KN_SPLITK");
-            split = force != nullptr && force[0] == '1';
-        }
-        if (split) {
-            const int64_t outs = h->rows - 1, S = h->split_S;
-            float* ws = nullptr;
-            if (plan_sink() == nullptr) {
-                rc = dense_workspace(h, s, n_vecs, &ws);
-                if (rc) return rc;
-            }
-            rc = convtaps_spmm(h->split_sub->ct, outs * S, h->cols - 1, x_dev, ldx, n_vecs, ws, n_vecs, 0, s);
-            if (rc) return rc;
-            rc = dense_reduce(ws, n_vecs, outs, S, h->ct.lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
-        } else {
-            rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
-        }
+        rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);
     }
     if (rc) return rc;
     if (absmax && !fused) return absmax_pass(y_dev, h->rows, ldy, n_vecs, absmax, s);
@@ -903,6 +929,23 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, floa
 
 int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, float* y_dev, int64_t ldy, uint32_t flags, float* y_absmax_dev, void* stream) {
     return guarded([&]() -> int { return spmm_impl(h, x_dev, ldx, n_vecs, y_dev, ldy, flags, y_absmax_dev, stream); });
+}
+
+int kn_spmm_f64(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, double* y_dev, int64_t ldy, uint32_t flags, void* stream) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    KN_REQUIRE(h->kind == KIND_CSR64, KN_ERR_UNSUPPORTED, "kn_spmm_f64: not a float64 CSR operator (kn_csr_create_f64); float32 operators return float32 (kn_spmm)");
+    if (plan_sink() == nullptr) KN_HOST_ONLY_GUARD();
+    KN_REQUIRE(n_vecs >= 0 && n_vecs < INT32_MAX, KN_ERR_INVALID, "n_vecs out of range");
+    if (n_vecs == 0 || h->rows == 0) return KN_OK;
+    KN_REQUIRE(x_dev && y_dev, KN_ERR_INVALID, "NULL activation pointer");
+    KN_REQUIRE(ldx >= n_vecs && ldy >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
+    KN_REQUIRE((const void*)x_dev != (const void*)y_dev, KN_ERR_INVALID, "x and y alias");
+    int cur = -1;
+    KN_HIP(hipGetDevice(&cur));
+    KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one (create it under the device of x)");
+    return csr_f64_spmm<double>(h->csr, x_dev, ldx, n_vecs, y_dev, ldy, flags, reinterpret_cast<hipStream_t>(stream));
+    });
 }
 
 int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax_dev, void* stream) {
@@ -919,7 +962,7 @@ int kn_reserve_workspace(kn_handle_t h, int64_t n_vecs, void* stream) {
     return guarded([&]() -> int {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
     KN_REQUIRE(n_vecs >= 0 && n_vecs < INT32_MAX, KN_ERR_INVALID, "n_vecs out of range");
-    if ((h->kind != KIND_DENSE && h->split_sub == nullptr) || n_vecs == 0) return KN_OK;      // only split-K operators keep per-call state (their partial sums)
+    if (h->kind != KIND_DENSE || n_vecs == 0) return KN_OK;      // only a dense (split-K) operator keeps per-call state (its partial sums)
     int cur = -1;
     KN_HIP(hipGetDevice(&cur));
     KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one");
@@ -938,6 +981,9 @@ int kn_spmm_plan(kn_handle_t h, int64_t n_vecs, int64_t ldx, int64_t ldy, uint32
     const int rc = kn_spmm(h, reinterpret_cast<const float*>((uintptr_t)4096), ldx, n_vecs, reinterpret_cast<float*>((uintptr_t)8192), ldy, flags, nullptr);
     plan_sink() = nullptr;
     if (rc) return rc;
+    if (h->kind == KIND_CSR || h->kind == KIND_CSR64) sink.text += h->csr.tune.describe();      // options recorded at create that differ from the defaults
+    else if (h->kind == KIND_CONVTAPS) sink.text += h->ct.tune.describe();
+    else if (h->kind == KIND_DENSE) sink.text += h->dense_sub->ct.tune.describe();
     std::strncpy(buf, sink.text.c_str(), (size_t)buf_len - 1);
     buf[buf_len - 1] = 0;
     return KN_OK;

@@ -574,7 +574,7 @@ static int chain_upload(ChainDev* c, const T** dst, const std::vector<T>& h) {
 // one layer: CSR (host copy, stored order) -> the sliced layout above.  in_base / zero_byte: LDS byte offsets of the layer's input buffer
 // and of the always-zero feature.
 static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_t cols, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix,
-                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte) {
+                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte, const Tuning& tune) {
     constexpr int RPS = 64;
     (void)cols;
     auto off = [&](int32_t col) { return in_base + 16 * col; };
@@ -723,7 +723,7 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
     bool all_shared = n_slices >= 1;
     for (int64_t s = 0; s < n_slices; s++) all_shared = all_shared && s_shared[(size_t)s];
     // (chain_create drops either choice when the staging area does not fit beside the activations)
-    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : (all_shared && !getenv("KN_CHAIN_NO_CL")) ? -(int32_t)pool_quads : 0;
+    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : (all_shared && !tune.chain_no_cl) ? -(int32_t)pool_quads : 0;
     int rc;
     if ((rc = chain_upload(c, &L.vals, vals)) || (rc = chain_upload(c, &L.cols, colpool)) || (rc = chain_upload(c, &L.lane_meta, lane_meta)) ||
         (rc = chain_upload(c, &L.slice_info, info)))
@@ -766,7 +766,7 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
             KN_HIP(hipMemcpy(dt.data(), A.data, sizeof(float) * dt.size(), hipMemcpyDeviceToHost));
         }
         int rc = chain_build_layer(c.get(), c->args.L[l], A.rows, A.cols, ip, ix, dt, (flags && (flags[l] & KN_FLAG_RELU)) ? 1 : 0,
-                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])));
+                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])), A.tune);
         if (rc) return rc;
     }
     c->args.n_layers = (int32_t)n_ops;

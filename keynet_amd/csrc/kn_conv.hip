@@ -1470,192 +1470,9 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     }
 }
 
-// ---- KN_FLAG_EXACT with the MULTIPLIES on the matrix pipe (round 4) ------------------------------------------------------------------
-// The order-preserving product of the factored operator, formulated like kn_csr_mfma.hip: v_mfma_f32_32x32x1_2b_f32 with a ZERO accumulator is
-// exactly the IEEE-rounded product (D[i][j] = fl(a_i * x_j): verified bit for bit against v_mul_f32, tools/micro/mfma_product.hip; a -0 product
-// comes back as +0, invisible in a sum that starts at +0.0), so per stored column -- (input channel ci, slot s) in the expansion's column order:
-// channel outer, the pixel's slots by ascending input pixel inner -- ONE matrix instruction forms the products of 32 output channels x 64 batch
-// columns and 16 v_pk_add_f32 add them to the running sums: separate rounding of product and sum, the reference's order, bit-exact.
-// Workgroup = one output pixel x NRB blocks of 32 output channels x 256 batch columns (wavefront w: columns 64w .. 64w+63); the A operand is
-// 128 contiguous bytes of tapsT[tap][ci][co0 + 32b ..] (lane & 31 = output channel), the B operand the wavefront's 256-byte piece of activation
-// row ci * HiWi + in(s) -- fetched once per 32 * NRB output channels (convtaps_exact_pipe_kernel: once per 16).  Operands run PF = 6 stored
-// columns ahead in a register ring (counted vmcnt); the walk over (slot, channel) stays on the scalar ALU, per-slot offsets live in lane s of
-// three VGPRs (v_readlane).  COEF: the reference's stored value is fl(coef * tap): one v_mul_f32 per A register.
-template <int NRB, bool COEF>
-__global__ __launch_bounds__(256, 2) void convtaps_exact_mfma_kernel(ConvArgs p, int n_cc) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef float f32x32 __attribute__((ext_vector_type(32)));
-    constexpr int PF = 6;
-    constexpr int LPS = NRB + 1;
-    const int64_t n_ct = (p.n_vecs + 255) / 256;
-    const int64_t n_items = n_ct * (int64_t)p.n_pix * n_cc;
-    const int64_t chunk = (n_items + 7) >> 3;
-    const int64_t item = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (item >= n_items || (blockIdx.x >> 3) >= chunk) return;
-    const int64_t per_ct = (int64_t)p.n_pix * n_cc;
-    const int64_t ct = item / per_ct;
-    const int64_t w = item - ct * per_ct;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[w / n_cc]);
-    const int co0 = __builtin_amdgcn_readfirstlane((int)(w % n_cc) * (32 * NRB));
-    const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
-    const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
-    const int64_t c0 = ct * 256 + (int64_t)wave * 64;
-    if (c0 >= p.n_vecs) return;
-    const int64_t c = c0 + lane;
-    const bool active = c < p.n_vecs;
-
-    f32x2 acc[NRB][16];
-#pragma unroll
-    for (int b = 0; b < NRB; b++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc[b][q] = f32x2{0.0f, 0.0f};
-
-    const int n_q = n_slots * p.Cin;
-    if (n_q > 0) {
-        int my_xoff = 0, my_aoff = 0;
-        float my_coef = 1.0f;
-        if (lane < n_slots) {
-            my_xoff = p.slot_in[s_beg + lane] * (int)p.ldx;
-            my_aoff = p.slot_tap[s_beg + lane] * (p.cin_pad * p.cout_pad);
-            if constexpr (COEF) my_coef = p.slot_coef[s_beg + lane];
-        }
-        const int ch_x = __builtin_amdgcn_readfirstlane(p.HiWi * (int)p.ldx);
-        const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);
-        const uint32_t a_off = 4u * (uint32_t)(lane & 31);
-        const float* a_base = p.tapsT + co0;
-        int s_f = 0, cix_f = 0, cia_f = 0, q_f = 0;              // fetch cursor (wave-uniform): slot inner, channel outer
-        float xa[PF][3], xb[PF], cfr[PF];
-#pragma unroll
-        for (int q = 0; q < PF; q++) {
-            xa[q][0] = xa[q][1] = xa[q][2] = xb[q] = 0.0f;
-            cfr[q] = 1.0f;
-        }
-        auto fetch = [&](float& rb, float& ra0, float& ra1, float& ra2, float& cf) {
-            const int xo = __builtin_amdgcn_readlane(my_xoff, s_f) + cix_f;
-            const int ao = __builtin_amdgcn_readlane(my_aoff, s_f) + cia_f;
-            if constexpr (COEF) cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_coef), s_f));
-            const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
-            const uint64_t aaddr = reinterpret_cast<uint64_t>(a_base + ao);
-            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(b_off), "s"(xaddr));
-            asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra0) : "v"(a_off), "s"(aaddr));
-            if (NRB > 1) asm volatile("global_load_dword %0, %1, %2 offset:128" : "=&v"(ra1) : "v"(a_off), "s"(aaddr));
-            if (NRB > 2) asm volatile("global_load_dword %0, %1, %2 offset:256" : "=&v"(ra2) : "v"(a_off), "s"(aaddr));
-            // advance the cursor; past the end the last column again (loaded to valid addresses, never used)
-            q_f++;
-            const bool more = q_f < n_q;
-            const bool wrap = (s_f + 1 == n_slots);
-            s_f = more ? (wrap ? 0 : s_f + 1) : s_f;
-            cix_f = __builtin_amdgcn_readfirstlane(cix_f + ((more && wrap) ? ch_x : 0));
-            cia_f = cia_f + ((more && wrap) ? p.cout_pad : 0);
-        };
-        auto landed = [&](float& rb, float& ra0, float& ra1, float& ra2) {
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rb), "+v"(ra0), "+v"(ra1), "+v"(ra2) : "n"(LPS * (PF - 1)));
-        };
-        fetch(xb[0], xa[0][0], xa[0][1], xa[0][2], cfr[0]);
-        fetch(xb[1], xa[1][0], xa[1][1], xa[1][2], cfr[1]);
-        fetch(xb[2], xa[2][0], xa[2][1], xa[2][2], cfr[2]);
-        fetch(xb[3], xa[3][0], xa[3][1], xa[3][2], cfr[3]);
-        fetch(xb[4], xa[4][0], xa[4][1], xa[4][2], cfr[4]);
-        fetch(xb[5], xa[5][0], xa[5][1], xa[5][2], cfr[5]);
-        f32x32 zero;
-#pragma unroll
-        for (int q = 0; q < 32; q++) zero[q] = 0.0f;
-        auto add_into = [&](f32x2 (&a)[16], const f32x32& d) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
-                asm("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
-            }
-        };
-        // two result blocks alternate: behind each matrix instruction the vector ALU adds the PREVIOUS one's block (zeros at the very first)
-        f32x32 d0 = zero, d1 = zero;
-        auto product = [&](auto T_, const float a, const float x, f32x2 (&pending_sum)[16]) {
-            constexpr int T = decltype(T_)::value;
-            if constexpr ((T & 1) == 0) {
-                d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                add_into(pending_sum, d1);
-            } else {
-                d1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                add_into(pending_sum, d0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto scaled = [&](const float a, const float cf) { return COEF ? a * cf : a; };          // the reference's stored value: fl(coef * tap)
-        auto step = [&](auto slot) {
-            constexpr int S = decltype(slot)::value;
-            landed(xb[S], xa[S][0], xa[S][1], xa[S][2]);
-            __builtin_amdgcn_sched_barrier(0);
-            product(std::integral_constant<int, S * NRB>(), scaled(xa[S][0], cfr[S]), xb[S], acc[NRB - 1]);
-            if constexpr (NRB > 1) product(std::integral_constant<int, S * NRB + 1>(), scaled(xa[S][1], cfr[S]), xb[S], acc[0]);
-            if constexpr (NRB > 2) product(std::integral_constant<int, S * NRB + 2>(), scaled(xa[S][2], cfr[S]), xb[S], acc[1]);
-            fetch(xb[S], xa[S][0], xa[S][1], xa[S][2], cfr[S]);
-        };
-        int j = 0;
-        for (; j + PF <= n_q; j += PF) {
-            step(std::integral_constant<int, 0>());
-            step(std::integral_constant<int, 1>());
-            step(std::integral_constant<int, 2>());
-            step(std::integral_constant<int, 3>());
-            step(std::integral_constant<int, 4>());
-            step(std::integral_constant<int, 5>());
-        }
-        add_into(acc[NRB - 1], d1);                              // the block still pending (zeros if the loop never ran)
-        asm volatile("s_waitcnt vmcnt(0)");
-#pragma unroll
-        for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q][0]), "+v"(xa[q][1]), "+v"(xa[q][2]));
-        auto tail = [&](auto slot) {                             // the last n_q % PF stored columns (already in the ring)
-            constexpr int S = decltype(slot)::value;
-#pragma unroll
-            for (int b = 0; b < NRB; b++) {
-                const f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(scaled(xa[S][b], cfr[S]), xb[S], zero, 0, 0, 0);
-                add_into(acc[b], d);
-            }
-        };
-        if (j < n_q) tail(std::integral_constant<int, 0>());
-        if (j + 1 < n_q) tail(std::integral_constant<int, 1>());
-        if (j + 2 < n_q) tail(std::integral_constant<int, 2>());
-        if (j + 3 < n_q) tail(std::integral_constant<int, 3>());
-        if (j + 4 < n_q) tail(std::integral_constant<int, 4>());
-    }
-    // epilogue: bias column last (separate multiply and add, skipped where the stored entry is absent: explicit zeros do not survive keying),
-    // ReLU, store.  D layout: register 16 * blk + r of lane l = (channel 8 * (r / 4) + 4 * (l / 32) + r % 4, column 32 * blk + l % 32).
-    const int half = lane >> 5;
-    const int64_t colo = c0 + (lane & 31);
-    float xl[2] = {0.0f, 0.0f};
-    if (p.lastcol) {
-#pragma unroll
-        for (int blk = 0; blk < 2; blk++)
-            if (colo + 32 * blk < p.n_vecs) xl[blk] = p.X[p.last_in_row * p.ldx + colo + 32 * blk];
-    }
-#pragma unroll
-    for (int b = 0; b < NRB; b++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int m = co0 + 32 * b + 8 * (r / 4) + 4 * half + (r % 4);
-            if (m < p.Cout) {
-                const int64_t row = (int64_t)m * p.HoWo + o;
-                const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
-#pragma unroll
-                for (int blk = 0; blk < 2; blk++) {
-                    const int64_t cc = colo + 32 * blk;
-                    if (cc < p.n_vecs) {
-                        float v = acc[b][(16 * blk + r) / 2][(16 * blk + r) % 2];
-                        if (lc != 0.0f) {
-                            const float bp = xl[blk] * lc;
-                            v = v + bp;
-                        }
-                        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-                        __builtin_nontemporal_store(v, p.Y + row * p.ldy + cc);
-                    }
-                }
-            }
-        }
-    }
-}
+// (KN_FLAG_EXACT with the multiplies on the matrix pipe -- convtaps_exact_mfma_kernel, round 4 -- was bit-exact but measured 4-8 % SLOWER than the pipeline
+// above on every keyed VGG-16 layer: the f32 matrix instruction runs on the vector ALU's own FP32 lanes, so the two do not overlap.  Removed in round 5;
+// profiles/HISTORY.md has the numbers.)
 
 // kn_convtaps_drop_zero_entries: the reference's UNTILED keyed conv CSR has no entry where a tap value is exactly 0, the order-preserving kernels
 // above add fl(0 * x) there -- the same bits while x is finite (+-0 added to a sum that is never -0), a NaN the reference does not have when it
@@ -1743,7 +1560,7 @@ static unsigned lds_pad_for_occupancy(size_t static_lds, int want) {
 }
 
 template <int MT, int NB, int KC, int WM, int WN>
-static void launch_conv(ConvArgs a, hipStream_t s) {
+static void launch_conv(ConvArgs a, const Tuning& tune, hipStream_t s) {
     const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
     const int64_t chunk = (items + 7) / 8;
     constexpr size_t static_lds = sizeof(float) * (2 * KC * MT + 2 * KC * NB + 4 * MAX_FAST_SLOTS + 2 * (MT + NB));
@@ -1751,8 +1568,8 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     // only a few rounds (VGG conv5_x: 196 items per XCD = 1.53 rounds of 128) a third of the work would fall into the last, partial
     // round.  Three workgroups per CU run as fast as four on the long layers (-1.5 %), and 196 items = 2.04 rounds of 96: when a
     // launch has fewer than four rounds, the resident set whose partial round is the smaller fraction wins (measured on conv5_x:
-    // 122.9 -> 125.4 TFLOP/s, same-process A/B).  KN_OCC forces a cap (A/B knob, read per call).
-    int occ_cap = getenv("KN_OCC") ? atoi(getenv("KN_OCC")) : 0;
+    // 122.9 -> 125.4 TFLOP/s, same-process A/B).  Tuning::occ forces a cap (diagnostic build).
+    int occ_cap = tune.occ;
     if (occ_cap == 0 && MT == 128 && NB == 128 && KC == 16) {
         const double r4 = (double)chunk / 128.0, r3 = (double)chunk / 96.0;
         const double f4 = r4 - (double)(int64_t)r4, f3 = r3 - (double)(int64_t)r3;
@@ -1767,16 +1584,15 @@ static void launch_conv(ConvArgs a, hipStream_t s) {
     };
     const bool fast = a.vec_ok && a.unit_coef && (a.Cin % KC == 0 || a.Cin < KC) && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&
                       a.max_slots <= MAX_FAST_SLOTS && (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
-    // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  KN_NO_SPTR = A/B
-    // switch (read per call).
+    // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  Tuning::no_sptr
+    // (KN_NO_SPTR=1 when the operator is created) keeps the other loaders for the parity tests' side-by-side.
     bool sptr = false;
     const bool fast_shape = a.vec_ok && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) && a.max_slots <= MAX_FAST_SLOTS &&
                             (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
-    if constexpr (KC == 16) sptr = fast_shape && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && getenv("KN_NO_SPTR") == nullptr;
+    if constexpr (KC == 16) sptr = fast_shape && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && !tune.no_sptr;
     a.tail_main = (int32_t)chunk;
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
-        static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
-        if ((fast || sptr) && a.wide_store && !no_tail) {
+        if ((fast || sptr) && a.wide_store && !tune.no_tail_split) {
             // resident workgroups per XCD of the instantiation that is actually launched (the two loader modes may differ in registers)
             static const int64_t slots_free_1 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
             static const int64_t slots_free_2 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>);
@@ -1913,7 +1729,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
 
     a.stamps = nullptr;
 #ifdef KN_ABLATION
-    a.abl = getenv("KN_ABL") ? atoi(getenv("KN_ABL")) : 0;
+    a.abl = A.tune.abl;
 #endif
     a.sk_desc = A.sk_desc;
     a.sk_stride = (int32_t)A.sk_stride;
@@ -1922,7 +1738,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     if (flags & KN_FLAG_EXACT) {
         const bool v4 = a.vec_ok && n_vecs >= 256;
         const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
-        static const int pipe_mode = getenv("KN_EXACT_PIPE") ? atoi(getenv("KN_EXACT_PIPE")) : 16;
+        const int pipe_mode = A.tune.exact_pipe;
         const bool pipe = pipe_mode > 0 && v4 && !A.has_dups && A.max_slots <= 64 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0 &&
                           (a.last_in_row + 1) * ldx < ((int64_t)1 << 31) && (int64_t)A.ntaps * A.cin_pad * A.cout_pad < ((int64_t)1 << 31);
         // 16 output channels per wavefront when that still leaves every SIMD several wavefronts, else 8
@@ -1934,47 +1750,29 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         // Same-process A/B, exact mode, ms at 1 / 4 / 8 groups: conv3_2 (2.4 MB of taps) 13.63 / 13.49 / 14.60, conv4_1 6.99 / 6.75 / 6.84,
         // conv4_2 14.05 / 13.54 / 13.48, conv4_3 14.01 / 13.34 / 13.53, conv5_1 4.26 / 3.82 / 3.82, conv5_2 4.24 / 3.84 / 4.10; layers with small tap
         // matrices lose 5 % (conv1_2, conv2_x: the bundles of a pixel no longer share its gathered rows in one XCD).  Rule: 4 groups when the taps exceed half
-        // of the L2 (2 MB: VGG-16 conv3_x and up; AllConvNet's 192-channel layers, 1.3 MB at 16 column tiles per layer, lose 10 % when grouped).  KN_EXACT_COB_GROUPS=g overrides (A/B knob, read per call).
+        // of the L2 (2 MB: VGG-16 conv3_x and up; AllConvNet's 192-channel layers, 1.3 MB at 16 column tiles per layer, lose 10 % when grouped).  Tuning::exact_cob_groups overrides (diagnostic build).
         a.tail_main = 0;
         {
             const int64_t tap_bytes = 4 * A.ntaps * A.cin_pad * A.cout_pad;
             int g = tap_bytes > (2 << 20) ? 4 : 1;
-            if (const char* e = getenv("KN_EXACT_COB_GROUPS")) g = atoi(e);
+            if (A.tune.exact_cob_groups > 0) g = A.tune.exact_cob_groups;
             while (g > 1 && n_cob % g != 0) g >>= 1;
             if (g > 1) a.tail_main = n_cob / g;
         }
         const int64_t grid = ((n_ct * n_rb + 7) / 8) * 8;
         // a factored stand-in of an untiled CSR that carries the stored-column table (kn_convtaps_drop_zero_entries) on a wide batch: the matrix-pipe
-        // grouped kernel reads its values from the tap table (kn_csr_mfma.hip, TAPS).  KN_NO_EXACT_TABLE=1 = A/B switch (read per call).
-        const bool table = A.ex_tab != nullptr && n_vecs >= 128 && getenv("KN_NO_EXACT_TABLE") == nullptr;
+        // grouped kernel reads its values from the tap table (kn_csr_mfma.hip, TAPS).  Tuning::no_exact_table keeps the conv pipeline instead.
+        const bool table = A.ex_tab != nullptr && n_vecs >= 128 && !A.tune.no_exact_table;
         if (table) {
             int rc = convtaps_exact_table_spmm(A, x, ldx, n_vecs, y, ldy, a.relu, s);
             if (rc) return rc;
         }
         // four activation rows in flight when the batch spans several 256-column tiles (the rows of a [D, 4096] block are L2 misses; at one tile --
-        // VGG-16 at 256 images -- three rows in flight measured 2-3 % slower than two).  KN_EXACT_XD=2|4 overrides (A/B knob, read per call).
+        // VGG-16 at 256 images -- three rows in flight measured 2-3 % slower than two).  Tuning::exact_xd = 2 | 4 overrides (diagnostic build).
         bool xd4 = n_ct >= 4;
-        if (const char* e = getenv("KN_EXACT_XD")) xd4 = atoi(e) == 4;
-        // products on the matrix pipe (convtaps_exact_mfma_kernel): whole 32-channel blocks, a batch of at least one wavefront's 64 columns.
-        // OPT-IN (KN_EXACT_MFMA=1, read per call; KN_EXACT_MFMA_NRB=1|2|3 picks the channel blocks per workgroup): bit-exact like the vector-ALU
-        // pipeline, but measured 4-8 % SLOWER than it on every keyed VGG-16 layer (round 4, same-process A/B: conv3_2 13.38 ms against 14.49; the
-        // f32 matrix instruction runs on the vector ALU's own FP32 lanes, so the two do not overlap, and the hand-scheduled pipeline already
-        // sits at 0.84-0.88 of the no-FMA roof with five wavefronts per SIMD against three here).
-        const bool mf = !table && pipe && A.Cout % 32 == 0 && n_vecs >= 64 && getenv("KN_EXACT_MFMA") != nullptr && getenv("KN_EXACT_MFMA")[0] == '1';
+        if (A.tune.exact_xd > 0) xd4 = A.tune.exact_xd == 4;
         if (table) {
             // (launched above)
-        } else if (mf) {
-            int nrb = (A.Cout % 64 == 0) ? 2 : 1;
-            if (const char* e = getenv("KN_EXACT_MFMA_NRB")) nrb = atoi(e);
-            if (nrb < 1 || nrb > 3 || A.Cout % (32 * nrb) != 0) nrb = 1;
-            const int n_cc = (int)(A.Cout / (32 * nrb));
-            const int64_t gridm = (((int64_t)((n_vecs + 255) / 256) * a.n_pix * n_cc + 7) / 8) * 8;
-            const std::string d = "convtaps_exact_mfma_kernel<row blocks=" + std::to_string(nrb) + (A.unit_coef ? "" : ",coef") + "> (products on the matrix pipe, K = 1, zero accumulator)";
-#define KN_EXM(N, C) KN_LAUNCH(d, (convtaps_exact_mfma_kernel<N, C>), dim3((unsigned)gridm), dim3(256), 0, s, a, n_cc)
-            if (nrb == 1) { if (A.unit_coef) KN_EXM(1, false); else KN_EXM(1, true); }
-            else if (nrb == 2) { if (A.unit_coef) KN_EXM(2, false); else KN_EXM(2, true); }
-            else { if (A.unit_coef) KN_EXM(3, false); else KN_EXM(3, true); }
-#undef KN_EXM
         } else
         if (pipe && rbx == 16 && A.unit_coef && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,rows in flight=4>", (convtaps_exact_pipe_kernel<16, false, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16 && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef,rows in flight=4>", (convtaps_exact_pipe_kernel<16, true, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
@@ -2023,8 +1821,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
             static const int64_t slots1 = xcd_slots(convtaps_bf16x3_kernel<128, 128, 2, 2, true, true>);
             const int64_t slots = A.unit_coef ? slots0 : slots1;
             const int64_t rem = slots > 0 ? chunk % slots : 0;
-            static const bool no_tail = getenv("KN_NO_TAIL_SPLIT") != nullptr;
-            if (rem > 0 && !no_tail) {
+            if (rem > 0 && !A.tune.no_tail_split) {
                 a.tail_main = (int32_t)(chunk - rem);
                 const int64_t grid = 8 * ((int64_t)a.tail_main + 4 * rem);
                 if (A.unit_coef) KN_LAUNCH(d + " tail_split", (convtaps_bf16x3_kernel<128, 128, 2, 2, false, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
@@ -2047,12 +1844,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     }
     const bool big_m = A.cout_pad % 128 == 0 && A.Cout > 64;
     const bool k16 = A.cin_pad % 16 == 0;
-    static const bool no_smallk = getenv("KN_NO_SMALLK") != nullptr;
-    if (!no_smallk && (int64_t)A.max_slots * A.Cin + (A.has_last ? 1 : 0) <= SMALLK_MAX && a.wide_store && n_vecs % 256 == 0 && A.cout_pad % 64 == 0) {
+    if (!A.tune.no_smallk && (int64_t)A.max_slots * A.Cin + (A.has_last ? 1 : 0) <= SMALLK_MAX && a.wide_store && n_vecs % 256 == 0 && A.cout_pad % 64 == 0) {
         a.n_mt = (int32_t)(A.cout_pad / 64);
         a.n_bt = (int32_t)(n_vecs / 256);
         const int64_t items = (int64_t)a.n_pix * a.n_bt * a.n_mt;
-        const bool no_pipe = getenv("KN_NO_SMALLK_PIPE") != nullptr;      // A/B switch (read per call)
+        const bool no_pipe = A.tune.no_smallk_pipe != 0;      // (the one-shot kernel, for the parity tests' side-by-side)
         if (a.sk_desc && a.n_mt == 1 && !no_pipe) {
             static const int64_t slots = xcd_slots(convtaps_smallk_pipe_kernel);
             const int64_t per_xcd = std::min<int64_t>(std::max<int64_t>(slots, 32), (items + 7) / 8);
@@ -2063,13 +1859,13 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     } else if (big_m) {
         a.n_mt = (int32_t)(A.cout_pad / 128);
         a.n_bt = (int32_t)((n_vecs + 127) / 128);
-        if (k16) launch_conv<128, 128, 16, 2, 2>(a, s);
-        else launch_conv<128, 128, 4, 2, 2>(a, s);
+        if (k16) launch_conv<128, 128, 16, 2, 2>(a, A.tune, s);
+        else launch_conv<128, 128, 4, 2, 2>(a, A.tune, s);
     } else {
         a.n_mt = (int32_t)(A.cout_pad / 64);
         a.n_bt = (int32_t)((n_vecs + 255) / 256);
-        if (k16) launch_conv<64, 256, 16, 1, 4>(a, s);
-        else launch_conv<64, 256, 4, 1, 4>(a, s);
+        if (k16) launch_conv<64, 256, 16, 1, 4>(a, A.tune, s);
+        else launch_conv<64, 256, 4, 1, 4>(a, A.tune, s);
     }
     if (A.has_last) {
         const int64_t out_last = A.Cout * A.Hout * A.Wout;

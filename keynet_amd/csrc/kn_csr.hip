@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void csr_big_group_kernel(int64_t n_big, const
 }
 
 void csr_free(CsrDev& c) {
-    void* ptrs[] = {c.indptr, c.indices, c.data, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
+    void* ptrs[] = {c.indptr, c.indices, c.data, c.data64, c.grp_colptr, c.grp_cols, c.grp_rowptr, c.grp_rows, c.grp_valptr, c.grp_vals,
                     c.work_grp, c.work_r0, c.loose_rows, c.big_grp, c.big_r0, c.long_rows, c.patch_rows, c.patch_ptr, c.patch_cols,
                     c.mf_grp[0], c.mf_grp[1], c.mf_grp[2], c.mf_r0[0], c.mf_r0[1], c.mf_r0[2], c.ws_grp, c.ws_r0, c.mf16_grp, c.mf16_r0};
     for (void* p : ptrs)
@@ -563,7 +563,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
     // columns where x at a missing position is NOT finite (0 * Inf would leak a NaN the reference's row does not have).
     constexpr int MAX_PATCH = 4;
     std::vector<std::vector<std::pair<int32_t, std::vector<int32_t>>>> patched(members.size());    // group -> (row, missing positions in the group's sequence)
-    if (!getenv("KN_NO_PATCH")) {
+    if (!A.tune.no_patch) {
         std::unordered_map<int32_t, std::vector<int32_t>> by_col;      // one of a group's first MAX_PATCH + 1 columns -> group
         for (size_t g = 0; g < members.size(); g++) {
             const int32_t s = indptr[rep[g]], e = indptr[rep[g] + 1];
@@ -644,7 +644,7 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             in_group[(size_t)r] = 1;
         }
         valptr.push_back((int64_t)vals.size());
-        if (n_mem >= 256 && ncol >= 2048 && !getenv("KN_NO_BIG_GROUPS")) {      // a keyed nn.Linear: LDS-staged kernel, 32 rows per workgroup
+        if (n_mem >= 256 && ncol >= 2048 && !A.tune.no_big_groups) {      // a keyed nn.Linear: LDS-staged kernel, 32 rows per workgroup
             for (int64_t r0 = 0; r0 < n_mem; r0 += BIG_ROWS) {
                 bgrp.push_back(gid);
                 br0.push_back((int32_t)r0);
@@ -661,8 +661,8 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
             if (n_mem >= MF_MIN_MEMBERS) {
                 // matrix-pipe kernel: chunks of ONE 32-row block (a last block may be partly filled): 125 registers, four wavefronts per SIMD -- the adds of a result
                 // block wait for its matrix instruction and only other wavefronts fill that wait.  AllConvNet kept in CSR form, whole forward, chunks of 3 / 2 / 1
-                // blocks (229 / 157 / 125 registers): 32.84 / 32.26 / 31.38 ms.  KN_MF_NRB = A/B knob, read when the operator is created.
-                const int nrb_max = getenv("KN_MF_NRB") ? std::max(1, std::min(3, atoi(getenv("KN_MF_NRB")))) : 1;
+                // blocks (229 / 157 / 125 registers): 32.84 / 32.26 / 31.38 ms.  Tuning::mf_nrb (KN_MF_NRB when the operator is created) picks another.
+                const int nrb_max = A.tune.mf_nrb;
                 for (int64_t r0 = 0; r0 < n_mem;) {
                     const int64_t left = n_mem - r0;
                     const int nrb = left >= 32 * nrb_max ? nrb_max : (int)((left + 31) / 32);
@@ -682,14 +682,14 @@ int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indic
         grouped_nnz += n_mem * ncol;
     }
     std::vector<int32_t> longrows;
-    const bool use_long = !getenv("KN_NO_BIG_GROUPS");
+    const bool use_long = !A.tune.no_big_groups;
     for (int64_t r = 0; r < rows; r++)
         if (!in_group[(size_t)r]) {
             if (use_long && indptr[r + 1] - indptr[r] >= 1024) longrows.push_back((int32_t)r);   // one wave would walk them latency-bound: deep-queue role
             else loose.push_back((int32_t)r);                     // includes empty rows (they must still be zeroed)
         }
     // loose rows of a big operator (keyed pooling: ~9 non-zeros per row, windows overlap): order them for L2 reuse of the gathers
-    if (loose.size() >= 4096 && !getenv("KN_NO_ROW_ORDER")) {
+    if (loose.size() >= 4096 && !A.tune.no_row_order) {
         int64_t lnnz = 0;
         for (int32_t r : loose) lnnz += indptr[r + 1] - indptr[r];
         if (lnnz <= 64 * (int64_t)loose.size()) loose = locality_order(loose, indptr, indices, h->cols, 64, 64);
@@ -1067,9 +1067,9 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
     // columns, when that gives every SIMD two wavefronts (>= 2048 of them).  Same-process A/B against the LDS-staged kernel below (ms, 4096 x 25088 at 512 /
     // 1024 / 2048 columns: 3.38 / 5.85 / 11.17 against 2.68 / 4.37 / 8.17; 4096 x 4096 at 512 / 1024: 0.59 / 1.02 against 0.49 / 0.77); with ONE wavefront per
     // SIMD (VGG-16 fc6 at 256 images: 1 024 chunks) it loses -- 2.16 against 1.74 ms, a lone wavefront pays ~9 cycles per instruction -- and the LDS-staged
-    // kernel stays.  KN_BIG_MFMA16=1 (force) / KN_NO_BIG_MFMA16=1 = A/B switches, read per call.
+    // kernel stays.  Tuning::big_mfma16 (KN_BIG_MFMA16=0|1 when the operator is created) forces either.
     bool big_done = false;
-    if (A.n_big > 0 && A.n_mf16 > 0 && n_vecs >= 64 && (getenv("KN_BIG_MFMA16") || A.n_mf16 * ((n_vecs + 63) / 64) >= 2048) && getenv("KN_NO_BIG_MFMA16") == nullptr) {
+    if (A.n_big > 0 && A.n_mf16 > 0 && n_vecs >= 64 && (A.tune.big_mfma16 < 0 ? A.n_mf16 * ((n_vecs + 63) / 64) >= 2048 : A.tune.big_mfma16 > 0)) {
         const int rc = csr_group_mfma16_spmm(A, x, ldx, n_vecs, y, ldy, relu, s);
         if (rc) return rc;
         big_done = true;
@@ -1090,12 +1090,12 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
     // take the same ALU time -- the f32 matrix instruction runs on the vector ALU's FP32 lanes -- so the long layers are within 0-2.5 % of each
     // other, and layers with short sequences (AllConvNet conv1: 28 columns, conv8: 193) are faster on the vector-ALU pipeline, whose five
     // wavefronts per SIMD hide the ring's start-up better: those stay there (mean stored columns per member row < 256).  The remaining small
-    // groups and the loose rows go through the kernels below.  KN_NO_GROUP_MFMA=1 / KN_GROUP_MFMA=1 (force) = A/B switches, read per call.
+    // groups and the loose rows go through the kernels below.  Tuning::group_mfma (KN_GROUP_MFMA=0|1 when the operator is created) forces either.
     {
         const int64_t n_mf = A.n_mf[0] + A.n_mf[1] + A.n_mf[2];
         const bool long_rows = A.mf_rows > 0 && A.mf_nnz >= 256 * A.mf_rows;
-        const bool want = getenv("KN_GROUP_MFMA") ? getenv("KN_GROUP_MFMA")[0] == '1' : long_rows;
-        if (want && n_mf > 0 && n_vecs >= 128 && n_mf * ((n_vecs + 255) / 256) * WAVES >= 2048 && getenv("KN_NO_GROUP_MFMA") == nullptr) {
+        const bool want = A.tune.group_mfma < 0 ? long_rows : A.tune.group_mfma > 0;
+        if (want && n_mf > 0 && n_vecs >= 128 && n_mf * ((n_vecs + 255) / 256) * WAVES >= 2048) {
             int rc = csr_group_mfma_spmm(A, x, ldx, n_vecs, y, ldy, relu, s);
             if (rc) return rc;
             if (A.n_ws == 0 && A.n_loose == 0) return KN_OK;
@@ -1124,8 +1124,8 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
 #define KN_TRY(V, R) \
     if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
     // wide case: the software-pipelined grouped kernel, 16 member rows per wavefront when the groups fill such bundles, else 8
-    // (KN_NO_GROUP_PIPE = A/B switch, read per call)
-    if (A.n_work > 0 && aligned(4) && A.cols * ldx < ((int64_t)1 << 31) && getenv("KN_NO_GROUP_PIPE") == nullptr) {
+    // (Tuning::no_group_pipe: the plain grouped kernel, for the parity tests' side-by-side)
+    if (A.n_work > 0 && aligned(4) && A.cols * ldx < ((int64_t)1 << 31) && !A.tune.no_group_pipe) {
         const int64_t grouped_rows = A.rows - A.n_loose - A.n_long - A.n_big * 32;           // upper bound (a big group's last bundle may be partial)
         if (waves(4, 16) >= ENOUGH && 10 * grouped_rows >= 7 * A.n_work * 16) return launch_csr_pipe<16>(A, x, ldx, n_vecs, y, ldy, relu, s);
         if (waves(4, 8) >= ENOUGH) return launch_csr_pipe<8>(A, x, ldx, n_vecs, y, ldy, relu, s);

@@ -9,8 +9,11 @@
 // results, overflow, Inf and NaN by tools/micro/mfma_product.hip -- the only difference is the SIGN OF A ZERO product, +0 from the matrix pipe
 // where v_mul_f32 gives -0, and a running sum that starts at +0.0 is never -0.0, so adding either zero leaves it unchanged bit for bit).
 // So the 32 x 64 products of one stored column -- 32 member rows of a pattern group x 64 batch columns -- come out of ONE matrix instruction
-// (64 cycles of the matrix pipe), and the vector ALU only adds them to the running sums, in stored order: 16 v_pk_add_f32 (64 cycles).  Both
-// pipes run side by side: 32 MACs per clock and SIMD instead of 16 -- the bit-exact contract at twice the old roof (78.6 T MAC/s).
+// (64 cycles of the matrix pipe), and the vector ALU only adds them to the running sums, in stored order: 16 v_pk_add_f32 (64 cycles).
+// MEASURED (tools/micro/mfma_add_rate.hip, profiles/r05_micro_*.txt): on gfx950 the f32 matrix instruction and the packed f32 adds do NOT
+// overlap -- the f32 MFMA runs on the vector ALU's own FP32 lanes -- so the pair costs 145-155 cycles per stored column and wavefront and the
+// no-FMA roof stays 39.3 T MAC/s.  What this formulation buys is traffic, not issue rate: an activation row is fetched once per 32-96 member
+// rows instead of once per 16, and (TAPS) the values come from the 0.3 MB tap table instead of per-row copies.
 //
 // Tile: a 256-thread workgroup owns NRB <= 3 row blocks (32 member rows each) of ONE pattern group x 256 batch columns; wavefront w owns
 // columns 64w .. 64w+63 for all NRB row blocks (96 x 64 running sums = 96 VGPRs).  Per stored column j a wavefront loads its activation
@@ -58,7 +61,7 @@ struct MfTaps {
 // (TAPS, measured and dropped: the four wavefronts of a workgroup on four pixels of a 2 x 2 block x the same 64 batch columns, so that the block's 16 input
 // pixels would be shared through the CU's vector cache -- HBM fetch of the AllConvNet forward 12.6 -> 19.5 GB and 2 % slower: the 256-byte row segments
 // cut the reuse between workgroups in L2 by more than the vector cache gives back.)
-template <int NRB, int PF, int NW = 4, bool TAPS = false, bool SB = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
+template <int NRB, int PF, int NW = 4, bool TAPS = false>       // NW wavefronts per workgroup = 64 * NW batch columns per gathered value block (NW = 8, one workgroup per CU, halves the value
                                             // re-reads but measured 8.5 % slower on the AllConvNet forward: 35.9 against 33.0 ms; not instantiated)
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kernel(int64_t n_work, const int32_t* __restrict__ work_grp, const int32_t* __restrict__ work_r0,
                                                                 const int32_t* __restrict__ grp_colptr, const int32_t* __restrict__ grp_cols,
@@ -177,25 +180,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
                 asm("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
             }
         };
+        auto add_into_c = [&](f32x2 (&a)[16], const f32x32& d) {              // the same sums with the dependency visible to the compiler (contraction is off: an add is an add)
+#pragma unroll
+            for (int q = 0; q < 16; q++) a[q] = a[q] + f32x2{d[2 * q], d[2 * q + 1]};
+        };
         // Products of one row block on the matrix pipe (zero accumulator: D = fl(a * x) exactly) into one of TWO result blocks, alternating;
         // behind each matrix instruction the vector ALU adds the PREVIOUS instruction's block to its running sums -- so a wavefront keeps both
-        // pipes busy by itself (a single result block would put ~18 idle issue slots between every matrix instruction and its adds).  The
+        // pipes busy by itself (a single result block would put ~18 idle issue slots between every matrix instruction and its adds; the
+        // one-result-block variant at five wavefronts per SIMD was measured -- 31.42 against 31.58 ms per AllConvNet forward but 16.2 -> 22.2 GB of HBM
+        // reads -- and removed).  The
         // block pending at the first instruction is all zeros: +0.0 added to sums that are still +0.0.
         f32x32 d0 = zero, d1 = zero;
         auto product = [&](auto T_, const float a, const float x, f32x2 (&pending_sum)[16]) {
             constexpr int T = decltype(T_)::value;
-            if constexpr (SB) {                                                  // ONE result block (NRB = 1): 32 registers fewer, the other wavefronts of the SIMD fill the wait
-                static_assert(!SB || NRB == 1, "single result block: one row block per workgroup");
+            // The adds are inline asm, which the compiler's hazard recognizer does not cover: a vector-ALU read of a matrix instruction's result
+            // needs passes + 2 = 18 wait states behind the 16-pass v_mfma_f32_32x32x1 (what LLVM inserts on gfx950: the tails below).  The reader of d0 sits behind
+            // [s_nop 1, 16 adds of d1, the next matrix instruction, s_nop 1] = 21; tests/test_isa_lint.py measures that distance in the ISA.
+            if constexpr ((T & 1) == 0) {
                 d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                add_into(acc[0], d0);
-            } else if constexpr ((T & 1) == 0) {
-                d0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1");
                 add_into(pending_sum, d1);
             } else {
                 d1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a, x, zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 1");
                 add_into(pending_sum, d0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -215,7 +224,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
         };
         int j = 0;
         for (; j + PF <= ncol; j += PF) mfma_static_for<0, PF>([&](auto S_) { step(S_, j + decltype(S_)::value); });
-        add_into(acc[NRB - 1], d1);                                             // the block still pending (PF * NRB is even: the last one written is d1; zeros if the loop never ran)
+        // the block still pending (PF * NRB is even: the last one written is d1; zeros if the loop never ran) -- through plain C++ adds: the compiler sees
+        // the dependency on the matrix instruction and spaces them itself (here and in the tail below nothing else fills the gap)
+        add_into_c(acc[NRB - 1], d1);
         // everything in flight lands (the ring holds the last ncol % PF stored columns and, behind them, harmless re-loads of the last column)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt), "+s"(cv_nxt));
 #pragma unroll
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void csr_group_mfma_kerne
 #pragma unroll
             for (int b = 0; b < NRB; b++) {
                 const f32x32 d = __builtin_amdgcn_mfma_f32_32x32x1f32(xa[S][b], xb[S], zero, 0, 0, 0);
-                add_into(acc[b], d);
+                add_into_c(acc[b], d);
             }
         };
         mfma_static_for<0, PF - 1>([&](auto S_) {
@@ -363,13 +374,17 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work
             fetch_col(j + PF + 1);
             landed(xb[S], xa[S]);
             __builtin_amdgcn_sched_barrier(0);
+            // (inline-asm adds: the 8-pass v_mfma_f32_16x16x1 needs 8 + 2 = 10 wait states before a vector-ALU read of its result; the reader of d0 sits
+            // behind [s_nop 2, 8 adds of d1, the next matrix instruction, s_nop 2] = 15; tests/test_isa_lint.py measures it)
             if constexpr ((S & 1) == 0) {
                 d0 = __builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 2");
                 add_into(d1);
             } else {
                 d1 = __builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 2");
                 add_into(d0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -377,13 +392,17 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work
         };
         int j = 0;
         for (; j + PF <= ncol; j += PF) mfma_static_for<0, PF>([&](auto S_) { step(S_, j + decltype(S_)::value); });
-        add_into(d1);                                       // the block still pending (PF is even: the last one written is d1; zeros if the loop never ran)
+        auto add_into_c = [&](const f32x16& d) {            // the same sums with the dependency visible to the compiler (it spaces them behind the matrix instruction itself)
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[q] = acc[q] + f32x2{d[2 * q], d[2 * q + 1]};
+        };
+        add_into_c(d1);                                     // the block still pending (PF is even: the last one written is d1; zeros if the loop never ran)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(col_nxt));
 #pragma unroll
         for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q]));
         mfma_static_for<0, PF - 1>([&](auto S_) {
             constexpr int S = decltype(S_)::value;
-            if (j + S < ncol) add_into(__builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0));
+            if (j + S < ncol) add_into_c(__builtin_amdgcn_mfma_f32_16x16x1f32(xa[S], xb[S], zero, 0, 0, 0));
         });
     }
     // D layout: register 4 * blk + r of lane l = element (row 4 * (l / 16) + r, column 16 * blk + l % 16)
@@ -408,19 +427,16 @@ __global__ __launch_bounds__(256, 2) void csr_group_mfma16_kernel(int64_t n_work
 }
 
 // The order-preserving product of a factored conv operator through the kernel above (convtaps_spmm, KN_FLAG_EXACT, operators that carry the table).
-static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
+static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, int force_nrb, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s) {
     // Row blocks (32 output channels each) per workgroup.  ONE (two result blocks alternating): 123 registers, four wavefronts per SIMD instead of two with three blocks (227 registers) -- the
     // matrix instruction and the packed adds behind it are dependent work of ONE wavefront, and the pair costs 145 cycles with four wavefronts interleaved
     // against 155 with two (tools/micro/mfma_add_rate.hip).  Same-process A/B on the AllConvNet forward (tools/ab_allconv.py): 33.9 -> 31.6 ms with the strided layers kept at three blocks, every
     // layer faster (conv2 10.23 -> 9.60, conv5 9.81 -> 8.97 ms), bit-equal.  The price is paid in L2: the activation rows of a pixel are now requested by
     // Cout / 32 workgroups instead of Cout / 96, and the siblings find each other's rows only while they stay within an XCD's 4 MB of each other: HBM reads
     // of the seven launches 13.1 -> 21.3 GB with one block everywhere.  Strided layers (neighbouring pixels share 3 of 9 input pixels instead of 6: conv3 +2.5 GB, conv6 +2.6 GB for
-    // 0.14 / 0.25 ms) keep three blocks: 16.2 GB.  KN_TABLE_NRB = A/B knob, read per call.
+    // 0.14 / 0.25 ms) keep three blocks: 16.2 GB.
     int nrb = strided ? (tp.Cout % 96 == 0 ? 3 : (tp.Cout % 64 == 0 ? 2 : 1)) : 1;
-    if (const char* e = getenv("KN_TABLE_NRB")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 3 && tp.Cout % (32 * v) == 0) nrb = v;
-    }
+    if (force_nrb >= 1 && force_nrb <= 3 && tp.Cout % (32 * force_nrb) == 0) nrb = force_nrb;      // Tuning::table_nrb (recorded at create)
     MfTaps t = tp;
     t.n_cc = tp.Cout / (32 * nrb);
     const int64_t n_work = n_pix * t.n_cc;
@@ -429,9 +445,6 @@ static int exact_table_launch(const MfTaps& tp, int64_t n_pix, bool strided, con
     const std::string d = "csr_group_mfma_kernel<row blocks=" + std::to_string(nrb) + ",taps> (factored operator: products on the matrix pipe from the tap table)";
     if (nrb == 3) KN_LAUNCH(d, (csr_group_mfma_kernel<3, 8, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     else if (nrb == 2) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
-    else if (getenv("KN_TABLE_1BLK") && atoi(getenv("KN_TABLE_1BLK")) == 1)      // A/B knob, read per call: ONE result block (91 registers, five wavefronts per SIMD): 31.42 against 31.58 ms per
-        // AllConvNet forward, but 320 instead of 256 workgroups share an XCD's L2: HBM reads of the seven launches 16.2 -> 22.2 GB (conv5 6.1 -> 9.0): not the default
-        KN_LAUNCH(d + " one result block", (csr_group_mfma_kernel<1, 6, 4, true, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     else KN_LAUNCH(d, (csr_group_mfma_kernel<1, 6, 4, true>), dim3((unsigned)grid), dim3(256), 0, s, n_work, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x, ldx, y, ldy, n_vecs, relu, t);
     KN_HIP(hipGetLastError());
     return KN_OK;
@@ -449,7 +462,7 @@ int convtaps_exact_table_spmm(const ConvTapsDev& A, const float* x, int64_t ldx,
     t.HoWo = (int32_t)(A.Hout * A.Wout);
     t.Cout = (int32_t)A.Cout;
     t.n_cc = 1;
-    return exact_table_launch(t, A.Hout * A.Wout, A.Hin * A.Win > A.Hout * A.Wout, x, ldx, n_vecs, y, ldy, relu, s);
+    return exact_table_launch(t, A.Hout * A.Wout, A.Hin * A.Win > A.Hout * A.Wout, A.tune.table_nrb, x, ldx, n_vecs, y, ldy, relu, s);
 }
 
 // work lists per NRB (CsrDev::mf_*): chunks of 32 * NRB member rows of the pattern groups with >= MF_MIN_MEMBERS members
@@ -465,7 +478,7 @@ int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_
         if (k == 1) KN_LAUNCH(d, (csr_group_mfma_kernel<2, 6>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr, A.grp_rows,
                               A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
         if (k == 2) {
-            static const int pf = getenv("KN_MF_PF") ? atoi(getenv("KN_MF_PF")) : 8;      // A/B knob (read once): operand columns in flight (AllConvNet forward, same box: 33.79 / 33.38 / 33.53 ms at 6 / 8 / 10)
+            const int pf = A.tune.mf_pf;      // operand columns in flight (diagnostic build: A/B knob) (AllConvNet forward, same box: 33.79 / 33.38 / 33.53 ms at 6 / 8 / 10)
             if (pf == 10) KN_LAUNCH(d + " pf=10", (csr_group_mfma_kernel<3, 10>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr,
                                     A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu);
             else if (pf == 8) KN_LAUNCH(d + " pf=8", (csr_group_mfma_kernel<3, 8>), dim3((unsigned)grid), dim3(256), 0, s, A.n_mf[k], A.mf_grp[k], A.mf_r0[k], A.grp_colptr, A.grp_cols, A.grp_rowptr,

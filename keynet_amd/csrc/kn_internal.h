@@ -121,15 +121,50 @@ PlanSink*& plan_sink();   // thread-local; null outside kn_spmm_plan
         }                                                                                                        \
     } while (0)
 
-enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2, KIND_CHAIN = 3 };
+// Options of an operator handle.  The environment is read ONCE, when a handle is created (tuning_from_env, kn_api.hip: the library's only
+// getenv), the values are recorded in the handle and kn_spmm_plan prints the ones that differ from the defaults: a handle is immutable after
+// create, kn_spmm's dispatch depends on the handle and the call's arguments only.  The first block are the switches the parity tests use to put
+// two formulations of one product side by side; the second block are measured tuning constants that only the diagnostic build (-DKN_ABLATION,
+// tools/ablate_conv.sh) reads from the environment -- in the product library they are the defaults below.
+struct Tuning {
+    int no_sptr = 0;          // KN_NO_SPTR=1         conv-taps matrix-core kernel: per-thread pointers / generic loader instead of wave-uniform pointers
+    int no_smallk_pipe = 0;   // KN_NO_SMALLK_PIPE=1  first-layer operators: the one-shot small-K kernel instead of the persistent pipeline
+    int no_group_pipe = 0;    // KN_NO_GROUP_PIPE=1   CSR pattern groups: the plain grouped kernel instead of the software-pipelined one
+    int no_big_groups = 0;    // KN_NO_BIG_GROUPS=1   a keyed Linear's rows as ordinary 16-row bundles instead of the LDS-staged workgroup kernel
+    int no_exact_table = 0;   // KN_NO_EXACT_TABLE=1  factored untiled conv under KN_FLAG_EXACT: the conv pipeline instead of the stored-column table kernel
+    int group_mfma = -1;      // KN_GROUP_MFMA=0|1    CSR pattern groups with their products on the matrix pipe: never / always (-1: the dispatch rule)
+    int big_mfma16 = -1;      // KN_BIG_MFMA16=0|1    a keyed Linear's 16-row chunks on the matrix pipe: never / always (-1: the dispatch rule)
+    int mf_nrb = 1;           // KN_MF_NRB=1|2|3      32-row blocks per chunk of the matrix-pipe grouped kernel
+    int table_nrb = 0;        // KN_TABLE_NRB=1|2|3   32-channel blocks per workgroup of the table kernel (0: the rule)
+    // ---- diagnostic build only ----
+    int occ = 0;              // KN_OCC               workgroups per CU cap of the 128 x 128 conv-taps launch (0: the rule)
+    int no_tail_split = 0;    // KN_NO_TAIL_SPLIT
+    int no_smallk = 0;        // KN_NO_SMALLK
+    int exact_pipe = 16;      // KN_EXACT_PIPE        0 = plain exact conv kernel, 8 / 16 = channels per wavefront of the pipeline
+    int exact_cob_groups = 0; // KN_EXACT_COB_GROUPS  (0: the rule)
+    int exact_xd = 0;         // KN_EXACT_XD          2 | 4 activation rows in flight (0: the rule)
+    int mf_pf = 8;            // KN_MF_PF             operand columns in flight of the matrix-pipe grouped kernel
+    int table_window = 0;     // KN_TABLE_WINDOW      (0: the rule)
+    int table_strip = -1;     // KN_TABLE_STRIP       (-1: best of the candidates, 0: keep the ball order)
+    int no_patch = 0;         // KN_NO_PATCH
+    int no_row_order = 0;     // KN_NO_ROW_ORDER
+    int chain_no_cl = 0;      // KN_CHAIN_NO_CL
+    int abl = 0;              // KN_ABL               kernel ablation mask (kn_conv.hip, KN_ABLATION code paths)
+    std::string describe() const;   // "" when everything is at its default, else " opts{name=value,...}"
+};
+Tuning tuning_from_env();
+
+enum Kind { KIND_CSR = 0, KIND_CONVTAPS = 1, KIND_DENSE = 2, KIND_CHAIN = 3, KIND_CSR64 = 4 };
 struct ChainDev;   // kn_chain.hip
 
 // Order-preserving CSR resident in HBM.
 struct CsrDev {
+    Tuning tune;                 // recorded at create
     int64_t rows = 0, cols = 0, nnz = 0;
     int32_t* indptr = nullptr;   // [rows+1]
     int32_t* indices = nullptr;  // [nnz]  stored order
     float* data = nullptr;       // [nnz]
+    double* data64 = nullptr;    // [nnz] values of a float64 operator (KIND_CSR64: kn_csr_create_f64); `data` and the group lists are unused then
     // pattern groups (rows sharing one column sequence, e.g. the Cout rows of one conv output pixel, or all rows of a
     // dense Linear): see kn_csr.hip.  Rows not in any group are listed in `loose_rows`.
     int64_t n_groups = 0;
@@ -178,6 +213,7 @@ struct CsrDev {
 
 // Factored conv operator  W = sum_e coef_e * taps[tap_e] (x) E[out_e,in_e] + lastcol + e_last.
 struct ConvTapsDev {
+    Tuning tune;                        // recorded at create
     int64_t Cin = 0, Hin = 0, Win = 0, Cout = 0, Hout = 0, Wout = 0;
     int64_t ntaps = 0;
     int64_t cin_pad = 0, cout_pad = 0;  // padded dims of tapsT
@@ -243,11 +279,6 @@ struct kn_operator {
         hipEvent_t done = nullptr;
     };
     std::vector<Retired> dense_ws_retired;
-    // split-K twin of a conv-taps operator whose launches have only a few tiles per CU (VGG conv5_x: 196 output pixels): every output pixel as
-    // split_S pseudo-pixels holding a share of its slots each; kn_spmm runs the twin into the per-stream workspace (dense_ws) and sums the shares
-    // in order + bias + ReLU (dense_reduce).  Matrix-core contract only (the summation order differs from the unsplit launch's by construction).
-    kn_operator* split_sub = nullptr;
-    int64_t split_S = 0;
     // a whole key-net of CSR operators as one launch (kn_chain.hip)
     kn::ChainDev* chain = nullptr;
 };
@@ -257,6 +288,8 @@ namespace kn {
 int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* absmax = nullptr,
              bool* absmax_fused = nullptr);
+template <typename TOUT>
+int csr_f64_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, TOUT* y, int64_t ldy, uint32_t flags, hipStream_t s);      // kn_csr_f64.hip
 int csr_group_mfma_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
 int csr_group_mfma16_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s);
 static constexpr int MF_MIN_MEMBERS = 24;   // a pattern group takes the matrix-pipe kernel when its members fill >= 3/4 of a 32-row block

@@ -5,7 +5,7 @@ Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_gold
     layer_names                      nn.Sequential order
     L.<name>.kind                    'relu' | 'csr' (+ optional fact_* arrays: the factored device form of an untiled conv) | 'tiled' | 'diagtiled' | 'conv2dtiled' | 'convtaps'
     L.<name>.layertype               str(type(module)) of the source layer ('ReLU' in it => keyed ReLU)
-    csr:          shape, indptr, indices, data           (STORED order)
+    csr:          shape, indptr, indices, data           (STORED order; data float32, or float64 for an operator the reference computes in float64)
     tiled:        shape, tileshape, blocks, tile_shapes, tile_ptr, tile_row, tile_col, tile_val
     conv2dtiled:  shape, inshape, outshape, tileshape, blocks, tile_keys, tile_isbias, tile_chan, tile_bias
     convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol [, tileshape]
@@ -44,7 +44,8 @@ def operator_from_arrays(z, p):
     shape = tuple(int(v) for v in z[p + 'shape'])
     if kind == 'csr':
         data = z[p + 'data']
-        M = scipy.sparse.csr_matrix((data.astype(np.float32) if data.dtype != np.float32 else data, z[p + 'indices'], z[p + 'indptr']), shape=shape)
+        # the values keep the dtype the reference computes in: a float64 operator (the public challenge key-net) stays float64
+        M = scipy.sparse.csr_matrix((data.astype(ksp._compute_dtype(data.dtype), copy=False), z[p + 'indices'], z[p + 'indptr']), shape=shape)
         if (p + 'fact_taps') in z.files:
             # saved from a FactoredSparseMatrix: the factored device form travels with the CSR and is PROVEN again against it on load (a file edited in
             # between simply loads as the plain CSR container)

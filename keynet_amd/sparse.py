@@ -26,12 +26,20 @@ def _stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _compute_dtype(dt):
+    """The dtype scipy's product of an operator of dtype `dt` with float32 activations runs and returns in (keynet/sparse.py:488-492:
+    `x_torch.type(torch.FloatTensor)` against `self._matrix` as it is; numpy up-casts the pair)."""
+    return np.dtype(np.float64) if np.result_type(dt, np.float32) == np.float64 else np.dtype(np.float32)
+
+
 def _stored_order_csr(M):
     """(indptr, indices, data) whose per-row order equals the accumulation order of scipy's matvec for M's format:
     CSR as stored (csr_matvecs); COO in entry order (coo_matmat_dense); CSC column-major (csc_matvecs).  Nothing is
-    sorted or summed -- keyed matrices are non-canonical and the order is part of the result."""
+    sorted or summed -- keyed matrices are non-canonical and the order is part of the result.  The values keep the dtype scipy
+    computes in against float32 activations (numpy's up-cast rule: float32 stays float32, float64 -- and integer types -- compute in float64)."""
+    vdt = _compute_dtype(M.dtype)
     if M.format == 'csr':
-        return (np.asarray(M.indptr, dtype=np.int32), np.asarray(M.indices, dtype=np.int32), np.asarray(M.data, dtype=np.float32))
+        return (np.asarray(M.indptr, dtype=np.int32), np.asarray(M.indices, dtype=np.int32), np.asarray(M.data, dtype=vdt))
     if M.format == 'csc':
         cols = np.repeat(np.arange(M.shape[1], dtype=np.int64), np.diff(M.indptr))
         (rows, vals) = (np.asarray(M.indices, dtype=np.int64), M.data)
@@ -41,7 +49,7 @@ def _stored_order_csr(M):
     order = np.argsort(rows, kind='stable')
     indptr = np.zeros(M.shape[0] + 1, dtype=np.int64)
     np.add.at(indptr, rows + 1, 1)
-    return (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), np.asarray(vals, dtype=np.float32)[order])
+    return (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), np.asarray(vals, dtype=vdt)[order])
 
 
 def _on_device(W, attr, make, device=None):
@@ -59,9 +67,10 @@ def _on_device(W, attr, make, device=None):
     return cache[idx]
 
 
-def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0, absmax=None):
+def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0, absmax=None, f64=False):
     """Y = W.X on the GPU.  x: torch tensor [cols, N] (any device / strides); get_op(device) -> the operator handle resident
-    on that device.  Returns [rows, N] on x's device."""
+    on that device.  Returns [rows, N] on x's device.  `f64`: the operator is float64 -- the result is the float64 block scipy returns for it
+    (kn_spmm_f64); the activations are float32 either way (keynet/sparse.py:489-491)."""
     assert shape[1] == x.shape[0], 'Non-conformal shape for W=%s, x=%s' % (str(shape), str(tuple(x.shape)))
     if not torch.cuda.is_available():
         raise _capi.KeynetHipError('keynet_amd: no MI355X visible -- the keyed forward has no CPU fallback')
@@ -74,10 +83,15 @@ def _run_torchdot(get_op, shape, x, relu=False, exact=True, extra_flags=0, absma
     if not xd.is_contiguous():
         xd = xd.contiguous()
     n = xd.shape[1]
-    y = torch.empty((shape[0], n), dtype=torch.float32, device=xd.device)
+    y = torch.empty((shape[0], n), dtype=torch.float64 if f64 else torch.float32, device=xd.device)
     flags = (_capi.KN_FLAG_RELU if relu else 0) | (_capi.KN_FLAG_EXACT if exact else 0) | int(extra_flags)
     with torch.cuda.device(xd.device):
-        get_op(xd.device).spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr(), absmax_ptr=None if absmax is None else absmax.data_ptr())
+        if f64:
+            get_op(xd.device).spmm_f64(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr())
+            if absmax is not None:               # (a float64 layer is never on a re-ordering kernel; the slot still feeds the NEXT layer's screen)
+                _capi.absmax(y.float().data_ptr(), shape[0], n, n, absmax.data_ptr(), _stream_ptr())
+        else:
+            get_op(xd.device).spmm(xd.data_ptr(), n, n, y.data_ptr(), n, flags, _stream_ptr(), absmax_ptr=None if absmax is None else absmax.data_ptr())
     return y if src_device.type == 'cuda' else y.to(src_device)
 
 
@@ -120,6 +134,12 @@ class SparseMatrix(object):
             return _capi.Operator.csr(self.shape, ip, ix, dt)
         return _on_device(self, '_op', make, device)
 
+    def is_float64(self):
+        """Does scipy compute this operator's product with float32 activations in float64 (a float64 -- or integer -- scipy matrix)?
+        Dense ndarray operators go through BLAS in the reference (no defined order) and stay float32 here."""
+        M = getattr(self, '_matrix', None)
+        return M is not None and is_scipy_sparse(M) and _compute_dtype(M.dtype) == np.float64
+
     DENSE_MIN_ELEMENTS = 1 << 20
 
     def _dense_device_op(self, device=None):
@@ -130,7 +150,7 @@ class SparseMatrix(object):
         def make():
             M = self._matrix
             (r, c) = self.shape
-            ok = (M is not None and r * c >= self.DENSE_MIN_ELEMENTS and (c - 1) % 256 == 0 and
+            ok = (M is not None and not self.is_float64() and r * c >= self.DENSE_MIN_ELEMENTS and (c - 1) % 256 == 0 and
                   (M.nnz if is_scipy_sparse(M) else M.size) >= 0.5 * r * c)
             if ok:
                 D = np.asarray(M.todense() if is_scipy_sparse(M) else M, dtype=np.float32)
@@ -146,6 +166,9 @@ class SparseMatrix(object):
         `absmax`: one-element device f32 tensor raised to max |W . x| (kn_spmm_screen)."""
         if exact == 'bf16x3':
             exact = False            # a dense operator has no bf16x3 path (yet): f32 matrix cores
+        if self.is_float64():
+            # a float64 operator computes in float64 and returns float64, as scipy does for it (the next layer's coercion rounds to f32 once)
+            return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True, absmax=absmax, f64=True)
         if not exact and torch.cuda.is_available() and self._dense_device_op(x_torch.device if x_torch.is_cuda else None) is not None:
             return _run_torchdot(self._dense_device_op, self.shape, x_torch, relu=relu, exact=False, absmax=absmax)
         return _run_torchdot(self._device_op, self.shape, x_torch, relu=relu, exact=True, absmax=absmax)
@@ -245,7 +268,7 @@ class FactoredSparseMatrix(SparseMatrix):
         """Is the stored CSR `M` (scipy) exactly -- indptr, indices AND values, in stored order -- the canonical expansion of `factored` with its
         zero-valued entries removed?  Also refuses operators with many exact zeros (a pruned filter): the device re-checks every such entry."""
         t = factored._taps
-        if t is None or M.format != 'csr' or tuple(M.shape) != tuple(factored.shape):
+        if t is None or M.format != 'csr' or tuple(M.shape) != tuple(factored.shape) or M.dtype != np.float32:
             return False
         taps = t['taps']
         live = taps[np.any(taps.reshape(taps.shape[0], -1) != 0, axis=1)]

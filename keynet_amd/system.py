@@ -259,7 +259,8 @@ class KeyedModel(object):
         ok = 0 < len(children)
         while ok and i < len(children):
             c = children[i]
-            if not isinstance(c, klayer.KeyedLayer) or getattr(c, '_exact', True) is not True or isinstance(c.W, ksp.Conv2dTiledMatrix) or not isinstance(c.W, ksp.SparseMatrix):
+            if (not isinstance(c, klayer.KeyedLayer) or getattr(c, '_exact', True) is not True or isinstance(c.W, ksp.Conv2dTiledMatrix) or not isinstance(c.W, ksp.SparseMatrix) or
+                    c.W.is_float64()):                  # (a float64 operator computes in float64: its own row kernel, one launch per layer)
                 ok = False
                 break
             fuse = (i + 1 < len(children)) and isinstance(children[i + 1], nn.ReLU)
@@ -317,7 +318,8 @@ class KeyedModel(object):
         half = batch // 2
         children = list(self._keynet.children())
         big = force or self._macs_per_image() * batch >= self.OVERLAP_MIN_MACS
-        if big and batch % 8 == 0 and half % 128 == 0 and all(isinstance(c, (klayer.KeyedLayer, nn.ReLU)) for c in children):
+        f64 = any(isinstance(c, klayer.KeyedLayer) and c.W.is_float64() for c in children)      # float64 operators return float64 blocks: layer by layer
+        if big and not f64 and batch % 8 == 0 and half % 128 == 0 and all(isinstance(c, (klayer.KeyedLayer, nn.ReLU)) for c in children):
             steps = []
             i = 0
             while i < len(children) and steps is not None:

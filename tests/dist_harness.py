@@ -79,7 +79,7 @@ def contract_worker(rank, world_size, port, mode, q):
     """Replicated key-nets whose calibration decisions differ between ranks (each rank calibrates on ITS batches) must end up running the
     same kernels: KeyedModel.sync_contract (one all-reduce: the most conservative decision per layer wins).
     mode 'host' (CPU box): the decisions are planted, no forward runs.  mode 'device' (two ranks sharing cuda:0, real kernels): a float-key
-    mini-net under the 'auto' contract; rank 1's images are 300x larger than rank 0's, so only ITS data can trip a layer's tolerance screen."""
+    mini-net under the 'auto' contract; the LAST rank's images are 300x larger than the others', so only ITS data can trip a layer's tolerance screen."""
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world_size)
@@ -111,16 +111,17 @@ def contract_worker(rank, world_size, port, mode, q):
             (sensor, knet) = ksys.TiledOrthogonalKeynet((2, 16, 16), net, 4)
         dev = torch.device('cuda:0')
         g = torch.Generator(device=dev).manual_seed(3)
-        x = torch.randn((16, 2, 16, 16), generator=g, device=dev)
-        x[8:] *= 300.0                                          # rank 1's half
+        n = 8 * world_size
+        x = torch.randn((n, 2, 16, 16), generator=g, device=dev)
+        x[kdist.shard_bounds(n, world_size - 1, world_size)[0]:] *= 300.0      # the LAST rank's shard
         xc = sensor.fromtensor(x).encrypt().astensor()
         y = kdist.sharded_forward(knet, xc)                     # local forward (calibrates on this rank's shard) + sync_contract + all-gather
-        state = {n: c._exact for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)}
-        (lo, hi) = kdist.shard_bounds(16, rank, world_size)
+        state = {n_: c._exact for (n_, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer)}
+        (lo, hi) = kdist.shard_bounds(n, rank, world_size)
         mine = knet.forward_linear(xc[lo:hi])[:, :-1]           # this rank's shard again, under the agreed contracts
         own = bool(torch.equal(y[lo:hi], mine))
-        # the peer's shard recomputed here (what bench.py's collective record does on rank 0): replicas are bit-identical
-        (plo, phi) = kdist.shard_bounds(16, 1 - rank, world_size)
+        # a peer's shard recomputed here (what bench.py's collective record does on rank 0): replicas are bit-identical
+        (plo, phi) = kdist.shard_bounds(n, (rank + 1) % world_size, world_size)
         peer = bool(torch.equal(y[plo:phi], knet.forward_linear(xc[plo:phi])[:, :-1]))
         q.put((rank, state, own, peer, knet.contract_report()['switched']))
     finally:

@@ -28,6 +28,7 @@ def main():
     rng = np.random.RandomState(0)
     Wc = ks.sparse_toeplitz_conv2d((2, 8, 8), rng.rand(3, 2, 3, 3).astype(np.float32), bias=rng.rand(3).astype(np.float32))
     objs = [ks.SparseMatrix(scipy.sparse.random(5, 7, 0.5, format='csr', dtype=np.float32, random_state=1)),
+            ks.SparseMatrix(scipy.sparse.random(5, 7, 0.5, format='csr', dtype=np.float64, random_state=3)),       # a float64 operator: kn_csr_create_f64
             ks.TiledMatrix(scipy.sparse.random(8, 8, 0.5, format='coo', dtype=np.float32, random_state=2), (4, 4)),
             ks.DiagonalTiledMatrix(rng.rand(3, 3).astype(np.float32), (10, 10)),
             ks.Conv2dTiledMatrix(Wc, (2, 8, 8), (3, 8, 8), (4, 4), bias=True)]

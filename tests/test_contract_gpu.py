@@ -13,7 +13,7 @@ from keynet_amd import io as kio
 from keynet_amd import sparse as ksp
 from keynet_amd import system as ksys
 from keynet_amd import _capi
-from keynet_amd.layer import KeyedLayer, FLOAT_KEY_TOL
+from keynet_amd.layer import KeyedLayer, FLOAT_KEY_TOL, gate
 from nets import MiniNet, load_weights
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,7 @@ def gain_keynet(golden, **kw):
 
 def layerwise_within_tolerance(knet, xc):
     """Every keyed layer's shipped output (on the layer input the shipped forward produces) against the order-preserving kernel -- which is
-    bit-exact with the reference's arithmetic (test_parity_gpu.py) -- on that same input: max over layers of diff / (1e-5 max(1, |y|))."""
+    bit-exact with the reference's arithmetic (test_parity_gpu.py) -- on that same input: max over layers and ELEMENTS of diff / (1e-5 + 1e-5 |y|)."""
     children = list(knet._keynet.named_children())
     y = xc
     worst = 0.0
@@ -51,8 +51,7 @@ def layerwise_within_tolerance(knet, xc):
             fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
             out = c.forward(y, fuse_relu=fuse)
             ref = c.W.torchdot(y.t(), relu=(fuse or c.iskeyedrelu()), exact=True).t()
-            (d, m) = (float((out - ref).abs().max()), float(ref.abs().max()))
-            worst = max(worst, d / (FLOAT_KEY_TOL * max(1.0, m)))
+            worst = max(worst, gate(out, ref)[0])                     # element-wise |d| / (1e-5 + 1e-5 |ref|): <= 1 is np.allclose(atol=1e-5)
             y = out
             i += 2 if fuse else 1
         else:

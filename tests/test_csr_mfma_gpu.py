@@ -1,6 +1,7 @@
 """The matrix-pipe grouped kernel (csrc/kn_csr_mfma.hip: products by v_mfma_f32_32x32x1_2b_f32 with a ZERO accumulator = the IEEE-rounded
 f32 product; running sums by v_pk_add_f32 in stored order) against the CPU oracle (scipy csr_matvecs restated), bit for bit, and against
-the vector-ALU kernels it replaces (KN_NO_GROUP_MFMA=1)."""
+the vector-ALU kernels it replaces (KN_GROUP_MFMA=0).  The KN_* options are read when an operator is CREATED and recorded in its handle
+(kn_spmm_plan prints them): each formulation gets its own handle."""
 import os
 
 import numpy as np
@@ -57,14 +58,13 @@ def test_matrix_pipe_grouped_kernel_vs_oracle(members, n_vecs, nrb, monkeypatch)
     for relu in (False, True):
         y = W.torchdot(xd, relu=relu).cpu().numpy()
         assert np.array_equal(y, np.maximum(ref, 0) if relu else ref), (members, n_vecs, relu, int(np.sum(y != (np.maximum(ref, 0) if relu else ref))))
-    os.environ['KN_NO_GROUP_MFMA'] = '1'
-    try:
-        with torch.cuda.device(dev()):
-            assert 'csr_group_mfma_kernel' not in W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
-        y2 = W.torchdot(xd).cpu().numpy()
-    finally:
-        del os.environ['KN_NO_GROUP_MFMA']
-    assert np.array_equal(y2, ref)
+    monkeypatch.setenv('KN_GROUP_MFMA', '0')                 # a second handle of the same operator, created with the vector-ALU kernels forced
+    W0 = ksp.SparseMatrix(W._matrix)
+    with torch.cuda.device(dev()):
+        plan0 = W0._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'csr_group_mfma_kernel' not in plan0 and 'group_mfma=0' in plan0, plan0
+    assert 'group_mfma=1' in plan                            # the options a handle was created with are part of its plan
+    assert np.array_equal(W0.torchdot(xd).cpu().numpy(), ref)
 
 
 def test_matrix_pipe_products_on_special_values(monkeypatch):
@@ -168,7 +168,7 @@ def test_default_dispatch_rule():
 def test_big_group_16_row_matrix_pipe_kernel_vs_oracle(rows, cols, n_vecs, forced, monkeypatch):
     """A keyed nn.Linear in the reference's order (ONE pattern group: >= 256 member rows x >= 2048 stored columns, here in a scrambled stored order with
     duplicate columns): csr_group_mfma16_kernel (v_mfma_f32_16x16x1_4b_f32 with a zero accumulator + packed adds) against the oracle and against the
-    LDS-staged big-group kernel (KN_NO_BIG_MFMA16=1), bit for bit; partly filled last 16-row chunk, ragged batches, loose rows beside the group, ReLU on
+    LDS-staged big-group kernel (KN_BIG_MFMA16=0 at create), bit for bit; partly filled last 16-row chunk, ragged batches, loose rows beside the group, ReLU on
     and off.  By default it is taken when its 16-row x 64-column wavefronts number >= 2048 (last case); the small cases force it."""
     if forced:
         monkeypatch.setenv('KN_BIG_MFMA16', '1')
@@ -191,13 +191,14 @@ def test_big_group_16_row_matrix_pipe_kernel_vs_oracle(rows, cols, n_vecs, force
         r = np.maximum(ref, 0) if relu else ref
         y = W.torchdot(xd, relu=relu).cpu().numpy()
         assert np.array_equal(y, r), (rows, cols, n_vecs, relu, int(np.sum(y != r)))
-    monkeypatch.delenv('KN_BIG_MFMA16', raising=False)
-    monkeypatch.setenv('KN_NO_BIG_MFMA16', '1')
+    monkeypatch.setenv('KN_BIG_MFMA16', '0')                 # a second handle with the LDS-staged kernel forced
+    W0 = ksp.SparseMatrix(W._matrix)
     with torch.cuda.device(dev()):
-        plan0 = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        plan0 = W0._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
     assert 'csr_group_mfma16_kernel' not in plan0 and 'csr_big_group_kernel' in plan0, plan0
-    assert np.array_equal(W.torchdot(xd, relu=False).cpu().numpy(), ref)
+    assert np.array_equal(W0.torchdot(xd, relu=False).cpu().numpy(), ref)
     # few wavefronts (one per SIMD or less): the LDS-staged kernel by default
-    monkeypatch.delenv('KN_NO_BIG_MFMA16')
+    monkeypatch.delenv('KN_BIG_MFMA16')
+    W1 = ksp.SparseMatrix(W._matrix)
     with torch.cuda.device(dev()):
-        assert 'csr_group_mfma16_kernel' not in W._device_op(dev()).plan(128, _capi.KN_FLAG_EXACT)
+        assert 'csr_group_mfma16_kernel' not in W1._device_op(dev()).plan(128, _capi.KN_FLAG_EXACT)

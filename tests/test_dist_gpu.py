@@ -36,6 +36,54 @@ def test_one_ranks_data_trips_the_contract_for_all():
     assert own0 and own1 and peer0 and peer1, res
 
 
+@pytest.mark.parametrize('kind', ['lenet', 'tiled'])
+def test_real_keynet_sharded_over_eight_ranks_ragged(kind):
+    """BASELINE configs[4] is an 8-rank job: the first 8-GPU run must not be the first 8-rank run.  Eight processes share cuda:0 (gloo), a
+    ragged total of 250 images (shards of 32 and 31), the real key-nets: every rank's gathered block equals the single-process forward
+    of the whole batch bit for bit, the shard bounds tile [0, 250) in rank order, one collective per forward."""
+    n = 250
+    res = dist_harness.run(kind, n, world_size=8, timeout=600)
+    assert [r[0] for r in res] == list(range(8)) and all(r[1] for r in res), res
+    bounds = [r[2] for r in res]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[k][1] == bounds[k + 1][0] for k in range(7))
+    assert sorted(set(hi - lo for (lo, hi) in bounds)) == [31, 32]
+    assert all(r[3][0] == n and r[4].startswith('cuda') and r[5] == 'gloo' for r in res)
+    assert all(len(r[6]) == 1 for r in res), [r[6] for r in res]          # ONE all_gather_into_tensor per sharded forward, nothing else on the data path
+
+
+def test_one_ranks_data_trips_the_contract_for_all_eight():
+    """The 'auto' contract on eight ranks: only the last rank's images (300x larger) can trip a tolerance screen; after sharded_forward ALL
+    eight run every layer under the same contract, own and peer shards are bit-equal on recompute."""
+    res = dist_harness.run_contract('device', world_size=8, timeout=600)
+    states = [r[1] for r in res]
+    assert all(st == states[0] for st in states), states
+    assert all(v in (True, False) for v in states[0].values())
+    assert all(r[2] and r[3] for r in res), res
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """`python bench.py --gpus 8` as the driver's multi-GPU tier starts it (its own ranks through torch.distributed.run), on a shared GPU with
+    gloo: the control flow of cfg5 -- 8 keyings, 8 uploads, the 8-way gather, max-over-ranks timing, the 8-rank compact line -- on a real box."""
+    import time
+    env = dict(os.environ, KN_BENCH_SHARE_GPU='1')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', 'lenet', '--steps', '3', '--warmup', '1', '--layer-iters', '1'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) < 4096, (len(lines), [len(l) for l in lines])
+    r = json.loads(lines[0])
+    c = r['collective']
+    assert r['n_gpus'] == 8 and r['config']['global_batch'] == 8 * r['config']['images_per_gpu'] and r['value'] > 0 and r['parity']['ok']
+    assert c['ranks_seen'] == 8 and sorted(x[0] for x in c['ranks']) == list(range(8))
+    assert c['every_rank_shard_bit_equal_to_its_local_forward'] is True and c['peer_shard_recomputed_on_rank0'] == {'peer_rank': 7, 'bit_equal': True}
+    assert r['scaling'] == 'weak' and 'N=1' in json.dumps(r.get('cpu_baseline'))
+    assert wall < 120, wall
+
+
 def test_bench_starts_its_own_ranks():
     env = dict(os.environ, KN_BENCH_SHARE_GPU='1')
     env.pop('WORLD_SIZE', None)

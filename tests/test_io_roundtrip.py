@@ -103,6 +103,26 @@ def test_reloaded_keynet_computes_identical_logits(golden, tmp_path, direct, exa
         assert np.abs(y2.cpu().numpy()[:, :-1] - z['logits_keyed']).max() <= 1e-5
 
 
+def test_float64_operators_keep_their_dtype(golden, tmp_path):
+    """The public challenge key-net (float64 conv / pool operators, float32 fc): loaded, saved and re-loaded, every operator keeps the dtype
+    the reference computes it in; integer matrices count as float64 (numpy's up-cast against float32 activations)."""
+    z = golden('challenge_kat.npz')
+    knet = kio.keynet_from_arrays(z)
+    want = {n: z['L.%s.data' % n].dtype for n in [str(v) for v in z['layer_names']] if ('L.%s.data' % n) in z.files}
+    assert sorted(str(d) for d in set(want.values())) == ['float32', 'float64']
+    f = kio.save_keynet(knet, str(tmp_path / 'challenge_again.npz'))
+    k2 = kio.load_keynet(f)
+    for (name, c) in k2._keynet.named_children():
+        if isinstance(c, KeyedLayer):
+            assert c.W._matrix.dtype == want[name] and c.W.is_float64() == (want[name] == np.float64), name
+            assert np.array_equal(c.W._matrix.data, z['L.%s.data' % name]), name
+            (ip, ix, dt) = ksp._stored_order_csr(c.W._matrix)
+            assert dt.dtype == want[name]
+    assert ksp.SparseMatrix(scipy.sparse.eye(3, dtype=np.int64).tocsr()).is_float64()
+    assert not ksp.SparseMatrix(scipy.sparse.eye(3, dtype=np.float32).tocsr()).is_float64()
+    assert not ksp.SparseMatrix(np.eye(3)).is_float64()            # dense ndarray operators: BLAS in the reference, float32 here
+
+
 @pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='the reference is only mounted in the build container')
 def test_import_reference_pickle(golden, tmp_path):
     """tests/golden/import_pickle.py on the pickle the reference ships (demo/keynet_challenge_lenet_10AUG20.pkl): the converted
@@ -117,6 +137,6 @@ def test_import_reference_pickle(golden, tmp_path):
         for k in ('kind', 'indptr', 'indices', 'data', 'shape'):
             key = 'L.%s.%s' % (n, k)
             if key in ref.files:
-                assert np.array_equal(z[key], ref[key]), key
+                assert np.array_equal(z[key], ref[key]) and z[key].dtype == ref[key].dtype, key     # (float64 conv / pool values stay float64)
     knet = kio.load_keynet(out)
     assert knet.num_parameters() > 0 and len(list(knet._keynet.children())) == len(z['layer_names'])

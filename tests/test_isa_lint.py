@@ -80,3 +80,122 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
                     assert not (_regs(srcs, 'v') & dests), (name, l)
             checked += 1
     assert checked >= len(PIPELINED[src])
+
+
+# ---- the bit-exact contract in the ISA -----------------------------------------------------------------------------------------------------
+# The order-preserving kernels must round every product and every sum separately (scipy's csr_matvecs: `y += a * x` compiled without
+# contraction; oracle/kn_oracle.c).  That hangs on -ffp-contract=off + `#pragma clang fp contract(off)`: one flag regression would pass every
+# CPU test and fail on the GPU box only.  So: no fused multiply-add of any kind in those kernels.  The one exception is the compiler's 64-bit
+# INTEGER division idiom (index arithmetic: item / n_work), which refines a reciprocal with v_fmac / v_fmamk against the literals +-2^32.
+FUSED = re.compile(r'^(v_fma\w*|v_fmac\w*|v_fmamk\w*|v_fmaak\w*|v_pk_fma\w*|v_mac\w*|v_mad_f\w*|v_mad_mix\w*|v_fma_mix\w*|v_dot\w*|v_pk_mad\w*)\b')
+INT_DIVISION_LITERALS = ('0x4f800000', '0xcf800000')
+ORDER_PRESERVING = {
+    'kn_csr.hip': [r'_ZN2kn'],                                  # every kernel of the file
+    'kn_csr_f64.hip': [r'_ZN2kn'],
+    'kn_csr_mfma.hip': [r'_ZN2kn'],
+    'kn_chain.hip': [r'_ZN2kn12chain_kernel'],
+    'kn_conv.hip': [r'_ZN2kn21convtaps_exact_kernel', r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn26convtaps_zero_guard_kernel', r'_ZN2kn19conv_lastrow_kernel'],
+}
+
+
+def _kernel_bodies(s, patterns):
+    out = []
+    for pat in patterns:
+        for name in re.findall(r'^(%s[^\n:]*):' % pat, s, re.M):
+            body = s[s.index(name + ':'):]
+            body = body[:body.index('.Lfunc_end')]
+            out.append((name, [l.split(';')[0].strip() for l in body.split('\n')[1:] if l.split(';')[0].strip()]))
+    return out
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+@pytest.mark.parametrize('src', sorted(ORDER_PRESERVING))
+def test_order_preserving_kernels_contain_no_fused_multiply_add(src, tmp_path):
+    s = _isa(src, tmp_path)
+    kernels = _kernel_bodies(s, ORDER_PRESERVING[src])
+    assert kernels, src
+    (n_mul, n_add) = (0, 0)
+    for (name, lines) in kernels:
+        for l in lines:
+            if FUSED.match(l):
+                assert any(c in l for c in INT_DIVISION_LITERALS), 'fused multiply-add in an order-preserving kernel: %s: %s' % (name, l)
+            n_mul += bool(re.match(r'v_(pk_)?mul_f(32|64)\b', l)) or l.startswith('v_mfma_f32_32x32x1') or l.startswith('v_mfma_f32_16x16x1')
+            n_add += bool(re.match(r'v_(pk_)?add_f(32|64)\b', l))
+    assert n_mul > 0 and n_add > 0, (src, n_mul, n_add)          # (the check looked at real arithmetic: separate multiplies and adds are there)
+
+
+def test_the_fused_multiply_add_lint_catches_a_contracted_build(tmp_path):
+    """The same source compiled WITHOUT the pragma / flag contracts a * x + y: the lint above must see it (i.e. it is not vacuous)."""
+    if shutil.which('hipcc') is None:
+        pytest.skip('needs hipcc')
+    src = os.path.join(str(tmp_path), 'contracted.hip')
+    open(src, 'w').write('#include <hip/hip_runtime.h>\nnamespace kn { __global__ void probe(const float* a, const float* x, float* y) {'
+                         ' const int i = threadIdx.x; const float p = a[i] * x[i]; y[i] = y[i] + p; } }\n')
+    out = os.path.join(str(tmp_path), 'contracted.s')
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=fast', '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+    lines = [l.split(';')[0].strip() for l in open(out).read().split('\n')]
+    assert any(FUSED.match(l) and not any(c in l for c in INT_DIVISION_LITERALS) for l in lines)
+    subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+    lines = [l.split(';')[0].strip() for l in open(out).read().split('\n')]
+    assert not any(FUSED.match(l) for l in lines)
+
+
+# A vector-ALU read of a matrix instruction's result needs passes + 2 wait states behind it (what LLVM's hazard recognizer inserts on gfx950: 18 for
+# the 16-pass v_mfma_f32_32x32x1 -- `s_nop 15; s_nop 1` in the compiler-managed tails of these very kernels -- and 10 for the 8-pass
+# v_mfma_f32_16x16x1; the last assertion below pins those two figures to the compiler's own output).  The compiler inserts them for its own instructions but NOT for inline asm,
+# and the running sums of kn_csr_mfma.hip are inline-asm v_pk_add_f32: their distance is held by construction (two result blocks alternate, one
+# s_nop behind every matrix instruction) and measured here, along every control-flow path, for every instruction that touches the result.
+MFMA_WAIT = {'v_mfma_f32_32x32x1': 18, 'v_mfma_f32_16x16x1': 10}
+
+
+def _wait_states(l):
+    m = re.match(r's_nop (\d+)', l)
+    return int(m.group(1)) + 1 if m else 1
+
+
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+def test_matrix_instruction_results_are_read_after_the_required_wait_states(tmp_path):
+    s = _isa('kn_csr_mfma.hip', tmp_path)
+    checked = 0
+    worst = {}
+    for (name, lines) in _kernel_bodies(s, [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel']):
+        labels = {l[:-1]: i for (i, l) in enumerate(lines) if l.endswith(':')}
+
+        def first_touch(i, regs, need, seen):
+            """min wait states from instruction i (exclusive of the producer) to the first instruction touching `regs`, over all paths; None = none within reach"""
+            best = None
+            w = 0
+            while i < len(lines) and w < need + 8:
+                l = lines[i]
+                if l.endswith(':'):
+                    i += 1
+                    continue
+                if l.startswith('s_endpgm'):
+                    break
+                ops = l.split(None, 1)[1] if ' ' in l else ''
+                if (_regs(ops, 'v') & regs) and not l.startswith('s_'):
+                    return w if best is None else min(best, w)
+                w += _wait_states(l)
+                m = re.match(r's_(c?branch\w*)\s+(\S+)', l)
+                if m and m.group(2) in labels and (m.group(2), w) not in seen and len(seen) < 64:
+                    seen.add((m.group(2), w))
+                    t = first_touch(labels[m.group(2)], regs, need - w, seen)
+                    if t is not None:
+                        best = w + t if best is None else min(best, w + t)
+                    if m.group(1) == 'branch':
+                        return best
+                i += 1
+            return best
+
+        for (i, l) in enumerate(lines):
+            for (op, need) in MFMA_WAIT.items():
+                if l.startswith(op):
+                    dest = _regs(l.split(None, 1)[1].split(',')[0], 'v')
+                    if not dest:
+                        continue                          # (an AGPR destination is read back by the compiler's own v_accvgpr_read, which it spaces itself)
+                    d = first_touch(i + 1, dest, need, set())
+                    if d is not None:
+                        assert d >= need, '%s: result of `%s` is touched after %d wait states, %d required' % (name, l, d, need)
+                        worst[op] = min(worst.get(op, 1 << 30), d)
+                    checked += 1
+    assert checked >= 100 and worst == MFMA_WAIT, (checked, worst)      # (the closest reader anywhere is a compiler-spaced one, at exactly the compiler's figure)

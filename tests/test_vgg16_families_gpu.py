@@ -14,7 +14,7 @@ import torch
 import oracle
 from keynet_amd import system as ksys
 from keynet_amd import sparse as ksp
-from keynet_amd.layer import KeyedLayer, FLOAT_KEY_TOL
+from keynet_amd.layer import KeyedLayer, FLOAT_KEY_TOL, gate
 from keynet_amd.models import VGG16
 
 pytestmark = pytest.mark.gpu
@@ -87,7 +87,7 @@ def test_keyed_equals_plain_at_the_references_tolerance(keyed):
         if isinstance(c.W, ksp.Conv2dTiledMatrix):
             ye = c.W.torchdot(yin.t(), relu=fuse, exact=True).t()
             (d, m) = (float((ye - out).abs().max()), float(ye.abs().max()))
-            assert d <= FLOAT_KEY_TOL * max(1.0, m), (lname, d, m, c._exact)
+            assert gate(out, ye)[0] <= 1.0, (lname, d, m, c._exact)          # element-wise np.allclose(atol=1e-5), the reference's own form
             with torch.cuda.device(dev):
                 plan = c.W._device_op(dev).plan(256, (1 if fuse else 0) | (2 if c._exact is True else 0))
             print(lname, 'exact' if c._exact is True else 'mfma', 'diff %.3g of %.3g' % (d, m), '|', plan)

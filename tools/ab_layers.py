@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Same-process A/B of kernel knobs on the REAL keyed VGG-16 layers (environment knobs the library re-reads per call).
+"""Same-process A/B of kernel options on the REAL keyed VGG-16 layers.  The library reads its KN_* options when an operator is CREATED and
+records them in the handle (kn_internal.h: Tuning), so every variant gets its own resident operator; the diagnostic options (KN_OCC, KN_EXACT_XD, ...)
+exist in the -DKN_ABLATION build only (tools/ablate_conv.sh builds it on demand under /tmp and points KEYNET_HIP_LIB at it).
 
     python3 tools/ab_layers.py --layers conv1_1,conv4_2,conv5_1 --variants "base;KN_OCC=3;KN_OCC=2" --rounds 5
 Each round times every variant once per layer (interleaved: A B C A B C ...), HIP events on the launch stream; prints median and
@@ -50,16 +52,16 @@ def main():
         if name in want:
             import copy
             nnz = bench.host_nnz(c)
-            # one resident operator per variant (create-time knobs KN_C_* are read when the device operator is built)
+            # one resident operator per variant (options are read when the device operator is built)
             layer_of = {}
             for (v, d) in variants:
                 for k in knobs:
                     os.environ.pop(k, None)
                 os.environ.update(d)
-                if any(k.startswith('KN_C_') for k in d):
+                if d:
                     lc = copy.copy(c)
                     lc.W = copy.copy(c.W)
-                    lc.W._op = None
+                    (lc.W._op, lc.W._op_dense) = (None, None)
                 else:
                     lc = c
                 lc.forward(y, fuse_relu=fuse)
@@ -68,9 +70,6 @@ def main():
             times = {v: [] for (v, _) in variants}
             for r in range(args.rounds):
                 for (v, d) in variants:
-                    for k in knobs:
-                        os.environ.pop(k, None)
-                    os.environ.update(d)
                     lc = layer_of[v]
                     for _ in range(args.warm):                       # back-to-back launches: the clock settles under THIS load
                         out = lc.forward(y, fuse_relu=fuse)
