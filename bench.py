@@ -45,6 +45,7 @@ if ROOT not in sys.path:
 from keynet_amd import system as ksys          # noqa: E402
 from keynet_amd import sparse as ksp           # noqa: E402
 from keynet_amd import dist as kdist           # noqa: E402
+from keynet_amd import io as kio               # noqa: E402
 from keynet_amd.layer import KeyedLayer        # noqa: E402
 from keynet_amd.models import VGG16, LeNet_AvgPool, AllConvNet   # noqa: E402
 
@@ -129,6 +130,44 @@ def build_workload(name, rank, exact=None):
         raise ValueError('unknown workload "%s"' % name)
     log('[bench rank %d] keyed %s on the host in %.1f s' % (rank, name, time.time() - t0))
     return (sensor, knet, inshape, batch, desc, net)
+
+
+def build_workload_shared(name, rank, world, exact=None, wait_s=900.0):
+    """build_workload for the ranks of ONE node: local rank 0 keys the net and hands the arrays to the others through the neutral archive
+    (keynet_amd.io, uncompressed, in /dev/shm) instead of every rank keying for itself.  Measured on the GPU box (tools/time_startup.py,
+    VGG-16): one keying 26 s, eight concurrent keyings 58-62 s each (they compete for memory bandwidth).  Falls back to keying locally when
+    the archive does not appear.  Ranks other than 0 get net = None (only rank 0 evaluates the plain network for the parity gate)."""
+    if world <= 1:
+        return build_workload(name, rank, exact=exact)
+    tag = '%s_%s_%d' % (name, os.environ.get('MASTER_PORT', '0'), os.getuid())
+    path = os.path.join('/dev/shm' if os.path.isdir('/dev/shm') else '/tmp', 'keynet_bench_%s.npz' % tag)
+    meta = path + '.json'
+    if int(os.environ.get('LOCAL_RANK', rank)) == 0:
+        out = build_workload(name, rank, exact=exact)
+        (sensor, knet, inshape, batch, desc, net) = out
+        t0 = time.time()
+        try:
+            kio.save_keynet(knet, path + '.tmp.npz', sensor=sensor, compress=False)
+            json.dump({'inshape': list(inshape), 'batch': batch, 'desc': desc}, open(meta + '.tmp', 'w'))
+            os.replace(meta + '.tmp', meta)
+            os.replace(path + '.tmp.npz', path)                     # (the archive appears last, whole)
+            import atexit
+            atexit.register(lambda: [os.path.exists(f) and os.remove(f) for f in (path, meta)])
+            log('[bench rank %d] keyed net handed to the other ranks through %s (%.1f s, %.0f MB)' % (rank, path, time.time() - t0, os.path.getsize(path) / 1e6))
+        except OSError as e:
+            log('[bench rank %d] could not write %s (%s): the other ranks key for themselves' % (rank, path, e))
+        return out
+    t0 = time.time()
+    while not os.path.exists(path) and time.time() - t0 < wait_s:
+        time.sleep(0.2)
+    if not os.path.exists(path):
+        log('[bench rank %d] no archive after %.0f s: keying locally' % (rank, wait_s))
+        return build_workload(name, rank, exact=exact)
+    t1 = time.time()
+    (sensor, knet) = kio.load_keynet(path, with_sensor=True)
+    m = json.load(open(meta))
+    log('[bench rank %d] waited %.1f s for rank 0\'s keying, loaded the archive in %.1f s' % (rank, t1 - t0, time.time() - t1))
+    return (sensor, knet, tuple(m['inshape']), m['batch'], m['desc'], None)
 
 
 def keyed_layers(knet):
@@ -874,7 +913,7 @@ def main():
     # Arithmetic contract of the headline: BASELINE configs[3] names "MFMA dense sub-tiles", so the tiled VGG-16 key-nets are built with the
     # 'auto' contract EXPLICITLY (matrix cores wherever the 1e-5 tolerance holds, screened on every forward); a permutation-only tiled key-net's
     # own default is the bit-exact contract, which the `exact` leg of the same line measures on the same key-net.
-    (sensor, knet, inshape, batch, desc, net) = build_workload(args.workload, rank, exact=True if args.exact else ('auto' if args.workload.startswith('vgg16') else None))
+    (sensor, knet, inshape, batch, desc, net) = build_workload_shared(args.workload, rank, world, exact=True if args.exact else ('auto' if args.workload.startswith('vgg16') else None))
     mode = 'exact' if (args.exact or not args.workload.startswith('vgg16')) else 'tolerance'
     mode_desc = {'exact': 'exact: order-preserving kernels, bit-exact with the reference (the default of permutation-only key-nets)',
                  'tolerance': "tolerance, explicit opt-in exact='auto': f32 MFMA within 1e-5 max(1,|y|) of the reference, re-screened every forward; bit-exact contract = `exact` leg"}[mode]

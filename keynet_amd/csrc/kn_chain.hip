@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <numeric>
 #include <type_traits>
@@ -48,14 +49,17 @@ static constexpr size_t CHAIN_THIN_POOL_BYTES = 12 * 1024;    // column pool of 
 static constexpr int CHAIN_OVERREAD_QUADS = 16;                // >= ring depth + next-slice quads: how far the walk may request past the end of an array
 
 struct ChainLayerArg {
-    const float* vals;          // quads: [slice][q][lane][4]
+    const float* vals;          // quads: [slice][q][lane][row of the lane (rpl)][4]
     const int32_t* cols;        // pool of column quads; an entry is the LDS BYTE offset of the feature in this layer's input buffer
-    const int32_t* lane_meta;   // [n_slices * 64][2]: output row (-1 = empty slot), index of the row's first column QUAD in `cols`
-    const int32_t* slice_info;  // [n_slices][4]: quads, column quad stride, first value quad / 64, 0
+    const int32_t* lane_meta;   // [n_slices * 64][4]: output row (-1 = empty slot), index of the lane's first column QUAD in `cols`, second output row (rpl = 2) or -1, 0
+    const int32_t* slice_info;  // [n_slices][4]: quads, column quad stride, first value quad / (64 * rpl), 0
     int32_t n_slices, n_rows, relu;
     int32_t cols_quads;         // size of the layer's column pool in quads when the pool is staged in LDS before the walk:
                                 //   > 0 a THIN layer (chain_rows_thin, two copies), < 0 a layer of shared patterns on all wavefronts
                                 //   (chain_rows_cl, one copy); 0 = columns from memory (chain_rows)
+    int32_t rpl;                // output rows per lane: 1, or 2 (chain_rows_cl: two rows of one column pattern share every activation read)
+    int32_t stage_off;          // float4 index of the LDS area the pool is staged in
+    int32_t early;              // 1 = the pool is staged while the PREVIOUS layer runs (layer 0: with the input), 0 = at the start of this layer
 };
 
 struct ChainArgs {
@@ -64,7 +68,6 @@ struct ChainArgs {
     float* Y;
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
-    int32_t cols_off;                                              // float4 index of the LDS area column pools are staged in (one layer at a time)
 #ifdef KN_ABLATION
     unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries (tools/chain_stamps.sh), or null
     unsigned long long* wstamps;                                   // [workgroup][12 layers][16 wavefronts][40] inside the walks: 0-7 per walk, 8 + 4 * slice + k per slice
@@ -127,6 +130,45 @@ __device__ __forceinline__ float* chain_lds_base() {
 }
 #define chain_lds (chain_lds_base<ST>())
 
+// What a wavefront requests of a layer's operator BEFORE the barrier that ends the previous layer (the operator words do not depend on the activations):
+// the lane records of its first two slices and the first ring of value (and, for the general walk, column) quads of the first one.  The walk starts
+// with these in registers instead of with two dependent memory round trips (records, then quads: ~1.5 us per layer when exposed -- seven layers).
+#ifndef KN_CHAIN_DV
+#define KN_CHAIN_DV 6           // value quads in flight per wavefront of the thin walk (a multiple of 6.  LeNet forward, same box: 6 -> 37.6 us, 12 -> 38.6 us with a few
+                                // spilled address registers, 18 spills the ring itself)
+#endif
+static constexpr int CHAIN_D = 4, CHAIN_NP = 2;       // ring depth / next-slice quads requested early (pattern walk, one row per lane)
+static constexpr int CHAIN_D_ROWS = 2;                // ... of the general walk (what takes it are short rows of unrelated patterns -- keyed pooling: 9 entries = 3 quads -- and it
+                                                      // holds a column quad per value quad: the register budget of 16 wavefronts per CU is 128)
+struct ChainMeta {
+    int row, row1, nq;
+    uint32_t cstride_b;                    // bytes between a row's consecutive column quads (16, or 16 * 64 for per-lane columns)
+    uint32_t coff, voff;                   // byte offsets of the lane's quad 0 in L.cols (or in the staged pool) / L.vals
+};
+struct ChainPre {
+    ChainMeta m0, m1;
+    f32x4 v[2 * CHAIN_D];
+    i32x4 c[CHAIN_D];
+};
+
+// lane + slice record of slice s for this lane; R = rows per lane of the layer's layout, POOL = columns are read from the pool staged in LDS at
+// float4 index pool4 (then coff is an LDS byte offset), else from memory
+template <int R, bool POOL>
+__device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int s, const int lane, const int pool4) {
+    constexpr int RPS = 64;
+    s = s < L.n_slices ? s : L.n_slices - 1;                    // past the end: the last slice again (unused)
+    const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
+    const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(s * RPS + lane));      // (uniform base + 32-bit offset: saddr form)
+    ChainMeta m;
+    m.row = lm.x;
+    if constexpr (R == 2) m.row1 = lm.z;      // (one row per lane: never read)
+    m.nq = si[0];
+    m.cstride_b = 16u * (uint32_t)si[1];
+    m.voff = 16u * (uint32_t)R * ((uint32_t)si[2] * RPS + (uint32_t)lane);
+    m.coff = 16u * (uint32_t)(POOL ? (pool4 + lm.y) : lm.y);
+    return m;
+}
+
 // One output row per lane, all four batch columns: acc[j] = acc[j] + v * x[j] over the row's stored non-zeros, serial in k.
 // A wavefront walks its slices s = wave, wave + 16, ...; per slice the operator words arrive through a register ring of D quads per lane
 // (a thin layer -- a 121-row Linear is two slices -- runs on few wavefronts: the L2 latency of its serial walk has to be covered inside the
@@ -137,52 +179,52 @@ __device__ __forceinline__ float* chain_lds_base() {
 // bit for bit, and no NaN / Inf of a live activation can leak through a padded entry.  So there is no predicate anywhere in the walk.
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
-template <int D, int NP, bool ST>
-__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, unsigned long long* const ws) {
+template <bool ST>
+__device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
+    constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS;
+    if (wave >= L.n_slices) return;
+    pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0);
+    pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
+    const char* const cols_b = reinterpret_cast<const char*>(L.cols);
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        pre.c[i] = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)i * pre.m0.cstride_b) + pre.m0.coff);
+        pre.v[i] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * 64)) + pre.m0.voff);
+    }
+}
+
+template <bool ST>
+__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
     constexpr int RPS = 64;                    // rows per slice (wavefront)
-    constexpr int NW = CHAIN_THREADS / 64;
+    constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS, NP = CHAIN_NP;
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
     // Operator words are addressed as (array base, wave-uniform) + (32-bit byte offset): the slice's offset and the running quad offset are scalar,
     // the lane's own offset is a constant of the slice -- the loads take the saddr form and the walk has no 64-bit vector address arithmetic and no
     // clamp: a request past a slice's last quad reads the next slice's words (or the arrays' zero padding) and is never used.
-    struct Meta {
-        int row, nq;
-        uint32_t cstride_b;                    // bytes between a row's consecutive column quads (16, or 16 * 64 for per-lane columns)
-        uint32_t coff, voff;                   // byte offsets of the lane's quad 0 in L.cols / L.vals
-    };
     const char* const cols_b = reinterpret_cast<const char*>(L.cols);
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
-    auto load_meta = [&](int s) {
-        s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
-        const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
-        const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (s * RPS + lane));
-        Meta m;
-        m.row = lm.x;
-        m.nq = si[0];
-        m.cstride_b = 16u * (uint32_t)si[1];
-        m.voff = 16u * ((uint32_t)si[2] * RPS + (uint32_t)lane);
-        m.coff = 16u * (uint32_t)lm.y;
-        return m;
-    };
-    auto fetch = [&](const Meta& m, const int q, i32x4& c, f32x4& v) {
+    auto fetch = [&](const ChainMeta& m, const int q, i32x4& c, f32x4& v) {
         c = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)q * m.cstride_b) + m.coff);
         v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     CHAIN_WSTAMP(0, false);
-    Meta m0 = load_meta(wave), m1 = load_meta(wave + NW);
-    CHAIN_WSTAMP(1, true);                                          // slice + lane records landed
+    ChainMeta m0 = pre.m0, m1 = pre.m1;
     i32x4 c[D], cn[NP];
     f32x4 v[D], vn[NP];
 #pragma unroll
-    for (int i = 0; i < D; i++) fetch(m0, i, c[i], v[i]);
+    for (int i = 0; i < D; i++) {
+        c[i] = pre.c[i];
+        v[i] = pre.v[i];
+    }
     CHAIN_WSTAMP(2, true);                                          // first ring landed
     for (int s = wave; s < n_slices; s += NW) {
 #pragma unroll
         for (int i = 0; i < NP; i++) fetch(m1, i, cn[i], vn[i]);
-        const Meta m2 = load_meta(s + 2 * NW);
+        const ChainMeta m2 = chain_load_meta<1, false>(L, s + 2 * NW, lane, 0);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
         f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
         // activations of a quad are read from LDS one quad AHEAD of their use (x double buffer): with two wavefronts on a CU (a Linear) the
@@ -265,64 +307,73 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // of arithmetic: the conv layers ran at the addresser's rate (conv2: 157 k non-zeros x 8 B / 64 B per clock = 8.2 us of its 15.6).  Staged
 // once per launch and layer by all sixteen wavefronts (one pass through the addresser instead of one per lane), a pattern's quad is a
 // broadcast ds_read_b128; the activation reads run one quad behind the column reads and one ahead of the arithmetic, as in the thin walk.
-template <int D, int NP, bool ST>
-__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane, unsigned long long* const ws) {
+//
+// R = 2 (round 5): a lane owns TWO output rows of one column pattern (two output channels of a conv pixel).  With one row per lane the walk is bound
+// by the CU's LDS read port, not by arithmetic: every stored non-zero costs its lane one 16-byte activation read, i.e. 5 wave-wide ds_read_b128
+// (8 clocks each of the one 128 B / clock port) per quad and wavefront = 40 clocks, against 16 clocks of the CU's four SIMDs for the quad's 16 packed
+// multiplies / adds -- LeNet conv2: 50 slices x 13 quads x 40 clocks = 10.8 us of the 12.0 it took.  Two rows per lane share every activation read:
+// the same LDS clocks now carry twice the arithmetic (conv2 12.0 -> see profiles/r05_lenet_chain_breakdown.txt).  Each row still sums its own stored
+// sequence serially, multiply then add: same bits.
+template <bool ST, int R>
+__device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
+    constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D;      // (R = 2: a quad is 32 bytes per lane -- the same bytes in flight with half the ring)
+    if (wave >= L.n_slices) return;
+    pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off);
+    pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+#pragma unroll
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int r = 0; r < R; r++) pre.v[i * R + r] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * R * 64)) + pre.m0.voff + 16u * r);
+}
+
+template <bool ST, int R>
+__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
     constexpr int RPS = 64;
-    constexpr int NW = CHAIN_THREADS / 64;
+    constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D, NP = (R == 2) ? 1 : CHAIN_NP;
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
-    const int tid = wave * 64 + lane;
-    const int pool4 = -L.cols_quads;                                             // quads
-    for (int i = tid; i < pool4; i += CHAIN_THREADS)
-        *reinterpret_cast<i32x4*>(&chain_lds[4 * (cols_off4 + i)]) = *reinterpret_cast<const i32x4*>(L.cols + 4 * i);
-    __syncthreads();
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
-    struct Meta {
-        int row, nq;
-        uint32_t coff, voff;                   // LDS byte offset of the row's column quad 0 in the staged pool; byte offset of the lane's value quad 0 in L.vals
-    };
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
-    auto load_meta = [&](int s) {
-        s = s < n_slices ? s : n_slices - 1;                        // past the end: the last slice again (unused)
-        const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
-        const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (s * RPS + lane));
-        Meta m;
-        m.row = lm.x;
-        m.nq = si[0];
-        m.voff = 16u * ((uint32_t)si[2] * RPS + (uint32_t)lane);
-        m.coff = 16u * (uint32_t)(cols_off4 + lm.y);
-        return m;
-    };
-    auto ldv = [&](const Meta& m, const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff); };
-    auto ldc = [&](const Meta& m, const int q) { return *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(chain_lds) + m.coff + 16u * (uint32_t)q); };     // (the pool is padded: quads past a row's end are readable)
+    auto ldv = [&](const ChainMeta& m, const int q, const int r) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * R * RPS)) + m.voff + 16u * r); };
+    auto ldc = [&](const ChainMeta& m, const int q) { return *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(chain_lds) + m.coff + 16u * (uint32_t)q); };     // (the pool is padded: quads past a row's end are readable)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    Meta m0 = load_meta(wave), m1 = load_meta(wave + NW);
-    f32x4 v[D], vn[NP];
+    ChainMeta m0 = pre.m0, m1 = pre.m1;
+    f32x4 v[D][R], vn[NP][R];
 #pragma unroll
-    for (int i = 0; i < D; i++) v[i] = ldv(m0, i);
+    for (int i = 0; i < D; i++)
+#pragma unroll
+        for (int r = 0; r < R; r++) v[i][r] = pre.v[i * R + r];
     int si = 0;                                                   // (slice counter: timestamps of the diagnostic build only)
     for (int s = wave; s < n_slices; s += NW, si++) {
         if (si < 8) CHAIN_WSTAMP(8 + 4 * si + 0, false);
 #pragma unroll
-        for (int i = 0; i < NP; i++) vn[i] = ldv(m1, i);
-        const Meta m2 = load_meta(s + 2 * NW);
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int r = 0; r < R; r++) vn[i][r] = ldv(m1, i, r);
+        const ChainMeta m2 = chain_load_meta<R, true>(L, s + 2 * NW, lane, L.stage_off);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
-        f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+        f32x2 a01[R], a23[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) a01[r] = a23[r] = f32x2{0.f, 0.f};
         auto xread = [&](const i32x4& cq, f32x4 (&x)[4]) {
             x[0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.x);
             x[1] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.y);
             x[2] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.z);
             x[3] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(chain_lds) + cq.w);
         };
-        auto macs = [&](const f32x4 (&x)[4], const f32x4& vq) {
-            const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
+        auto macs = [&](const f32x4 (&x)[4], const f32x4 (&vq)[R]) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const f32x2 x01 = {x[e].x, x[e].y}, x23 = {x[e].z, x[e].w};
-                const f32x2 p01 = (e & 1) ? chain_mul_hi(x01, vp[e >> 1]) : chain_mul_lo(x01, vp[e >> 1]);
-                const f32x2 p23 = (e & 1) ? chain_mul_hi(x23, vp[e >> 1]) : chain_mul_lo(x23, vp[e >> 1]);
-                a01 = a01 + p01;
-                a23 = a23 + p23;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const f32x2 vp = (e >> 1) ? f32x2{vq[r].z, vq[r].w} : f32x2{vq[r].x, vq[r].y};
+                    const f32x2 p01 = (e & 1) ? chain_mul_hi(x01, vp) : chain_mul_lo(x01, vp);
+                    const f32x2 p23 = (e & 1) ? chain_mul_hi(x23, vp) : chain_mul_lo(x23, vp);
+                    a01[r] = a01[r] + p01;
+                    a23[r] = a23[r] + p23;
+                }
             }
         };
         const int nq = m0.nq;
@@ -348,7 +399,8 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
                 xread(c1, xn);
                 __builtin_amdgcn_sched_barrier(0);                 // next quad's LDS reads in flight under this quad's arithmetic
                 macs(xc, v[i]);
-                v[i] = ldv(m0, q + D + i);
+#pragma unroll
+                for (int r = 0; r < R; r++) v[i][r] = ldv(m0, q + D + i, r);
                 __builtin_amdgcn_sched_barrier(0);                 // the value request stays HERE (see chain_rows)
                 c1 = c2;
             }
@@ -366,15 +418,19 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
             }
         }
         if (si < 8) CHAIN_WSTAMP(8 + 4 * si + 2, false);
-        if (m0.row >= 0) {
-            f32x4 t = {a01.x, a01.y, a23.x, a23.y};
-            if (L.relu) {                                          // torch relu: NaN stays NaN
-                t.x = (t.x < 0.0f) ? 0.0f : t.x;
-                t.y = (t.y < 0.0f) ? 0.0f : t.y;
-                t.z = (t.z < 0.0f) ? 0.0f : t.z;
-                t.w = (t.w < 0.0f) ? 0.0f : t.w;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row = r ? m0.row1 : m0.row;
+            if (row >= 0) {
+                f32x4 t = {a01[r].x, a01[r].y, a23[r].x, a23[r].y};
+                if (L.relu) {                                      // torch relu: NaN stays NaN
+                    t.x = (t.x < 0.0f) ? 0.0f : t.x;
+                    t.y = (t.y < 0.0f) ? 0.0f : t.y;
+                    t.z = (t.z < 0.0f) ? 0.0f : t.z;
+                    t.w = (t.w < 0.0f) ? 0.0f : t.w;
+                }
+                *reinterpret_cast<f32x4*>(&chain_lds[out_off + 4 * row]) = t;
             }
-            *reinterpret_cast<f32x4*>(&chain_lds[out_off + 4 * m0.row]) = t;
         }
         m0 = m1;
         m1 = m2;
@@ -384,9 +440,13 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
         asm volatile("" : "+v"(m0.coff), "+v"(m0.row));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NP; i++) v[i] = vn[i];
+        for (int i = 0; i < NP; i++)
 #pragma unroll
-        for (int i = NP; i < D; i++) v[i] = ldv(m0, i);
+            for (int r = 0; r < R; r++) v[i][r] = vn[i][r];
+#pragma unroll
+        for (int i = NP; i < D; i++)
+#pragma unroll
+            for (int r = 0; r < R; r++) v[i][r] = ldv(m0, i, r);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -401,26 +461,32 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
 // memory (the two wavefronts of a slice load the same values: with the columns also from memory that would double the texture addresser's
 // work, which is shared by the CU -- the reason an earlier two-/four-lanes-per-row variant was slower).
 template <int DV, bool ST>
-__device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const int out_off, const int cols_off4, const int wave, const int lane, unsigned long long* const ws) {
+__device__ __forceinline__ void chain_rows_thin_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int RPS = 64;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int tid = wave * 64 + lane;
-    const int pool = 4 * L.cols_quads;                                            // entries of one copy
-    for (int i = tid; i < 2 * pool; i += CHAIN_THREADS) {
-        const int half = i >= pool ? 1 : 0;
-        reinterpret_cast<int*>(chain_lds)[4 * cols_off4 + i] = L.cols[i - half * pool] + 8 * half;
-    }
-    CHAIN_WSTAMP(0, false);
-    __syncthreads();
-    CHAIN_WSTAMP(1, false);                                                      // pool staged
     if (wave >= 2 * L.n_slices) return;
     const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
     const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
-    const int2 lm = *reinterpret_cast<const int2*>(L.lane_meta + 2 * (sl * RPS + lane));
-    const int nq = __builtin_amdgcn_readfirstlane(info.x);
+    const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(sl * RPS + lane));
+    pre.m0.row = lm.x;
+    pre.m0.nq = __builtin_amdgcn_readfirstlane(info.x);
+    pre.m0.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
+    pre.m0.coff = (uint32_t)lm.y;
+    // (the value ring itself is requested by the walk: DV quads per lane held across the barrier next to the other walk kinds' words do not fit the
+    // 128 registers a wavefront has at 16 wavefronts per CU -- the compiler spills them)
+}
+
+template <int DV, bool ST>
+__device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
+    constexpr int RPS = 64;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int pool = 4 * L.cols_quads;                                            // entries of one copy
+    const int cols_off4 = L.stage_off;
+    if (wave >= 2 * L.n_slices) return;
+    const int half = wave >= L.n_slices ? 1 : 0;
+    const int nq = pre.m0.nq;
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
-    const uint32_t voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
-    const int cbase = 4 * cols_off4 + half * pool + 4 * lm.y;                    // int index of the row's column quad 0 in the wavefront's copy (+ 4 q)
+    const uint32_t voff = pre.m0.voff;
+    const int cbase = 4 * cols_off4 + half * pool + 4 * (int)pre.m0.coff;         // int index of the row's column quad 0 in the wavefront's copy (+ 4 q)
     auto ldc = [&](const int q) { return *reinterpret_cast<const i32x4*>(&reinterpret_cast<const int*>(chain_lds)[cbase + 4 * q]); };      // (the pool is padded: requests past the row's end are readable)
     auto ldv = [&](const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + voff); };
     auto xread = [&](const i32x4& cq, f32x2 (&x)[4]) {
@@ -443,48 +509,69 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     for (int i = 0; i < DV; i++) v[i] = ldv(i);
     __builtin_amdgcn_sched_barrier(0);
     CHAIN_WSTAMP(2, true);                                                       // records + first ring landed
-    i32x4 c1 = ldc(1);                       // columns two quads ahead, activations one quad ahead
-    f32x2 xa[4], xb[4];
+    // Software pipeline of one wavefront alone on its SIMD: the running sum is a chain of dependent packed adds (~14 clocks each, 4 per quad: the floor of
+    // this walk is ~56 clocks per quad), and nothing else may sit in that chain.  Column quads are read from LDS THREE quads ahead, the activations they
+    // address TWO quads ahead (an LDS round trip is 75-100 clocks -- more than one quad's arithmetic: one quad ahead, as in rounds 3-4, left ~40 clocks
+    // of every quad exposed), values DV quads ahead.
+    f32x2 x[3][4];
+    i32x4 cq[2];                                   // cq[k & 1] = column quad k + 2 (read while quad k runs; consumed by the activation request of quad k + 1's turn)
     {
-        const i32x4 c0 = ldc(0);
-        xread(c0, xa);
+        const i32x4 c0 = ldc(0), c1 = ldc(1);
+        cq[0] = ldc(2);
+        xread(c0, x[0]);
+        xread(c1, x[1]);
     }
+    static_assert(DV % 6 == 0, "the activation buffers rotate with period 3, the column quads with period 2: an unrolled trip must be a multiple of both");
     int q = 0;
     for (; q + DV <= nq; q += DV) {
 #pragma unroll
         for (int i = 0; i < DV; i++) {
-            f32x2 (&xc)[4] = (i & 1) ? xb : xa;
-            f32x2 (&xn)[4] = (i & 1) ? xa : xb;
-            const i32x4 c2 = ldc(q + i + 2);
-            xread(c1, xn);
-            __builtin_amdgcn_sched_barrier(0);             // next quad's LDS reads in flight under this quad's arithmetic
-            macs(xc, v[i]);
+            cq[(i + 1) & 1] = ldc(q + i + 3);
+            xread(cq[i & 1], x[(i + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);             // the next quads' LDS reads in flight under this quad's arithmetic
+            macs(x[i % 3], v[i]);
             v[i] = ldv(q + DV + i);
             __builtin_amdgcn_sched_barrier(0);             // the value request stays HERE (see chain_rows)
-            c1 = c2;
         }
-        static_assert(DV % 2 == 0, "the x double buffer alternates per quad");
     }
 #pragma unroll
     for (int i = 0; i < DV - 1; i++) {
         if (q + i < nq) {
-            f32x2 (&xc)[4] = (i & 1) ? xb : xa;
-            f32x2 (&xn)[4] = (i & 1) ? xa : xb;
-            const i32x4 c2 = ldc(q + i + 2);
-            xread(c1, xn);
+            cq[(i + 1) & 1] = ldc(q + i + 3);
+            xread(cq[i & 1], x[(i + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);
-            macs(xc, v[i]);
-            c1 = c2;
+            macs(x[i % 3], v[i]);
         }
     }
-    if (lm.x >= 0) {
+    if (pre.m0.row >= 0) {
         f32x2 t = acc;
         if (L.relu) {                                          // torch relu: NaN stays NaN
             t.x = (t.x < 0.0f) ? 0.0f : t.x;
             t.y = (t.y < 0.0f) ? 0.0f : t.y;
         }
-        *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * lm.x + 2 * half]) = t;
+        *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * pre.m0.row + 2 * half]) = t;
     }
+}
+
+// Column pool of a layer into its LDS staging area: a pattern layer's quads as they are, a thin layer's twice (the second copy with + 8 bytes on every
+// entry: the address of the wavefront's column pair).  `q` = a quad already loaded from L.cols + 4 * i.
+template <bool ST>
+__device__ __forceinline__ void chain_stage_quad(const ChainLayerArg& L, const int i, const i32x4 q) {
+    *reinterpret_cast<i32x4*>(&chain_lds[4 * (L.stage_off + i)]) = q;
+    if (L.cols_quads > 0) *reinterpret_cast<i32x4*>(&chain_lds[4 * (L.stage_off + L.cols_quads + i)]) = q + 8;
+}
+template <bool ST>
+__device__ __forceinline__ void chain_stage_now(const ChainLayerArg& L, const int tid) {
+    const int n = L.cols_quads > 0 ? L.cols_quads : -L.cols_quads;
+    for (int i = tid; i < n; i += CHAIN_THREADS) chain_stage_quad<ST>(L, i, *reinterpret_cast<const i32x4*>(L.cols + 4 * i));
+}
+
+template <bool ST>
+__device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
+    if (L.cols_quads > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST>(L, wave, lane, pre);
+    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2>(L, wave, lane, pre);
+    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1>(L, wave, lane, pre);
+    else chain_rows_pre<ST>(L, wave, lane, pre);
 }
 
 template <bool ST>
@@ -517,6 +604,15 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         *reinterpret_cast<f32x4*>(&chain_lds[4 * f]) = v;
     }
     if (tid == 0) *reinterpret_cast<f32x4*>(&chain_lds[4 * a.zero_off]) = f32x4{0.f, 0.f, 0.f, 0.f};      // what padded operator entries read
+    // the first layer's column pool and first operator words travel with the input (nothing here depends on it)
+    if (a.L[0].cols_quads != 0 && a.L[0].early) chain_stage_now<ST>(a.L[0], tid);
+#ifndef KN_CHAIN_PRE
+#define KN_CHAIN_PRE 0          // 1 = a layer's first operator words are requested before the barrier that ends the previous layer.  Built and measured (round 5):
+                                // the words held across the barrier push the kernel over its 128 registers (16 wavefronts per CU), the spills cost more than the
+                                // hidden round trips gain: 42.4 against 39.0 us per LeNet forward.  Kept as a build switch for a device with more registers per wavefront.
+#endif
+    ChainPre pre;
+    if (KN_CHAIN_PRE) chain_pre<ST>(a.L[0], wave, lane, pre);
     __syncthreads();
     CHAIN_STAMP(1);
     for (int l = 0; l < a.n_layers; l++) {
@@ -527,11 +623,27 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         constexpr unsigned long long* ws = nullptr;
 #endif
         const int out_off = (l & 1) ? boff[0] : boff[1];         // (the input buffer's base is folded into the stored column offsets)
-        if (L.cols_quads > 0) chain_rows_thin<8, ST>(L, out_off, a.cols_off, wave, lane, ws);
-        else if (L.cols_quads < 0) chain_rows_cl<4, 2, ST>(L, out_off, a.cols_off, wave, lane, ws);
-        else chain_rows<4, 2, ST>(L, out_off, wave, lane, ws);
+        // The NEXT layer's column pool is staged by every wavefront right behind its own walk of THIS layer (into an area this layer does not read:
+        // chain_create places it; the barrier that ends this layer publishes it): the wavefronts finish their walks a few microseconds apart, so all but
+        // the last one hide the round trip, and the layer no longer starts with a stage + barrier of its own.
+        const bool stage_next = (l + 1 < a.n_layers) && a.L[l + 1].cols_quads != 0 && a.L[l + 1].early;
+        if (L.cols_quads != 0 && !L.early) {                     // a pool that found no free area while the previous layer ran: staged here, as before
+            chain_stage_now<ST>(L, tid);
+            __syncthreads();
+        }
+        if (!KN_CHAIN_PRE) chain_pre<ST>(L, wave, lane, pre);
+        if (L.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(L, out_off, wave, lane, pre, ws);
+        else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl<ST, 2>(L, out_off, wave, lane, pre, ws);
+        else if (L.cols_quads < 0) chain_rows_cl<ST, 1>(L, out_off, wave, lane, pre, ws);
+        else chain_rows<ST>(L, out_off, wave, lane, pre, ws);
         CHAIN_WSTAMP(6, false);
+        if (stage_next) chain_stage_now<ST>(a.L[l + 1], tid);
+        // the next layer's first operator words: on their way across the barrier.  (A fresh object per layer: what a wavefront without a slice, or a walk
+        // kind that needs fewer words, leaves unwritten is then undefined rather than the previous layer's values kept alive through the walk.)
+        ChainPre nxt;
+        if (KN_CHAIN_PRE && l + 1 < a.n_layers) chain_pre<ST>(a.L[l + 1], wave, lane, nxt);
         __syncthreads();
+        if (KN_CHAIN_PRE) pre = nxt;
         CHAIN_WSTAMP(7, false);
         CHAIN_STAMP(2 + l);
     }
@@ -574,8 +686,8 @@ static int chain_upload(ChainDev* c, const T** dst, const std::vector<T>& h) {
 // one layer: CSR (host copy, stored order) -> the sliced layout above.  in_base / zero_byte: LDS byte offsets of the layer's input buffer
 // and of the always-zero feature.
 static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_t cols, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix,
-                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte, const Tuning& tune) {
-    constexpr int RPS = 64;
+                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte, const Tuning& tune, const size_t room_quads) {
+    constexpr int RPS = 64;                      // room_quads: LDS left beside the activations, in 16-byte quads (what a staged column pool may take)
     (void)cols;
     auto off = [&](int32_t col) { return in_base + 16 * col; };
     // column patterns: rows with an identical stored column sequence share one copy
@@ -607,126 +719,181 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
             pat[(size_t)r] = found;
         }
     }
-    std::vector<int32_t> order((size_t)rows);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        const int32_t lx = ip[(size_t)x + 1] - ip[(size_t)x], ly = ip[(size_t)y + 1] - ip[(size_t)y];
-        if (lx != ly) return lx > ly;
-        return pat[(size_t)x] < pat[(size_t)y];
-    });
-    const int64_t n_slices = (rows + RPS - 1) / RPS;
-    std::vector<int32_t> lane_meta((size_t)(n_slices * RPS) * 2, 0), info((size_t)(n_slices * 4), 0);
-    for (size_t o = 0; o < (size_t)(n_slices * RPS); o++) lane_meta[2 * o] = -1;
-    // pass 1: per slice its longest row and whether its lanes share column patterns; per shared pattern the quads it must be readable for
-    // (every lane of a slice walks up to the slice's LONGEST row)
-    std::vector<int> s_max((size_t)n_slices, 0);
-    std::vector<char> s_shared((size_t)n_slices, 0);
-    std::vector<int> pat_quads(pat_rep.size(), 0);
-    for (int64_t s = 0; s < n_slices; s++) {
-        int mx = 0, distinct = 0;
-        int32_t last_pat = -2;
-        const int real = (int)std::min<int64_t>(RPS, rows - s * RPS);
-        for (int i = 0; i < real; i++) {
-            const int32_t r = order[(size_t)(s * RPS + i)];
-            mx = std::max(mx, ip[(size_t)r + 1] - ip[(size_t)r]);
-            if (pat[(size_t)r] != last_pat) distinct++;
-            last_pat = pat[(size_t)r];
-            lane_meta[2 * (size_t)(s * RPS + i)] = r;
-        }
-        s_max[(size_t)s] = mx;
-        s_shared[(size_t)s] = (distinct * 2 <= real) ? 1 : 0;     // most lanes share a pattern with a neighbour: one copy per pattern
-    }
-    // a layer that is shared almost everywhere (a conv layer and its odd last slice: the homogeneous row) stores every slice that way -- one layout
-    // per layer lets its whole pool be staged in LDS (chain_rows_cl); the few unrelated rows then read scattered instead of lane-adjacent quads
-    {
-        int64_t rows_shared = 0;
-        for (int64_t s = 0; s < n_slices; s++)
-            if (s_shared[(size_t)s]) rows_shared += std::min<int64_t>(RPS, rows - s * RPS);
-        if (rows_shared * 10 >= rows * 9)
-            for (int64_t s = 0; s < n_slices; s++) s_shared[(size_t)s] = 1;
-    }
-    for (int64_t s = 0; s < n_slices; s++) {
-        if (!s_shared[(size_t)s]) continue;
-        const int real = (int)std::min<int64_t>(RPS, rows - s * RPS);
-        for (int i = 0; i < real; i++) {
-            const int32_t p = pat[(size_t)order[(size_t)(s * RPS + i)]];
-            pat_quads[(size_t)p] = std::max(pat_quads[(size_t)p], (s_max[(size_t)s] + 3) / 4);
-        }
-    }
-    // pass 2: storage.  Padding = (zero feature, 0.0f).
-    std::vector<float> vals;
-    std::vector<int32_t> colpool(4, zero_byte);
-    std::vector<int64_t> pat_cq(pat_rep.size(), -1);         // column quad offset of a pattern stored once
-    int64_t vq = 0;                                          // running value-quad offset, in units of RPS quads
-    for (int64_t s = 0; s < n_slices; s++) {
-        const int nq = (s_max[(size_t)s] + 3) / 4;
-        const int real = (int)std::min<int64_t>(RPS, rows - s * RPS);
-        const size_t v0 = vals.size();
-        vals.resize(v0 + (size_t)nq * RPS * 4, 0.0f);
-        for (int i = 0; i < real; i++) {
-            const int32_t r = order[(size_t)(s * RPS + i)];
-            const int32_t rs = ip[(size_t)r];
-            const int len = ip[(size_t)r + 1] - rs;
-            for (int k = 0; k < len; k++) vals[v0 + ((size_t)(k >> 2) * RPS + (size_t)i) * 4 + (size_t)(k & 3)] = dt[(size_t)(rs + k)];
-        }
-        int cstride = 1;
-        if (s_shared[(size_t)s]) {
-            for (int i = 0; i < RPS; i++) {
-                const size_t o = (size_t)(s * RPS + i);
-                if (i >= real) {                             // empty slots of the last slice read along with a real row's pattern (their values are 0)
-                    lane_meta[2 * o + 1] = lane_meta[2 * (size_t)(s * RPS) + 1];
-                    continue;
-                }
-                const int32_t r = order[o];
-                const int32_t p = pat[(size_t)r];
-                if (pat_cq[(size_t)p] < 0) {
-                    pat_cq[(size_t)p] = (int64_t)colpool.size() / 4;
-                    const int32_t rs = ip[(size_t)r];
-                    const int len = ip[(size_t)r + 1] - rs;
-                    const size_t c0 = colpool.size();
-                    colpool.resize(c0 + (size_t)std::max(pat_quads[(size_t)p], 1) * 4, zero_byte);
-                    for (int k = 0; k < len; k++) colpool[c0 + (size_t)k] = off(ix[(size_t)(rs + k)]);
-                }
-                lane_meta[2 * o + 1] = (int32_t)pat_cq[(size_t)p];
+    struct Built {
+        std::vector<float> vals;
+        std::vector<int32_t> colpool, lane_meta, info;
+        int64_t n_slices = 0;
+        size_t pool_quads = 0;
+        bool thin = false, all_shared = false;
+        int longest = 0;
+    };
+    // R output rows per lane (R = 2: two rows of ONE column pattern; a pattern with an odd number of rows leaves one lane half empty)
+    auto build = [&](const int R) {
+        Built B;
+        std::vector<int32_t> rows_sorted((size_t)rows);
+        std::iota(rows_sorted.begin(), rows_sorted.end(), 0);
+        std::stable_sort(rows_sorted.begin(), rows_sorted.end(), [&](int32_t x, int32_t y) {
+            const int32_t lx = ip[(size_t)x + 1] - ip[(size_t)x], ly = ip[(size_t)y + 1] - ip[(size_t)y];
+            if (lx != ly) return lx > ly;
+            return pat[(size_t)x] < pat[(size_t)y];
+        });
+        // units = what a lane owns: R consecutive rows of the sorted order when they share a pattern (equal pattern => equal length), else one row
+        std::vector<std::array<int32_t, 2>> units;
+        for (size_t i = 0; i < rows_sorted.size();) {
+            std::array<int32_t, 2> u = {rows_sorted[i], -1};
+            if (R == 2 && i + 1 < rows_sorted.size() && pat[(size_t)rows_sorted[i + 1]] == pat[(size_t)rows_sorted[i]]) {
+                u[1] = rows_sorted[i + 1];
+                i += 2;
+            } else {
+                i += 1;
             }
-        } else {
-            cstride = RPS;
-            const size_t c0 = colpool.size();
-            colpool.resize(c0 + (size_t)std::max(nq, 1) * RPS * 4, zero_byte);
+            units.push_back(u);
+        }
+        const int64_t n_units = (int64_t)units.size();
+        const int64_t n_slices = (n_units + RPS - 1) / RPS;
+        B.n_slices = n_slices;
+        auto len_of = [&](int32_t r) { return ip[(size_t)r + 1] - ip[(size_t)r]; };
+        B.lane_meta.assign((size_t)(n_slices * RPS) * 4, 0);
+        B.info.assign((size_t)(n_slices * 4), 0);
+        for (size_t o = 0; o < (size_t)(n_slices * RPS); o++) B.lane_meta[4 * o] = B.lane_meta[4 * o + 2] = -1;
+        // pass 1: per slice its longest row and whether its lanes share column patterns; per shared pattern the quads it must be readable for
+        // (every lane of a slice walks up to the slice's LONGEST row)
+        std::vector<int> s_max((size_t)n_slices, 0);
+        std::vector<char> s_shared((size_t)n_slices, 0);
+        std::vector<int> pat_quads(pat_rep.size(), 0);
+        for (int64_t s = 0; s < n_slices; s++) {
+            int mx = 0, distinct = 0;
+            int32_t last_pat = -2;
+            const int real = (int)std::min<int64_t>(RPS, n_units - s * RPS);
             for (int i = 0; i < real; i++) {
-                const int32_t r = order[(size_t)(s * RPS + i)];
-                const int32_t rs = ip[(size_t)r];
-                const int len = ip[(size_t)r + 1] - rs;
-                for (int k = 0; k < len; k++) colpool[c0 + ((size_t)(k >> 2) * RPS + (size_t)i) * 4 + (size_t)(k & 3)] = off(ix[(size_t)(rs + k)]);
+                const std::array<int32_t, 2>& u = units[(size_t)(s * RPS + i)];
+                mx = std::max(mx, len_of(u[0]));
+                if (pat[(size_t)u[0]] != last_pat) distinct++;
+                last_pat = pat[(size_t)u[0]];
+                B.lane_meta[4 * (size_t)(s * RPS + i)] = u[0];
+                B.lane_meta[4 * (size_t)(s * RPS + i) + 2] = u[1];
             }
-            for (int i = 0; i < RPS; i++) lane_meta[2 * (size_t)(s * RPS + i) + 1] = (int32_t)(c0 / 4 + (size_t)i);
+            s_max[(size_t)s] = mx;
+            s_shared[(size_t)s] = (distinct * 2 <= real || R == 2) ? 1 : 0;     // most lanes share a pattern with a neighbour: one copy per pattern
         }
-        info[(size_t)(4 * s + 0)] = nq;
-        info[(size_t)(4 * s + 1)] = cstride;
-        info[(size_t)(4 * s + 2)] = (int32_t)vq;
-        vq += nq;
+        // a layer that is shared almost everywhere (a conv layer and its odd last slice: the homogeneous row) stores every slice that way -- one layout
+        // per layer lets its whole pool be staged in LDS (chain_rows_cl); the few unrelated rows then read scattered instead of lane-adjacent quads
+        {
+            int64_t units_shared = 0;
+            for (int64_t s = 0; s < n_slices; s++)
+                if (s_shared[(size_t)s]) units_shared += std::min<int64_t>(RPS, n_units - s * RPS);
+            if (units_shared * 10 >= n_units * 9)
+                for (int64_t s = 0; s < n_slices; s++) s_shared[(size_t)s] = 1;
+        }
+        for (int64_t s = 0; s < n_slices; s++) {
+            if (!s_shared[(size_t)s]) continue;
+            const int real = (int)std::min<int64_t>(RPS, n_units - s * RPS);
+            for (int i = 0; i < real; i++) {
+                const int32_t p = pat[(size_t)units[(size_t)(s * RPS + i)][0]];
+                pat_quads[(size_t)p] = std::max(pat_quads[(size_t)p], (s_max[(size_t)s] + 3) / 4);
+            }
+        }
+        // pass 2: storage.  Padding = (zero feature, 0.0f).
+        B.colpool.assign(4, zero_byte);
+        std::vector<int64_t> pat_cq(pat_rep.size(), -1);         // column quad offset of a pattern stored once
+        int64_t vq = 0;                                          // running value-quad offset, in units of RPS * R quads
+        for (int64_t s = 0; s < n_slices; s++) {
+            const int nq = (s_max[(size_t)s] + 3) / 4;
+            const int real = (int)std::min<int64_t>(RPS, n_units - s * RPS);
+            const size_t v0 = B.vals.size();
+            B.vals.resize(v0 + (size_t)nq * RPS * R * 4, 0.0f);
+            for (int i = 0; i < real; i++)
+                for (int rr = 0; rr < R; rr++) {
+                    const int32_t r = units[(size_t)(s * RPS + i)][(size_t)rr];
+                    if (r < 0) continue;
+                    const int32_t rs = ip[(size_t)r];
+                    const int len = len_of(r);
+                    for (int k = 0; k < len; k++) B.vals[v0 + ((((size_t)(k >> 2) * RPS + (size_t)i) * R + (size_t)rr) * 4) + (size_t)(k & 3)] = dt[(size_t)(rs + k)];
+                }
+            int cstride = 1;
+            if (s_shared[(size_t)s]) {
+                for (int i = 0; i < RPS; i++) {
+                    const size_t o = (size_t)(s * RPS + i);
+                    if (i >= real) {                             // empty slots of the last slice read along with a real row's pattern (their values are 0)
+                        B.lane_meta[4 * o + 1] = B.lane_meta[4 * (size_t)(s * RPS) + 1];
+                        continue;
+                    }
+                    const int32_t r = units[o][0];
+                    const int32_t p = pat[(size_t)r];
+                    if (pat_cq[(size_t)p] < 0) {
+                        pat_cq[(size_t)p] = (int64_t)B.colpool.size() / 4;
+                        const int32_t rs = ip[(size_t)r];
+                        const int len = len_of(r);
+                        const size_t c0 = B.colpool.size();
+                        B.colpool.resize(c0 + (size_t)std::max(pat_quads[(size_t)p], 1) * 4, zero_byte);
+                        for (int k = 0; k < len; k++) B.colpool[c0 + (size_t)k] = off(ix[(size_t)(rs + k)]);
+                    }
+                    B.lane_meta[4 * o + 1] = (int32_t)pat_cq[(size_t)p];
+                }
+            } else {
+                cstride = RPS;
+                const size_t c0 = B.colpool.size();
+                B.colpool.resize(c0 + (size_t)std::max(nq, 1) * RPS * 4, zero_byte);
+                for (int i = 0; i < real; i++) {
+                    const int32_t r = units[(size_t)(s * RPS + i)][0];
+                    const int32_t rs = ip[(size_t)r];
+                    const int len = len_of(r);
+                    for (int k = 0; k < len; k++) B.colpool[c0 + ((size_t)(k >> 2) * RPS + (size_t)i) * 4 + (size_t)(k & 3)] = off(ix[(size_t)(rs + k)]);
+                }
+                for (int i = 0; i < RPS; i++) B.lane_meta[4 * (size_t)(s * RPS + i) + 1] = (int32_t)(c0 / 4 + (size_t)i);
+            }
+            B.info[(size_t)(4 * s + 0)] = nq;
+            B.info[(size_t)(4 * s + 1)] = cstride;
+            B.info[(size_t)(4 * s + 2)] = (int32_t)vq;
+            vq += nq;
+        }
+        B.vals.resize(B.vals.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * R * 4, 0.0f);     // requests run past a slice's (and the array's) last quad: readable, never used
+        B.pool_quads = B.colpool.size() / 4 + 3;                                           // what is staged: the patterns + the three quads a walk requests ahead
+        B.colpool.resize(B.colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
+        // thin layer: two wavefronts per slice fit the workgroup, every slice on shared patterns, a walk long enough to be bound by one wavefront's
+        // instruction issue, a column pool of a few KB (staged twice)
+        B.thin = n_slices >= 1 && 2 * n_slices <= CHAIN_THREADS / 64 && B.pool_quads * 16 <= CHAIN_THIN_POOL_BYTES;
+        B.all_shared = n_slices >= 1;
+        for (int64_t s = 0; s < n_slices; s++) {
+            B.thin = B.thin && s_shared[(size_t)s];
+            B.all_shared = B.all_shared && s_shared[(size_t)s];
+            B.longest = std::max(B.longest, s_max[(size_t)s]);
+        }
+        return B;
+    };
+    Built B = build(1);
+    // (chain_create drops either choice when the staging area does not fit beside the activations)
+    int32_t cols_quads = (B.thin && B.longest >= 64) ? (int32_t)B.pool_quads : (B.all_shared && !tune.chain_no_cl) ? -(int32_t)B.pool_quads : 0;
+    if ((cols_quads > 0 ? 2 * (size_t)cols_quads : (size_t)(-(int64_t)cols_quads)) > room_quads) cols_quads = 0;      // no room for the pool: columns from memory (general walk)
+    int rpl = 1;
+    if (cols_quads < 0 && !tune.chain_no_rpl2) {
+        // Two rows per lane for a pattern layer whose patterns mostly hold two rows or more (the output channels of a conv pixel): halves the LDS reads
+        // per multiply-add (see chain_rows_cl).  Not when it would leave fewer slices than wavefronts of work worth having (a thin layer stays thin).
+        int64_t paired = 0;
+        {
+            std::vector<int32_t> cnt(pat_rep.size(), 0);
+            for (int64_t r = 0; r < rows; r++) cnt[(size_t)pat[(size_t)r]]++;
+            for (int32_t n : cnt) paired += n / 2 * 2;
+        }
+        if (paired * 10 >= rows * 9 && rows >= 2 * RPS * 8) {
+            Built B2 = build(2);
+            if (B2.pool_quads <= room_quads) {
+                B = std::move(B2);
+                cols_quads = -(int32_t)B.pool_quads;
+                rpl = 2;
+            }
+        }
     }
-    vals.resize(vals.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, 0.0f);       // requests run past a slice's (and the array's) last quad: readable, never used
-    const size_t pool_quads = colpool.size() / 4 + 2;                               // what a thin layer stages: the patterns + the two quads its walk requests ahead
-    colpool.resize(colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
-    L.n_slices = (int32_t)n_slices;
+    L.n_slices = (int32_t)B.n_slices;
     L.n_rows = (int32_t)rows;
     L.relu = relu;
-    // thin layer: two wavefronts per slice fit the workgroup, every slice on shared patterns, a walk long enough to be bound by one wavefront's
-    // instruction issue, a column pool of a few KB (staged twice)
-    bool thin = n_slices >= 1 && 2 * n_slices <= CHAIN_THREADS / 64 && pool_quads * 16 <= CHAIN_THIN_POOL_BYTES;
-    int longest = 0;
-    for (int64_t s = 0; s < n_slices; s++) {
-        thin = thin && s_shared[(size_t)s];
-        longest = std::max(longest, s_max[(size_t)s]);
-    }
-    bool all_shared = n_slices >= 1;
-    for (int64_t s = 0; s < n_slices; s++) all_shared = all_shared && s_shared[(size_t)s];
-    // (chain_create drops either choice when the staging area does not fit beside the activations)
-    L.cols_quads = (thin && longest >= 64) ? (int32_t)pool_quads : (all_shared && !tune.chain_no_cl) ? -(int32_t)pool_quads : 0;
+    L.cols_quads = cols_quads;
+    L.rpl = rpl;
+    L.stage_off = 0;
+    L.early = 0;
     int rc;
-    if ((rc = chain_upload(c, &L.vals, vals)) || (rc = chain_upload(c, &L.cols, colpool)) || (rc = chain_upload(c, &L.lane_meta, lane_meta)) ||
-        (rc = chain_upload(c, &L.slice_info, info)))
+    if ((rc = chain_upload(c, &L.vals, B.vals)) || (rc = chain_upload(c, &L.cols, B.colpool)) || (rc = chain_upload(c, &L.lane_meta, B.lane_meta)) ||
+        (rc = chain_upload(c, &L.slice_info, B.info)))
         return rc;
     return KN_OK;
 }
@@ -766,7 +933,7 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
             KN_HIP(hipMemcpy(dt.data(), A.data, sizeof(float) * dt.size(), hipMemcpyDeviceToHost));
         }
         int rc = chain_build_layer(c.get(), c->args.L[l], A.rows, A.cols, ip, ix, dt, (flags && (flags[l] & KN_FLAG_RELU)) ? 1 : 0,
-                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])), A.tune);
+                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])), A.tune, (CHAIN_LDS_BYTES - lds) / 16);
         if (rc) return rc;
     }
     c->args.n_layers = (int32_t)n_ops;
@@ -774,16 +941,33 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     c->args.n_out = (int32_t)ops[n_ops - 1]->rows;
     c->args.buf1_off = (int32_t)feat[0];
     c->args.zero_off = (int32_t)(feat[0] + feat[1]);
-    c->args.cols_off = (int32_t)(feat[0] + feat[1] + 1);
-    // one staging area for the column pools, reused layer after layer (thin layers hold two copies); a layer whose pool does not fit beside
-    // the activations reads its columns from memory (general walk)
-    size_t stage_quads = 0;
+    // Staging areas of the column pools, behind the activations.  A layer whose pool does not fit beside the activations reads its columns from memory
+    // (general walk).  A pool is staged EARLY -- while the previous layer runs (layer 0: with the input) -- when it can have an area that layer does not
+    // read: the base area when the previous layer has no pool, else right behind the previous layer's area when that still fits.
+    const size_t base4 = feat[0] + feat[1] + 1;                   // float4 index
+    const size_t limit4 = CHAIN_LDS_BYTES / 16;
+    size_t stage_end4 = base4;
+    size_t prev_end4 = base4;                                      // end of the area the previous layer reads (base4: none)
     for (int64_t l = 0; l < n_ops; l++) {
         ChainLayerArg& L = c->args.L[l];
         const size_t need = L.cols_quads > 0 ? 2 * (size_t)L.cols_quads : (size_t)(-(int64_t)L.cols_quads);
-        if (lds + need * 16 > CHAIN_LDS_BYTES) L.cols_quads = 0;
-        else stage_quads = std::max(stage_quads, need);
+        if (need == 0) {
+            prev_end4 = base4;
+            continue;
+        }
+        KN_REQUIRE(base4 + need <= limit4, KN_ERR_INVALID, "internal: a column pool larger than the room chain_build_layer was given");
+        const bool small = !ops[l]->csr.tune.chain_no_early;      // (name kept: every pool qualifies for early staging)
+        if (small && prev_end4 + need <= limit4) {
+            L.stage_off = (int32_t)prev_end4;
+            L.early = 1;
+        } else {
+            L.stage_off = (int32_t)base4;
+            L.early = (small && prev_end4 == base4) ? 1 : 0;
+        }
+        prev_end4 = (size_t)L.stage_off + need;
+        stage_end4 = std::max(stage_end4, prev_end4);
     }
+    const size_t stage_quads = stage_end4 - base4;
     c->lds_bytes = lds + stage_quads * 16;
     KN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)CHAIN_LDS_BYTES));
     *rows_out = ops[n_ops - 1]->rows;
@@ -813,15 +997,16 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
         if (n_stamps > (size_t)grid * 16) a.wstamps = a.stamps + (size_t)grid * 16;
     }
 #endif
-    int n_thin = 0;
-    int n_cl = 0;
+    int n_thin = 0, n_cl = 0, n_rpl2 = 0, n_early = 0;
     for (int l = 0; l < a.n_layers; l++) {
         n_thin += a.L[l].cols_quads > 0 ? 1 : 0;
         n_cl += a.L[l].cols_quads < 0 ? 1 : 0;
+        n_rpl2 += a.L[l].rpl == 2 ? 1 : 0;
+        n_early += (a.L[l].cols_quads != 0 && a.L[l].early) ? 1 : 0;
     }
     const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk, " + std::to_string(n_cl) +
-                          " with column patterns in LDS), 4 batch columns per workgroup, " +
-                          std::to_string(c->lds_bytes) + " B LDS>";
+                          " with column patterns in LDS), " + std::to_string(n_rpl2) + " with two rows per lane, " + std::to_string(n_early) +
+                          " column pools staged a layer early, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
     else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
     KN_HIP(hipGetLastError());

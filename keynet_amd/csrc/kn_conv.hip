@@ -317,9 +317,10 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     // read back with v_readlane).
     uint32_t a_voff = 0, b_voff = 0;
     int dtab_a_lo = 0, dtab_a_hi = 0, dtab_b_lo = 0, dtab_b_hi = 0;
-    int g_slot = 0;
-    int st_slot = 0;                                  // slot of the chunk the next LDS store writes (non-unit coefficients)
-    float ctab = 1.0f;                                // lane s: coefficient of slot s
+    int g_slot = 0;                                   // the loader's position inside its current GROUP of <= 64 slots (lane s of the tables = slot g_base + s)
+    int g_base = 0, g_n = 0, g_row = 0;               // first slot / size of that group, channel chunk the loader is in
+    float cf_pend = 1.0f;                             // coefficient of the chunk most recently requested (= the one the next LDS store writes)
+    float ctab = 1.0f;                                // lane s: coefficient of slot g_base + s
     const int n_slots_u = __builtin_amdgcn_readfirstlane(n_slots);
     auto uni64 = [](const char* q) {                 // readfirstlane on an already-scalar value is free; it keeps loop-carried pointers in SGPR pairs
         const uint64_t v = reinterpret_cast<uint64_t>(q);
@@ -329,32 +330,49 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     constexpr int ARL = 1024 / MT, BRL = 1024 / NB;
     const char* sa[AL];
     const char* sb[BL];
-    if constexpr (SPTR) {
-        static_assert(A4 % 256 == 0 && B4 % 256 == 0, "whole load instructions");
-        if (lane < n_slots) {
-            const int nxt = (lane + 1 < n_slots) ? lane + 1 : 0;
-            const int64_t wrap_a = (lane + 1 < n_slots) ? 0 : a_step, wrap_b = (lane + 1 < n_slots) ? 0 : b_step;
-            const int64_t d_a = 4 * ((int64_t)(p.slot_tap[s_beg + nxt] - p.slot_tap[s_beg + lane]) * p.cin_pad * p.cout_pad + wrap_a);
-            const int64_t d_b = 4 * ((int64_t)(p.slot_in[s_beg + nxt] - p.slot_in[s_beg + lane]) * p.ldx + wrap_b);
+    // Slot GROUPS (round 5: fill-in-aware loaders).  A pixel with more than 64 slots -- keys whose inverse fills a block in: a doubly-stochastic key leaves
+    // 500 .. 5 400 slots per output pixel of keyed VGG-16 -- is walked group by group, slot GROUP outermost: for each group of <= 64 slots, channel chunk
+    // outer / slot inner as before (the order of a re-ordered f32 sum is free under the matrix-core contract), the tables of the next group loaded when the
+    // loader has requested the group's last chunk.  One group (<= 64 slots: permutation, Givens, gain keys) is the round-2 walk, instruction for instruction.
+    auto sptr_group = [&](const int base) {           // lane s: byte deltas from slot base + s to the next chunk's tiles, and its coefficient
+        g_base = base;
+        g_n = (n_slots_u - base) < 64 ? (n_slots_u - base) : 64;
+        g_slot = 0;
+        g_row = 0;
+        if (lane < g_n) {
+            const int nxt = (lane + 1 < g_n) ? lane + 1 : 0;
+            const int64_t wrap_a = (lane + 1 < g_n) ? 0 : a_step, wrap_b = (lane + 1 < g_n) ? 0 : b_step;
+            const int64_t d_a = 4 * ((int64_t)(p.slot_tap[s_beg + base + nxt] - p.slot_tap[s_beg + base + lane]) * p.cin_pad * p.cout_pad + wrap_a);
+            const int64_t d_b = 4 * ((int64_t)(p.slot_in[s_beg + base + nxt] - p.slot_in[s_beg + base + lane]) * p.ldx + wrap_b);
             dtab_a_lo = (int)(uint32_t)d_a;
             dtab_a_hi = (int)(d_a >> 32);
             dtab_b_lo = (int)(uint32_t)d_b;
             dtab_b_hi = (int)(d_b >> 32);
-            if (!p.unit_coef) ctab = p.slot_coef[s_beg + lane];
+            if (!p.unit_coef) ctab = p.slot_coef[s_beg + base + lane];
         }
+        const int64_t tap0 = __builtin_amdgcn_readfirstlane(p.slot_tap[s_beg + base]);
+        const int64_t in0 = __builtin_amdgcn_readfirstlane(p.slot_in[s_beg + base]);
+#pragma unroll
+        for (int i = 0; i < AL; i++) sa[i] = uni64(reinterpret_cast<const char*>(p.tapsT + m0 + (tap0 * p.cin_pad + (int64_t)i * ARL) * p.cout_pad));
+#pragma unroll
+        for (int i = 0; i < BL; i++) sb[i] = uni64(reinterpret_cast<const char*>(p.X + b0 + ((int64_t)i * BRL * p.HiWi + in0) * p.ldx));
+    };
+    if constexpr (SPTR) {
+        static_assert(A4 % 256 == 0 && B4 % 256 == 0, "whole load instructions");
         a_voff = 4u * (uint32_t)((tid / (MT / 4)) * p.cout_pad + (tid % (MT / 4)) * 4);
         b_voff = 4u * (uint32_t)((int64_t)(tid / (NB / 4)) * p.HiWi * p.ldx + (tid % (NB / 4)) * 4);      // < 2^31: checked by the launcher
-        if (n_slots > 0) {
-            const int64_t tap0 = __builtin_amdgcn_readfirstlane(p.slot_tap[s_beg]);
-            const int64_t in0 = __builtin_amdgcn_readfirstlane(p.slot_in[s_beg]);
-#pragma unroll
-            for (int i = 0; i < AL; i++) sa[i] = uni64(reinterpret_cast<const char*>(p.tapsT + m0 + (tap0 * p.cin_pad + (int64_t)i * ARL) * p.cout_pad));
-#pragma unroll
-            for (int i = 0; i < BL; i++) sb[i] = uni64(reinterpret_cast<const char*>(p.X + b0 + ((int64_t)i * BRL * p.HiWi + in0) * p.ldx));
-        }
+        if (n_slots > 0) sptr_group(0);
     }
+    bool g_switch = false;                            // the loader has requested its group's last chunk: the next call starts with the next group's tables
     auto sptr_load = [&]() {                          // SPTR: the next chunk's tiles -> ra / rb, saddr form; then the scalar pointer walk
         if constexpr (SPTR) {
+            // (the tables are replaced HERE, before this chunk's loads are issued and after the previous chunk's have been consumed -- never with tile loads
+            // in flight: vector code between an asm-issued load and its wait invites the compiler to copy a destination register that has not landed yet,
+            // tests/test_isa_lint.py.  One memory round trip, once per 64 * cpk chunks.)
+            if (g_switch) {
+                sptr_group(g_base + g_n < n_slots_u ? g_base + g_n : 0);
+                g_switch = false;
+            }
             if (!KN_ABL(p, 5)) {
 #pragma unroll
                 for (int i = 0; i < AL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(ra[i]) : "v"(a_voff), "s"(reinterpret_cast<uint64_t>(sa[i])));
@@ -364,13 +382,17 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
                 for (int i = 0; i < BL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[i]) : "v"(b_voff), "s"(reinterpret_cast<uint64_t>(sb[i])));
             }
             if (KN_ABL(p, 4)) return;
+            if (!p.unit_coef) cf_pend = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), g_slot));
             const int64_t da = ((int64_t)__builtin_amdgcn_readlane(dtab_a_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_a_lo, g_slot);
             const int64_t db = ((int64_t)__builtin_amdgcn_readlane(dtab_b_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_b_lo, g_slot);
+            const bool wrap = (g_slot + 1 == g_n);
+            g_slot = wrap ? 0 : g_slot + 1;
+            g_row = wrap ? g_row + 1 : g_row;
+            g_switch = n_slots_u > 64 && wrap && g_row == cpk;       // (wave-uniform; a single group never switches: the round-2 walk)
 #pragma unroll
             for (int i = 0; i < AL; i++) sa[i] = uni64(sa[i] + da);
 #pragma unroll
             for (int i = 0; i < BL; i++) sb[i] = uni64(sb[i] + db);
-            g_slot = (g_slot + 1 == n_slots_u) ? 0 : g_slot + 1;
         }
     };
     auto sptr_landed = [&]() {                        // the asm loads are invisible to the compiler's vmcnt bookkeeping: explicit wait
@@ -411,10 +433,9 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             // float keys whose entries carry a coefficient (photometric gains: a_out[o] / a_in[i] per (output, input) pixel pair): the
             // activation tile of the chunk is scaled by its slot's coefficient on the way to LDS, as the generic loader does per element
             if (!p.unit_coef) {
-                const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), st_slot));
+                const float cf = cf_pend;              // (recorded when the chunk was requested: exactly one chunk waits in registers at a time)
 #pragma unroll
                 for (int i = 0; i < BL; i++) rb[i] = rb[i] * cf;
-                st_slot = (st_slot + 1 == n_slots_u) ? 0 : st_slot + 1;
             }
         }
         float* a = As + buf * KC * MT;
@@ -1244,9 +1265,15 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // read back with v_readlane), step q+1's activation row (16 B per lane) and its RBX tap values (one s_load) are issued
 // before step q's 2*RBX packed multiplies / adds, so neither latency is exposed -- the generic kernel above waits
 // vmcnt(0) on every step.  RBX = 16 output channels per wavefront halves the activation gathers per MAC.
-template <int RBX, bool COEF = false, int XD = 2>       // XD = activation rows in flight per wavefront (2, or 4 for wide batches: see the launcher)
+// VEC = batch columns per lane: 4 (a wavefront covers 256 columns, 16-byte row loads) or 2 (128 columns, 8-byte loads: the half-batch windows of the
+// overlapped forward at 256 images, and batches that fill 128-column tiles better than 256-column ones).  Same instruction count per MAC either way
+// (one packed multiply and one packed add per output channel and column pair); what VEC = 2 halves is the work per wavefront -- finer balance.
+template <int RBX, bool COEF = false, int XD = 2, int VEC = 4>       // XD = activation rows in flight per wavefront (2, or 4 for wide batches: see the launcher)
 __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, int n_cob, int64_t n_rb) {
-    const int64_t n_ct = (p.n_vecs + 255) / 256;
+    static_assert(VEC == 4 || VEC == 2, "two or four batch columns per lane");
+    constexpr int NP = VEC / 2;                                           // column pairs per lane
+    typedef float xrow_t __attribute__((ext_vector_type(VEC)));
+    const int64_t n_ct = (p.n_vecs + 64 * VEC - 1) / (64 * VEC);
     const int64_t n_items = n_ct * n_rb;
     const int64_t chunk = (n_items + 7) >> 3;
     const int64_t xl = blockIdx.x & 7;
@@ -1271,14 +1298,16 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     const int co0 = __builtin_amdgcn_readfirstlane((cg * G + (int)(rem % G)) * RBX);
     const int s_beg = __builtin_amdgcn_readfirstlane(p.pix_ptr[o]);
     const int n_slots = __builtin_amdgcn_readfirstlane(p.pix_ptr[o + 1]) - s_beg;
-    const int64_t c = ct * 256 + (int64_t)lane * 4;
+    const int64_t c = ct * (64 * VEC) + (int64_t)lane * VEC;
     const bool active = c < p.n_vecs;
     const uint32_t lane_off_bytes = 4u * (uint32_t)(active ? c : 0);      // byte offset: (uniform base) + zext(VGPR) selects the saddr load form
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc[RBX][2];                                                    // [output channel][columns 0-1 | 2-3]
+    f32x2 acc[RBX][NP];                                                   // [output channel][columns 0-1 | 2-3]
 #pragma unroll
-    for (int r = 0; r < RBX; r++) acc[r][0] = acc[r][1] = f32x2{0.f, 0.f};
+    for (int r = 0; r < RBX; r++)
+#pragma unroll
+        for (int h = 0; h < NP; h++) acc[r][h] = f32x2{0.f, 0.f};
 
     if (n_slots > 0) {
         // lane s: element offsets of slot s (32-bit: the launcher checks the ranges)
@@ -1301,10 +1330,11 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         // not see these loads; the waits are written out below.  Each fetch advances its cursor, branch-free (selects on wave-uniform
         // values, all on the scalar ALU); past the end the last step's operands are fetched again, so the waits stay counted ones.
         typedef float taps_t __attribute__((ext_vector_type(RBX)));
-        auto fetch_x = [&](f32x4& xr) {
+        auto fetch_x = [&](xrow_t& xr) {
             const int xo = __builtin_amdgcn_readlane(my_xoff, s) + ci_x;
             const uint64_t xaddr = reinterpret_cast<uint64_t>(p.X + xo);
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
+            if constexpr (VEC == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
+            else asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(xr) : "v"(lane_off_bytes), "s"(xaddr));
             q_next++;
             const bool more = q_next < n_q;
             const bool wrap = (s + 1 == n_slots);
@@ -1326,60 +1356,95 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
         auto advance = [&]() {};                                 // (the fetches advance their own cursors)
         // the "+" operands make the multiplies that follow depend on the wait
         auto taps_landed = [&](taps_t& ar) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ar)); };
-        auto row_landed = [&](f32x4& xr, auto younger) {                 // vector loads return in order
+        auto row_landed = [&](xrow_t& xr, auto younger) {                 // vector loads return in order
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(decltype(younger)::value));
         };
         // acc[r] += x * av[r] (separate IEEE multiply and add).  The packed multiply reads an aligned SGPR pair and broadcasts its low
         // or high half with op_sel, so one pair serves two output channels.  The instruction order is pinned (volatile asm): the four
         // multiplies of channel pair k are followed by the four adds of pair k-1, so no add waits on the multiply right in front of it
         // (left to itself the scheduler serialises "mul, add, mul, add" through one temporary in the second half of the loop body).
-        auto mul4 = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, f32x2 (&pr)[4]) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "s"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "s"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "s"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "s"(a2));
+        // mul4: the four products of ONE channel pair (VEC = 4: two column pairs x two channels) or of TWO channel pairs (VEC = 2: one column pair x
+        // four channels); add4 adds them to their running sums.  `r` is the first of the 2 (VEC = 4) or 4 (VEC = 2) channels a call covers.
+        auto mul4 = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, const f32x2& b2, f32x2 (&pr)[4]) {
+            if constexpr (VEC == 4) {
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "s"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "s"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "s"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "s"(a2));
+            } else {
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "s"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[1]) : "v"(xlo), "s"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[2]) : "v"(xlo), "s"(b2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xlo), "s"(b2));
+            }
         };
         auto add4 = [&](int r, const f32x2 (&pr)[4]) {
-            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(pr[0]));
-            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][1]) : "v"(pr[1]));
-            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[2]));
-            asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][1]) : "v"(pr[3]));
+            if constexpr (VEC == 4) {
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(pr[0]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][NP - 1]) : "v"(pr[1]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[2]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][NP - 1]) : "v"(pr[3]));
+            } else {
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r][0]) : "v"(pr[0]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 1][0]) : "v"(pr[1]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 2][0]) : "v"(pr[2]));
+                asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[r + 3][0]) : "v"(pr[3]));
+            }
         };
         // COEF (float keys whose entries carry a coefficient): the stored non-zero of the reference is fl(coef * tap) -- one more packed
         // multiply per channel pair, tap pair (SGPR) x the step's coefficient (broadcast from a VGPR pair's low half), and the products
         // are then formed from that VGPR pair.
-        auto mul4v = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, f32x2 (&pr)[4]) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "v"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "v"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "v"(a2));
-            asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "v"(a2));
+        auto mul4v = [&](const f32x2& xlo, const f32x2& xhi, const f32x2& a2, const f32x2& b2, f32x2 (&pr)[4]) {
+            if constexpr (VEC == 4) {
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "v"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[1]) : "v"(xhi), "v"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[2]) : "v"(xlo), "v"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xhi), "v"(a2));
+            } else {
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[0]) : "v"(xlo), "v"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[1]) : "v"(xlo), "v"(a2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(pr[2]) : "v"(xlo), "v"(b2));
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(pr[3]) : "v"(xlo), "v"(b2));
+            }
         };
-        auto mac = [&](const f32x4& xv, const taps_t& av, const float cf) {
-            const f32x2 xlo = {xv.x, xv.y}, xhi = {xv.z, xv.w};
+        auto mac = [&](const xrow_t& xv, const taps_t& av, const float cf) {
+            const f32x2 xlo = {xv[0], xv[1]}, xhi = {xv[VEC - 2], xv[VEC - 1]};
             f32x2 pa[4], pb[4];
+            constexpr int CH = (VEC == 4) ? 2 : 4;                       // channels per mul4 / add4
             if constexpr (COEF) {
                 const f32x2 cf2 = {cf, cf};
-                f32x2 sa, sb;
+                f32x2 sa, sb, sc, sd;
 #pragma unroll
-                for (int r = 0; r < RBX; r += 4) {
+                for (int r = 0; r < RBX; r += 2 * CH) {
                     asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sa) : "s"(f32x2{av[r], av[r + 1]}), "v"(cf2));
                     asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sb) : "s"(f32x2{av[r + 2], av[r + 3]}), "v"(cf2));
-                    if (r > 0) add4(r - 2, pb);
-                    mul4v(xlo, xhi, sa, pa);
-                    mul4v(xlo, xhi, sb, pb);
+                    if constexpr (VEC == 2) {
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sc) : "s"(f32x2{av[r + 4], av[r + 5]}), "v"(cf2));
+                        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(sd) : "s"(f32x2{av[r + 6], av[r + 7]}), "v"(cf2));
+                    }
+                    if (r > 0) add4(r - CH, pb);
+                    if constexpr (VEC == 4) {
+                        mul4v(xlo, xhi, sa, sa, pa);
+                        mul4v(xlo, xhi, sb, sb, pb);
+                    } else {
+                        mul4v(xlo, xhi, sa, sb, pa);
+                        mul4v(xlo, xhi, sc, sd, pb);
+                    }
                     add4(r, pa);
                 }
-                add4(RBX - 2, pb);
+                add4(RBX - CH, pb);
                 return;
             }
 #pragma unroll
-            for (int r = 0; r < RBX; r += 4) {
-                mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, pa);
-                if (r > 0) add4(r - 2, pb);
-                mul4(xlo, xhi, f32x2{av[r + 2], av[r + 3]}, pb);
+            for (int r = 0; r < RBX; r += 2 * CH) {
+                if constexpr (VEC == 4) mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, f32x2{av[r], av[r + 1]}, pa);
+                else mul4(xlo, xhi, f32x2{av[r], av[r + 1]}, f32x2{av[r + 2], av[r + 3]}, pa);
+                if (r > 0) add4(r - CH, pb);
+                if constexpr (VEC == 4) mul4(xlo, xhi, f32x2{av[r + 2], av[r + 3]}, f32x2{av[r + 2], av[r + 3]}, pb);
+                else mul4(xlo, xhi, f32x2{av[r + 4], av[r + 5]}, f32x2{av[r + 6], av[r + 7]}, pb);
                 add4(r, pa);
             }
-            add4(RBX - 2, pb);
+            add4(RBX - CH, pb);
         };
         // Two steps per trip, operands double-buffered.  Step q+1's tap load is issued right after step q's taps have landed (scalar
         // loads return out of order, so lgkmcnt can only be waited to zero) and its activation row right after that; both have step q's
@@ -1388,7 +1453,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             // FOUR activation rows in flight (wide batches: a gathered row of a [D, 4096] block misses L2 -- the grouped CSR pipeline's finding),
             // tap values one step ahead as before.  One step: this step's taps have landed -> request the next step's -> wait for this step's
             // row (three younger rows stay in flight) -> arithmetic -> request the row four steps ahead into the register just released.
-            f32x4 x0, x1, x2, x3;
+            xrow_t x0, x1, x2, x3;
             taps_t a0, a1;
             float c0 = 1.0f, c1 = 1.0f;
             fetch_x(x0);
@@ -1396,7 +1461,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             fetch_x(x2);
             fetch_x(x3);
             fetch_a(a0, c0);
-            auto step4 = [&](const int q, f32x4& xq, taps_t& aq, float& cq, taps_t& an, float& cn) {
+            auto step4 = [&](const int q, xrow_t& xq, taps_t& aq, float& cq, taps_t& an, float& cn) {
                 taps_landed(aq);
                 fetch_a(an, cn);
                 row_landed(xq, std::integral_constant<int, 3>());
@@ -1413,7 +1478,7 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
             }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+s"(a0));
         } else {
-        f32x4 x0, x1;
+        xrow_t x0, x1;
         taps_t a0, a1;
         float c0 = 1.0f, c1 = 1.0f;
         fetch_x(x0);
@@ -1445,28 +1510,30 @@ __global__ __launch_bounds__(256) void convtaps_exact_pipe_kernel(ConvArgs p, in
     }
     if (!active) return;
     const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
-    f32x4 xl4 = {0.f, 0.f, 0.f, 0.f};
-    if (xlast) xl4 = *reinterpret_cast<const f32x4*>(xlast);
+    xrow_t xl4;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) xl4[v] = 0.f;
+    if (xlast) xl4 = *reinterpret_cast<const xrow_t*>(xlast);
 #pragma unroll
     for (int r = 0; r < RBX; r++) {
         const int m = co0 + r;
         if (m >= p.Cout) continue;
         const int64_t row = (int64_t)m * p.HoWo + o;
-        f32x4 t = {acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y};
+        xrow_t t;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) t[v] = acc[r][v / 2][v % 2];
         if (xlast) {
             const float lc = p.lastcol[row];
             if (lc != 0.0f) {
-                const f32x4 bp = xl4 * lc;
+                const xrow_t bp = xl4 * lc;
                 t = t + bp;
             }
         }
         if (p.relu) {
-            t.x = (t.x < 0.0f) ? 0.0f : t.x;
-            t.y = (t.y < 0.0f) ? 0.0f : t.y;
-            t.z = (t.z < 0.0f) ? 0.0f : t.z;
-            t.w = (t.w < 0.0f) ? 0.0f : t.w;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) t[v] = (t[v] < 0.0f) ? 0.0f : t[v];
         }
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p.Y + row * p.ldy + c));      // the output is not re-read by this launch (conv1_1: 1.33 -> 1.11 ms)
+        __builtin_nontemporal_store(t, reinterpret_cast<xrow_t*>(p.Y + row * p.ldy + c));      // the output is not re-read by this launch (conv1_1: 1.33 -> 1.11 ms)
     }
 }
 
@@ -1587,7 +1654,7 @@ static void launch_conv(ConvArgs a, const Tuning& tune, hipStream_t s) {
     // scalar-pointer loaders (MODE 2): 16-row chunks of whole channels, a thread's offsets inside one chunk in 31 bits.  Tuning::no_sptr
     // (KN_NO_SPTR=1 when the operator is created) keeps the other loaders for the parity tests' side-by-side.
     bool sptr = false;
-    const bool fast_shape = a.vec_ok && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) && a.max_slots <= MAX_FAST_SLOTS &&
+    const bool fast_shape = a.vec_ok && (a.n_vecs % NB == 0) && ((int64_t)KC * a.HiWi * a.ldx < (int64_t)1 << 31) &&      // (any number of slots per pixel: slot groups)
                             (int64_t)a.HiWi * a.ldx < (int64_t)1 << 31 && (int64_t)a.ntaps * a.cin_pad * a.cout_pad < (int64_t)1 << 31;
     if constexpr (KC == 16) sptr = fast_shape && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && !tune.no_sptr;
     a.tail_main = (int32_t)chunk;
@@ -1737,10 +1804,16 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.tail_main = 0;
     if (flags & KN_FLAG_EXACT) {
         const bool v4 = a.vec_ok && n_vecs >= 256;
-        const int64_t n_ct = v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64;
         const int pipe_mode = A.tune.exact_pipe;
-        const bool pipe = pipe_mode > 0 && v4 && !A.has_dups && A.max_slots <= 64 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0 &&
-                          (a.last_in_row + 1) * ldx < ((int64_t)1 << 31) && (int64_t)A.ntaps * A.cin_pad * A.cout_pad < ((int64_t)1 << 31);
+        const bool pipe_shape = pipe_mode > 0 && !A.has_dups && A.max_slots <= 64 && (a.last_in_row + 1) * ldx < ((int64_t)1 << 31) &&
+                                (int64_t)A.ntaps * A.cin_pad * A.cout_pad < ((int64_t)1 << 31);
+        const bool pipe4 = pipe_shape && v4 && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0;
+        // two batch columns per lane (128-column tiles): a half-batch window of the overlapped forward at 256 images, or a batch that fills 128-column
+        // tiles better than 256-column ones (384 images).  Tuning::exact_vec = 2 | 4 forces either where both apply (diagnostic build).
+        const bool pipe2_ok = pipe_shape && n_vecs >= 128 && n_vecs % 2 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && ((uintptr_t)x) % 8 == 0 && ((uintptr_t)y) % 8 == 0;
+        const bool pipe2 = pipe2_ok && (A.tune.exact_vec == 2 || (A.tune.exact_vec != 4 && (!pipe4 || (n_vecs + 127) / 128 * 128 < (n_vecs + 255) / 256 * 256)));
+        const bool pipe = pipe4 || pipe2;
+        const int64_t n_ct = pipe2 ? (n_vecs + 127) / 128 : (v4 ? (n_vecs + 255) / 256 : (n_vecs + 63) / 64);
         // 16 output channels per wavefront when that still leaves every SIMD several wavefronts, else 8
         const int rbx = (pipe && pipe_mode >= 16 && A.Cout % 16 == 0 && (int64_t)a.n_pix * (A.Cout / 16) * n_ct >= 4096) ? 16 : 8;
         const int n_cob = (int)((A.Cout + rbx - 1) / rbx);
@@ -1774,7 +1847,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         if (table) {
             // (launched above)
         } else
-        if (pipe && rbx == 16 && A.unit_coef && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,rows in flight=4>", (convtaps_exact_pipe_kernel<16, false, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        if (pipe2 && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16,128-column tiles>", (convtaps_exact_pipe_kernel<16, false, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe2 && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef,128-column tiles>", (convtaps_exact_pipe_kernel<16, true, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe2 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8,128-column tiles>", (convtaps_exact_pipe_kernel<8, false, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe2) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef,128-column tiles>", (convtaps_exact_pipe_kernel<8, true, 2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (pipe && rbx == 16 && A.unit_coef && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,rows in flight=4>", (convtaps_exact_pipe_kernel<16, false, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16 && xd4) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef,rows in flight=4>", (convtaps_exact_pipe_kernel<16, true, 4>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16 && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<16>", (convtaps_exact_pipe_kernel<16>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef>", (convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);

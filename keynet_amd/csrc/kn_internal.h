@@ -143,12 +143,15 @@ struct Tuning {
     int exact_pipe = 16;      // KN_EXACT_PIPE        0 = plain exact conv kernel, 8 / 16 = channels per wavefront of the pipeline
     int exact_cob_groups = 0; // KN_EXACT_COB_GROUPS  (0: the rule)
     int exact_xd = 0;         // KN_EXACT_XD          2 | 4 activation rows in flight (0: the rule)
+    int exact_vec = 0;        // KN_EXACT_VEC         2 | 4 batch columns per lane of the exact conv pipeline (0: the rule)
     int mf_pf = 8;            // KN_MF_PF             operand columns in flight of the matrix-pipe grouped kernel
     int table_window = 0;     // KN_TABLE_WINDOW      (0: the rule)
     int table_strip = -1;     // KN_TABLE_STRIP       (-1: best of the candidates, 0: keep the ball order)
     int no_patch = 0;         // KN_NO_PATCH
     int no_row_order = 0;     // KN_NO_ROW_ORDER
     int chain_no_cl = 0;      // KN_CHAIN_NO_CL
+    int chain_no_rpl2 = 0;    // KN_CHAIN_NO_RPL2     whole-net kernel: one output row per lane in the pattern walk
+    int chain_no_early = 0;   // KN_CHAIN_NO_EARLY    whole-net kernel: column pools staged at the start of their own layer
     int abl = 0;              // KN_ABL               kernel ablation mask (kn_conv.hip, KN_ABLATION code paths)
     std::string describe() const;   // "" when everything is at its default, else " opts{name=value,...}"
 };

@@ -162,7 +162,8 @@ def sensor_from_arrays(z, inshape=None):
     return KeyedSensor(tuple(inshape), (enc, dec))
 
 
-def save_keynet(knet, filename, sensor=None):
+def save_keynet(knet, filename, sensor=None, compress=True):
+    """`compress=False`: a plain (stored) archive -- seconds instead of minutes for a GB-sized key-net handed to other processes on one node."""
     out = {'layer_names': np.array([n for (n, _) in knet._keynet.named_children()]), 'outshape': np.array(knet._outshape, dtype=np.int64)}
     for (name, c) in knet._keynet.named_children():
         p = 'L.%s.' % name
@@ -184,7 +185,7 @@ def save_keynet(knet, filename, sensor=None):
             (out['sensor.%s.indptr' % tag], out['sensor.%s.indices' % tag], out['sensor.%s.data' % tag]) = (ip, ix, dt)
         out['sensor.shape'] = np.array(sensor._encryptkey.shape, dtype=np.int64)
         out['sensor.inshape'] = np.array(sensor._inshape[1:], dtype=np.int64)
-    np.savez_compressed(filename, **out)
+    (np.savez_compressed if compress else np.savez)(filename, **out)
     return filename
 
 

@@ -336,7 +336,10 @@ class KeyedModel(object):
                     (op, ex, ok) = (W._dense_device_op(device), False, half % 128 == 0)
                 elif isinstance(W, ksp.Conv2dTiledMatrix):
                     (op, ex) = (W._device_op(device), exact)
-                    # order-preserving conv kernels work on 256-column tiles; MFMA tiles are 128 (Cout > 64) or 256 columns wide
+                    # order-preserving conv kernels: 256-column tiles (four batch columns per lane).  They also have a 128-column form (two per lane), but
+                    # that one is 5-8 % slower per layer (round 5, same-process A/B on every VGG-16 layer shape: conv5_1 4.08 against 3.88 ms) and the
+                    # bit-exact forward of 256 images as two overlapped 128-column windows lost 11 % (1 884 against 2 107 images/s): not split.  MFMA tiles
+                    # are 128 (Cout > 64) or 256 columns wide
                     ok = (half % 256 == 0) if exact else (half % (128 if W._outshape[0] > 64 else 256) == 0)
                     with torch.cuda.device(device):          # kn_spmm_plan checks the current device like kn_spmm does
                         if contract == 'bf16x3' and 'bf16x3' in op.plan(batch, _capi.KN_FLAG_BF16X3) and 'bf16x3' not in op.plan(half, _capi.KN_FLAG_BF16X3):

@@ -16,7 +16,7 @@ S = torch.cuda.current_stream().cuda_stream
 bad = 0
 for case in range(n_cases):
     n_ops = rng.randint(1, 7)
-    dims = [int(rng.randint(1, 400)) for _ in range(n_ops + 1)]
+    dims = [int(rng.randint(1, 400)) if rng.rand() < 0.8 else int(rng.randint(1024, 2600)) for _ in range(n_ops + 1)]      # (>= 1024 rows: the two-rows-per-lane layout)
     mats = []
     for l in range(n_ops):
         (rows, cols) = (dims[l + 1], dims[l])

@@ -24,7 +24,7 @@ PIPELINED = {
 }
 
 # what an asm-issued load looks like per file (the compiler's own saddr-form dword loads in the other files are tracked by its waitcnt pass)
-ASM_LOAD = {'default': r'global_load_dwordx4 (v\[\d+:\d+\]), v\d+, s\[', 'kn_csr_mfma.hip': r'global_load_dword (v\d+), v\d+, s\['}
+ASM_LOAD = {'default': r'global_load_dwordx[24] (v\[\d+:\d+\]), v\d+, s\[', 'kn_csr_mfma.hip': r'global_load_dword (v\d+), v\d+, s\['}
 
 
 def _isa(src, tmp_path):
@@ -58,26 +58,73 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
             body = s[s.index(name + ':'):]
             body = body[:body.index('.Lfunc_end')]                # (not the first s_endpgm: an early wave-uniform return may be laid out ahead of the loops)
             lines = [l.split(';')[0].strip() for l in body.split('\n') if l.strip()]
-            # In program order: the destinations of the asm-issued loads of a loop body are "owned" from the body's first such load until its
-            # epilogue begins (= the first global store behind it: the loops themselves store nothing, and every operand has landed and been
-            # consumed by then).  A register copy out of an owned register is the bug; a copy in the epilogue of a register that merely WAS a
-            # load destination (the allocator reuses registers there: the running max of kn_spmm_screen, for one) is not.  Kernels with a
-            # quarter-tile tail hold two bodies in sequence: an asm-issued load behind an epilogue opens the next body.
-            dests = set()
-            for l in lines:
-                m = re.match(ASM_LOAD.get(src, ASM_LOAD['default']), l)
-                if m:
-                    dests |= _regs(m.group(1), 'v')
-            assert dests, name
-            in_body = False
-            for l in lines:
-                if re.match(ASM_LOAD.get(src, ASM_LOAD['default']), l):
-                    in_body = True
-                elif l.startswith('global_store') or l.startswith('buffer_store'):
-                    in_body = False
-                if in_body and (l.startswith('v_mov') or l.startswith('v_accvgpr')):
-                    srcs = ','.join(l.split(',')[1:])
-                    assert not (_regs(srcs, 'v') & dests), (name, l)
+            # Which registers are OWNED by an asm-issued load in flight, at every instruction: a forward data-flow over the kernel's code.  An asm-issued load
+            # adds its destination (youngest); an explicit `s_waitcnt vmcnt(N)` -- the waits of these kernels are written out, loads return in order -- leaves
+            # only the N youngest; the state at a label is the union of the fall-through state and of the states at every branch to it (loops: iterated to a
+            # fixed point).  A register copy (v_mov / v_accvgpr) out of an owned register is the bug.  (Until round 4 the check took every register that is
+            # EVER a load destination in the kernel as owned throughout a loop body; with more code paths per kernel the allocator re-uses such registers for
+            # constants after their loads have long landed, which that rule flagged.)
+            pat_load = re.compile(ASM_LOAD.get(src, ASM_LOAD['default']))
+            labels = {l[:-1]: i for (i, l) in enumerate(lines) if l.endswith(':')}
+            state_at = {}                                          # label -> tuple of register-sets, oldest load first
+            n_loads = sum(1 for l in lines if pat_load.match(l))
+            assert n_loads, name
+
+            def merge(x, y):                                       # union of two in-flight lists, keeping an order (longest first: conservative for counted waits)
+                (x, y) = (list(x), list(y))
+                if len(x) < len(y):
+                    (x, y) = (y, x)
+                out = list(x)
+                for (k, r) in enumerate(y):                        # align the YOUNGEST ends
+                    j = len(out) - len(y) + k
+                    out[j] = out[j] | r
+                return tuple(frozenset(r) for r in out)
+
+            changed = True
+            passes = 0
+            while changed and passes < 12:
+                changed = False
+                passes += 1
+                fly = ()
+                epilogue = False                                   # in program order, from the first store behind a loop body to the next asm-issued load
+                for (i, l) in enumerate(lines):
+                    if epilogue and not pat_load.match(l):
+                        fly = ()
+                        continue
+                    if l.endswith(':'):
+                        if l[:-1] in state_at:
+                            fly = merge(fly, state_at[l[:-1]])
+                        continue
+                    m = pat_load.match(l)
+                    if m:
+                        epilogue = False
+                        fly = fly + (frozenset(_regs(m.group(1), 'v')),)
+                        continue
+                    m = re.match(r's_waitcnt .*vmcnt\((\d+)\)', l)
+                    if m:
+                        n = int(m.group(1))
+                        fly = fly[len(fly) - n:] if n else ()
+                        continue
+                    if l.startswith('global_store') or l.startswith('buffer_store'):
+                        epilogue = True                            # an epilogue begins: the loops store nothing, every operand has landed and been consumed by then
+                        fly = ()                                   # (the analysis is path-insensitive: "no next chunk, so no load" and "no next chunk, so no wait" look
+                        continue                                   # independent to it, and an epilogue's stores sit behind branches of their own)
+                    if l.startswith('v_mov') or l.startswith('v_accvgpr'):
+                        owned = set().union(*fly) if fly else set()
+                        srcs = ','.join(l.split(',')[1:])
+                        assert not (_regs(srcs, 'v') & owned), (name, l)
+                    m = re.match(r's_c?branch\w*\s+(\S+)', l)
+                    if m and m.group(1) in labels:
+                        t = m.group(1)
+                        new = merge(state_at.get(t, ()), fly)
+                        if new != state_at.get(t, ()):
+                            state_at[t] = new
+                            changed = True
+                        if l.startswith('s_branch'):
+                            fly = ()                               # (unreachable by fall-through)
+                    if l.startswith('s_endpgm'):
+                        fly = ()
+            assert passes < 12, name
             checked += 1
     assert checked >= len(PIPELINED[src])
 

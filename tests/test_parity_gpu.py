@@ -1097,7 +1097,16 @@ def test_whole_net_kernel_layout_choices_vs_oracle():
         '4 operators (2 on the thin walk, 2 with column patterns in LDS)')
     # 4200 + 4100 features of four columns = 133 KB of activations; 700 patterns of 28 quads = 314 KB: no room for the pool
     run([((4100, 4200), grouped(4100, 4200, 6, 110, 2), 1), ((64, 4100), grouped(64, 4100, 8, 9, 0), 0)],
-        '2 operators (0 on the thin walk, 1 with column patterns in LDS)')
+        '2 operators (0 on the thin walk, 1 with column patterns in LDS), 0 with two rows per lane')
+    # conv layers of >= 1024 rows whose patterns hold several rows each: TWO rows per lane (they share every activation read).  Groups of 6 (three
+    # lanes per pattern), of 11 (an odd row left over per pattern: a half-empty lane), of 16; 1 .. 9 unrelated rows at the end (lanes of their own, among
+    # them the homogeneous row); row lengths that are not a multiple of four; a pooling layer (general walk) and a Linear (thin walk) behind them, so
+    # the pools of layers 0, 2 and 3 are staged a layer early and layer 1 runs while layer 2's pool is being written.
+    run([((2051, 300), grouped(2051, 300, 6, 11, 5), 1), ((1300, 2051), grouped(1300, 2051, 1, 7, 0), 0), ((1609, 1300), grouped(1609, 1300, 16, 50, 9), 1),
+         ((90, 1609), dense(90, 1609), 1), ((10, 90), dense(10, 90), 0)],
+        '5 operators (2 on the thin walk, 2 with column patterns in LDS), 2 with two rows per lane, 4 column pools staged a layer early')
+    run([((1500, 257), grouped(1500, 257, 11, 13, 1), 0), ((33, 1500), dense(33, 1500), 0)],
+        '2 operators (1 on the thin walk, 1 with column patterns in LDS), 1 with two rows per lane, 2 column pools staged a layer early')
 
 
 def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
@@ -1180,6 +1189,102 @@ def _check_convtaps_vs_oracle(W, rng, n_vecs, has_last, tag):
         y = W.torchdot(xd, relu=relu).cpu().numpy()
         r = np.maximum(ref, 0) if relu else ref
         assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (tag, np.abs(y - r).max())
+
+
+@pytest.mark.parametrize('Cin,Cout,H,k,stride,n_vecs,unit,has_last', [
+    (16, 64, 12, 3, 1, 128, True, True),       # 16 channels per wavefront (enough bundles), one 128-column tile
+    (16, 64, 12, 3, 1, 384, True, True),       # 384 columns fill three 128-column tiles (two 256-column tiles would waste a quarter)
+    (5, 24, 8, 3, 1, 128, True, True),         # 8 channels per wavefront, odd channel counts, Cout not a multiple of 16
+    (3, 64, 10, 3, 1, 128, True, False),       # first-layer shape without a bias column
+    (8, 32, 8, 3, 2, 128, True, True),         # stride 2
+    (12, 48, 8, 3, 1, 128, False, True),       # float coefficients (stored value = fl(coef * tap)): the COEF instantiations
+    (4, 16, 6, 5, 1, 640, False, True),        # five 128-column tiles, 5 x 5 window
+])
+def test_convtaps_exact_pipeline_on_128_column_tiles(Cin, Cout, H, k, stride, n_vecs, unit, has_last):
+    """convtaps_exact_pipe_kernel with TWO batch columns per lane (128-column tiles: what each stream of the overlapped forward hands a conv
+    layer at 256 images, and batches that fill 128-column tiles better than 256-column ones): bit-equal to the oracle on the whole expansion,
+    bit-equal to the four-columns-per-lane instantiation on the same columns (batch columns are independent), ReLU and a column window of a
+    wider block through the C ABI."""
+    rng = np.random.RandomState(7 * Cin + Cout + n_vecs)
+    W = _random_convtaps(rng, Cin, Cout, H, k, stride, True, has_last)
+    if not unit:            # one float coefficient per (output pixel, input pixel) entry, no pixel pair hit twice: the shape of a permutation + gain key
+        t = W._taps
+        W = ksp.Conv2dTiledMatrix.fromtaps(W._inshape, W._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'],
+                                           (0.5 + rng.rand(len(t['ent_out']))).astype(np.float32), t['lastcol'])
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'convtaps_exact_pipe_kernel' in plan and '128-column tiles' in plan and ('coef' in plan) == (not unit), plan
+    X = rng.randn(W.shape[1], 1024).astype(np.float32)
+    if has_last:
+        X[-1] = 1.0
+    M = W.tosparse('csr')
+    M.sort_indices()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), np.ascontiguousarray(X[:, :n_vecs]))
+    xd = torch.as_tensor(np.ascontiguousarray(X[:, :n_vecs])).to(dev())
+    for relu in (False, True):
+        ye = W.torchdot(xd, relu=relu, exact=True).cpu().numpy()
+        assert np.array_equal(ye, np.maximum(ref, 0) if relu else ref), (Cin, Cout, n_vecs, relu)
+    # the 256-column tiles of the four-columns-per-lane instantiation compute the same columns bit for bit
+    xw = torch.as_tensor(X).to(dev())
+    with torch.cuda.device(dev()):
+        assert '128-column tiles' not in W._device_op(dev()).plan(1024, _capi.KN_FLAG_EXACT)
+    yw = W.torchdot(xw, exact=True).cpu().numpy()
+    assert np.array_equal(yw[:, :n_vecs], ref)
+    # a 128-column window of the 1024-wide block (ldx = ldy = 1024): the overlapped forward's operand
+    yd = torch.full((W.shape[0], 1024), 7.0, device=dev())
+    c0 = 256
+    with torch.cuda.device(dev()):
+        W._device_op(dev()).spmm(xw.data_ptr() + 4 * c0, 1024, 128, yd.data_ptr() + 4 * c0, 1024, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = yd.cpu().numpy()
+    assert np.array_equal(got[:, c0:c0 + 128], yw[:, c0:c0 + 128]) and np.all(got[:, :c0] == 7.0) and np.all(got[:, c0 + 128:] == 7.0)
+
+
+@pytest.mark.parametrize('Cin,Cout,H,k,n_vecs,unit', [
+    (16, 128, 12, 9, 128, True),        # up to 81 slots per pixel = two slot groups (64 + 17), 128 x 128 tiles
+    (16, 128, 12, 9, 256, False),       # ... with a float coefficient per slot (the activation tile is scaled on its way to LDS)
+    (32, 64, 14, 13, 256, True),        # up to 169 slots = three groups, 64 x 256 tiles, two channel chunks per slot
+    (48, 192, 10, 11, 384, False),      # 121 slots, three channel chunks, three batch tiles, Cout over two tiles (the second half empty)
+])
+def test_convtaps_slot_groups_beyond_64_slots(Cin, Cout, H, k, n_vecs, unit):
+    """Fill-in-aware loaders (the reference's doubly-stochastic VGG-16, test/test_keynet.py:116-129, has 500 - 5 400 slots per output
+    pixel): a pixel with more than 64 slots is walked slot GROUP by slot group on the wave-uniform-pointer loaders of the matrix-core kernel
+    (until round 5 such operators fell to the generic loader: 5-14 TFLOP/s).  Against the order-preserving kernel -- bit-exact with the oracle on
+    the whole expansion -- within the conditioned float-key bound, ReLU on and off, and equal to the generic loader (KN_NO_SPTR) to rounding."""
+    import os
+    rng = np.random.RandomState(Cin + Cout + k)
+    W = _random_convtaps(rng, Cin, Cout, H, k, 1, True, True)
+    if not unit:
+        t = W._taps
+        W = ksp.Conv2dTiledMatrix.fromtaps(W._inshape, W._outshape, t['taps'], t['ent_out'], t['ent_in'], t['ent_tap'],
+                                           (0.5 + rng.rand(len(t['ent_out']))).astype(np.float32), t['lastcol'])
+    slots = np.bincount(W._taps['ent_out'])
+    assert slots.max() > 64 and slots.min() < slots.max()                     # border pixels have fewer: groups of every size, pixels with one group too
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, 0)
+    assert 'sptr(wave-uniform pointers)' in plan and ('+coef' in plan) == (not unit), plan
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    X[-1] = 1.0
+    xd = torch.as_tensor(X).to(dev())
+    M = W.tosparse('csr')
+    M.sort_indices()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    ye = W.torchdot(xd, exact=True).cpu().numpy()
+    assert np.array_equal(ye, ref)
+    for relu in (False, True):
+        y = W.torchdot(xd, relu=relu, exact=False).cpu().numpy()
+        r = np.maximum(ref, 0) if relu else ref
+        assert close_conditioned(y.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (Cin, Cout, k, relu, np.abs(y - r).max())
+    os.environ['KN_NO_SPTR'] = '1'
+    try:
+        Wg = copy.deepcopy(W)
+        Wg._op = None
+        yg = Wg.torchdot(xd, exact=False).cpu().numpy()
+        with torch.cuda.device(dev()):
+            assert 'generic' in Wg._device_op(dev()).plan(n_vecs, 0)
+    finally:
+        del os.environ['KN_NO_SPTR']
+    assert close_conditioned(yg.T, ref.T, (M.shape, M.indptr, M.indices, M.data), X.T)
 
 
 @pytest.mark.parametrize('case', range(10))

@@ -75,6 +75,31 @@ def test_keyed_vgg16_equals_plain_network(vgg):
     assert np.allclose(y128.cpu().numpy(), y256[:128].cpu().numpy(), atol=1e-4)
 
 
+def test_exact_kernels_on_128_and_256_column_tiles_agree(vgg):
+    """The bit-exact contract at 256 and 128 images: the conv layers run four batch columns per lane on the whole batch, two per lane on a
+    128-image batch (convtaps_exact_pipe_kernel's 128-column form; the generic one-column kernel served such batches before round 5) -- same
+    arithmetic per column, so the 128-image logits equal the first 128 rows of the 256-image logits bit for bit."""
+    (net, sensor, knet) = vgg
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 3, 224, 224, generator=g)
+    xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+    x256 = torch.cat([xc] * 32, dim=0).t().contiguous().t()
+    knet.exact_mode(True)
+    try:
+        assert knet._overlap_plan(x256.device, 256) is None          # (the overlapped forward is for the matrix-core layers: measured slower here)
+        y0 = knet.forward_linear(x256)
+        x128 = x256[:128].t().contiguous().t()
+        y1 = knet.forward_linear(x128)
+        assert torch.equal(y0[:128], y1)
+        assert torch.equal(y0[:8], y0[8:16]) and torch.equal(y0[:8], y0[248:256])
+        with torch.cuda.device(dev):
+            conv = knet._keynet.conv3_2.W._device_op(dev)
+            assert '128-column tiles' in conv.plan(128, 2 | 1) and '128-column tiles' not in conv.plan(256, 2 | 1)
+    finally:
+        knet.exact_mode(None)
+
+
 def test_exact_mode_is_bit_exact_at_full_layer_size(vgg):
     """KN_FLAG_EXACT on EVERY operator of the real key-net (conv1_1 ... fc8: up to 3.2M x 3.2M, 1.84 G nnz), chained layer to layer:
     the order-preserving kernels (factored conv, expanded pooling tiles, keyed nn.Linear) equal the CPU oracle (scipy csr_matvecs
