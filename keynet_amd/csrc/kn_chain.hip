@@ -179,12 +179,15 @@ __device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int
 // bit for bit, and no NaN / Inf of a live activation can leak through a padded entry.  So there is no predicate anywhere in the walk.
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
-template <bool ST>
+template <bool ST, int PART>          // PART: 1 = the lane records, 2 = the first ring, 3 = both
 __device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS;
     if (wave >= L.n_slices) return;
-    pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0);
-    pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
+    if (PART & 1) {
+        pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0);
+        pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
+    }
+    if (!(PART & 2)) return;
     const char* const cols_b = reinterpret_cast<const char*>(L.cols);
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
 #pragma unroll
@@ -314,12 +317,15 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // multiplies / adds -- LeNet conv2: 50 slices x 13 quads x 40 clocks = 10.8 us of the 12.0 it took.  Two rows per lane share every activation read:
 // the same LDS clocks now carry twice the arithmetic (conv2 12.0 -> see profiles/r05_lenet_chain_breakdown.txt).  Each row still sums its own stored
 // sequence serially, multiply then add: same bits.
-template <bool ST, int R>
+template <bool ST, int R, int PART>
 __device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D;      // (R = 2: a quad is 32 bytes per lane -- the same bytes in flight with half the ring)
     if (wave >= L.n_slices) return;
-    pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off);
-    pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
+    if (PART & 1) {
+        pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off);
+        pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
+    }
+    if (!(PART & 2)) return;
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
 #pragma unroll
     for (int i = 0; i < D; i++)
@@ -460,10 +466,10 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
 // entry, so that a wavefront's activation address is the staged entry itself (no per-read address add) and only the VALUE quads are loaded from
 // memory (the two wavefronts of a slice load the same values: with the columns also from memory that would double the texture addresser's
 // work, which is shared by the CU -- the reason an earlier two-/four-lanes-per-row variant was slower).
-template <int DV, bool ST>
+template <int DV, bool ST, int PART>
 __device__ __forceinline__ void chain_rows_thin_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int RPS = 64;
-    if (wave >= 2 * L.n_slices) return;
+    if (wave >= 2 * L.n_slices || !(PART & 1)) return;
     const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
     const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
     const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(sl * RPS + lane));
@@ -566,12 +572,12 @@ __device__ __forceinline__ void chain_stage_now(const ChainLayerArg& L, const in
     for (int i = tid; i < n; i += CHAIN_THREADS) chain_stage_quad<ST>(L, i, *reinterpret_cast<const i32x4*>(L.cols + 4 * i));
 }
 
-template <bool ST>
+template <bool ST, int PART>
 __device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
-    if (L.cols_quads > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST>(L, wave, lane, pre);
-    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2>(L, wave, lane, pre);
-    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1>(L, wave, lane, pre);
-    else chain_rows_pre<ST>(L, wave, lane, pre);
+    if (L.cols_quads > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST, PART>(L, wave, lane, pre);
+    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2, PART>(L, wave, lane, pre);
+    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1, PART>(L, wave, lane, pre);
+    else chain_rows_pre<ST, PART>(L, wave, lane, pre);
 }
 
 template <bool ST>
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
                                 // hidden round trips gain: 42.4 against 39.0 us per LeNet forward.  Kept as a build switch for a device with more registers per wavefront.
 #endif
     ChainPre pre;
-    if (KN_CHAIN_PRE) chain_pre<ST>(a.L[0], wave, lane, pre);
+    if (KN_CHAIN_PRE) chain_pre<ST, (KN_CHAIN_PRE == 2 ? 1 : 3)>(a.L[0], wave, lane, pre);
     __syncthreads();
     CHAIN_STAMP(1);
     for (int l = 0; l < a.n_layers; l++) {
@@ -631,7 +637,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
             chain_stage_now<ST>(L, tid);
             __syncthreads();
         }
-        if (!KN_CHAIN_PRE) chain_pre<ST>(L, wave, lane, pre);
+        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(L, wave, lane, pre);
+        if (KN_CHAIN_PRE == 2) chain_pre<ST, 2>(L, wave, lane, pre);            // (the lane records crossed the barrier; the ring is requested here)
         if (L.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(L, out_off, wave, lane, pre, ws);
         else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl<ST, 2>(L, out_off, wave, lane, pre, ws);
         else if (L.cols_quads < 0) chain_rows_cl<ST, 1>(L, out_off, wave, lane, pre, ws);
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         // the next layer's first operator words: on their way across the barrier.  (A fresh object per layer: what a wavefront without a slice, or a walk
         // kind that needs fewer words, leaves unwritten is then undefined rather than the previous layer's values kept alive through the walk.)
         ChainPre nxt;
-        if (KN_CHAIN_PRE && l + 1 < a.n_layers) chain_pre<ST>(a.L[l + 1], wave, lane, nxt);
+        if (KN_CHAIN_PRE && l + 1 < a.n_layers) chain_pre<ST, (KN_CHAIN_PRE == 2 ? 1 : 3)>(a.L[l + 1], wave, lane, nxt);
         __syncthreads();
         if (KN_CHAIN_PRE) pre = nxt;
         CHAIN_WSTAMP(7, false);

@@ -147,6 +147,7 @@ struct Tuning {
     int mf_pf = 8;            // KN_MF_PF             operand columns in flight of the matrix-pipe grouped kernel
     int table_window = 0;     // KN_TABLE_WINDOW      (0: the rule)
     int table_strip = -1;     // KN_TABLE_STRIP       (-1: best of the candidates, 0: keep the ball order)
+    int conv_ball = 64;       // KN_CONV_BALL         output pixels per breadth-first ball of a conv-taps operator's processing order
     int no_patch = 0;         // KN_NO_PATCH
     int no_row_order = 0;     // KN_NO_ROW_ORDER
     int chain_no_cl = 0;      // KN_CHAIN_NO_CL

@@ -267,6 +267,13 @@ class FactoredSparseMatrix(SparseMatrix):
     def proven(M, factored, max_zero_fraction=0.01):
         """Is the stored CSR `M` (scipy) exactly -- indptr, indices AND values, in stored order -- the canonical expansion of `factored` with its
         zero-valued entries removed?  Also refuses operators with many exact zeros (a pruned filter): the device re-checks every such entry."""
+        try:
+            return FactoredSparseMatrix._proven(M, factored, max_zero_fraction)
+        except Exception:                # any surprise in a crafted / damaged description: the plain CSR container it is (the comments promise a fallback)
+            return False
+
+    @staticmethod
+    def _proven(M, factored, max_zero_fraction):
         t = factored._taps
         if t is None or M.format != 'csr' or tuple(M.shape) != tuple(factored.shape) or M.dtype != np.float32:
             return False
@@ -278,8 +285,7 @@ class FactoredSparseMatrix(SparseMatrix):
         keep = E.data != 0
         if M.nnz != int(np.count_nonzero(keep)):
             return False
-        counts = np.add.reduceat(keep, E.indptr[:-1].astype(np.int64)) if E.nnz else np.zeros(E.shape[0], np.int64)
-        counts[np.diff(E.indptr) == 0] = 0                                   # (reduceat on an empty row returns the next element)
+        counts = np.diff(np.concatenate(([0], np.cumsum(keep, dtype=np.int64)))[E.indptr.astype(np.int64)])      # kept entries per row (empty rows, trailing ones included: 0)
         (ip, ix, dt) = _stored_order_csr(M)
         return bool(np.array_equal(np.concatenate(([0], np.cumsum(counts))).astype(np.int64), ip.astype(np.int64)) and
                     np.array_equal(E.indices[keep].astype(np.int32), ix) and np.array_equal(E.data[keep].view(np.uint32), dt.view(np.uint32)))
