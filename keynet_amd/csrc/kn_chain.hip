@@ -528,26 +528,25 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
         xread(c1, x[1]);
     }
     static_assert(DV % 6 == 0, "the activation buffers rotate with period 3, the column quads with period 2: an unrolled trip must be a multiple of both");
+    // (Measured and dropped, round 5: the quad's instructions in a hand-written order -- four products, then the four dependent adds with the quad's LDS reads
+    // and value request between them -- changes nothing: 36.9-37.3 against 36.5 us per LeNet forward.  A wavefront ALONE on its SIMD pays ~9 clocks per vector
+    // instruction whatever stands between them (tools/micro/dep_chain.hip: 20 instructions of a quad = 190 clocks), so fc1 costs 197 quads x 15 instructions.)
+    auto quad = [&](const int i, const int k, const bool refill) {          // i: ring slot (static), k: quad index
+        cq[(i + 1) & 1] = ldc(k + 3);
+        xread(cq[i & 1], x[(i + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);                 // the next quads' LDS reads in flight under this quad's arithmetic
+        macs(x[i % 3], v[i]);
+        if (refill) v[i] = ldv(k + DV);
+        __builtin_amdgcn_sched_barrier(0);                 // the value request stays HERE (see chain_rows)
+    };
     int q = 0;
     for (; q + DV <= nq; q += DV) {
 #pragma unroll
-        for (int i = 0; i < DV; i++) {
-            cq[(i + 1) & 1] = ldc(q + i + 3);
-            xread(cq[i & 1], x[(i + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);             // the next quads' LDS reads in flight under this quad's arithmetic
-            macs(x[i % 3], v[i]);
-            v[i] = ldv(q + DV + i);
-            __builtin_amdgcn_sched_barrier(0);             // the value request stays HERE (see chain_rows)
-        }
+        for (int i = 0; i < DV; i++) quad(i, q + i, true);
     }
 #pragma unroll
     for (int i = 0; i < DV - 1; i++) {
-        if (q + i < nq) {
-            cq[(i + 1) & 1] = ldc(q + i + 3);
-            xread(cq[i & 1], x[(i + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            macs(x[i % 3], v[i]);
-        }
+        if (q + i < nq) quad(i, q + i, false);
     }
     if (pre.m0.row >= 0) {
         f32x2 t = acc;

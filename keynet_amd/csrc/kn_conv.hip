@@ -1189,6 +1189,14 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
     for (int r = 0; r < RBX; r++)
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[r][v] = 0.0f;
+    // VEC == 1 (narrow batches; operators the pipelined kernel does not take: more than 64 slots per pixel, or several taps on one (output, input) pixel
+    // pair -- a doubly-stochastic key has both): one batch column per lane, so the PACKED instructions pair two output channels instead of two columns --
+    // v_pk_mul_f32 (a_r, a_r+1) x (x, x), v_pk_add_f32 into the pair's running sums: the same separate IEEE multiply and add per element at half the
+    // vector instructions (round 5; the reference's VGG-16 with doubly-stochastic keys runs four layers here by contract).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[RBX / 2];
+#pragma unroll
+    for (int r = 0; r < RBX / 2; r++) acc2[r] = f32x2{0.0f, 0.0f};
 
     for (int ci = 0; ci < p.Cin; ci++) {
         const float* xrow = xc + (int64_t)ci * p.HiWi * p.ldx;
@@ -1223,15 +1231,28 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 #pragma unroll
                 for (int v = 0; v < VEC; v++) xv[v] = xrow[(int64_t)in * p.ldx + v];
             }
+            if constexpr (VEC == 1) {
+                const f32x2 xx = {xv[0], xv[0]};
 #pragma unroll
-            for (int r = 0; r < RBX; r++) {
+                for (int r = 0; r < RBX / 2; r++) {
+                    const f32x2 pr = f32x2{ar[2 * r], ar[2 * r + 1]} * xx;
+                    acc2[r] = acc2[r] + pr;
+                }
+            } else {
 #pragma unroll
-                for (int v = 0; v < VEC; v++) {
-                    const float pr = ar[r] * xv[v];
-                    acc[r][v] = acc[r][v] + pr;
+                for (int r = 0; r < RBX; r++) {
+#pragma unroll
+                    for (int v = 0; v < VEC; v++) {
+                        const float pr = ar[r] * xv[v];
+                        acc[r][v] = acc[r][v] + pr;
+                    }
                 }
             }
         }
+    }
+    if constexpr (VEC == 1) {
+#pragma unroll
+        for (int r = 0; r < RBX; r++) acc[r][0] = acc2[r / 2][r % 2];
     }
     if (!active) return;
     const float* xlast = p.lastcol ? (p.X + p.last_in_row * p.ldx + c) : nullptr;
@@ -1873,9 +1894,11 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         return KN_OK;
     }
     a.wide_store = (a.vec_ok && ldy % 4 == 0 && ((uintptr_t)y) % 16 == 0) ? 1 : 0;
-    // every matrix-core kernel below streams its tiles out through kn_store_tile when the stores are wide and the batch fills whole tiles
-    // (256 covers every tile width): then max |Y| rides in the epilogues (tiles + conv_lastrow_kernel for the homogeneous row)
-    if (absmax && a.wide_store && n_vecs % 256 == 0) {
+    // every matrix-core kernel below streams its tiles out through kn_store_tile when the stores are wide and the batch fills whole tiles of the
+    // kernel that will run (128 columns for the 128 x 128 and bf16x3 tiles -- so also the half-batch windows of the overlapped forward at 256 images --,
+    // 256 for the 64 x 256 and small-K tiles): then max |Y| rides in the epilogues (tiles + conv_lastrow_kernel for the homogeneous row)
+    const int64_t nb_tile = (((flags & KN_FLAG_BF16X3) && convtaps_bf16x3_ok(A, x, ldx, n_vecs, y, ldy)) || (A.cout_pad % 128 == 0 && A.Cout > 64)) ? 128 : 256;
+    if (absmax && a.wide_store && n_vecs % nb_tile == 0) {
         a.absmax = absmax;
         if (absmax_fused) *absmax_fused = true;
     }

@@ -154,8 +154,10 @@ class KeyedLayer(nn.Module):
         `direct`: None = automatic (factored, Toeplitz-free keying for tiled conv/avgpool layers whose Toeplitz matrix
         would exceed DIRECT_THRESHOLD entries -- the reference route cannot build those at all); True / False force it.
         `exact`: True = every product in the reference's accumulation order and rounding (bit-exact with scipy);
-        False = float-key tolerance (1e-5): conv-taps and large dense operators run on the matrix cores.  None = exact
-        for untiled layers (the permutation key-nets), tolerance for tiled ones (BASELINE north_star).
+        False = conv-taps and large dense operators run on the matrix cores, whatever the error; 'auto' = the matrix cores where a
+        calibration on the first batch shows the result inside the float-key tolerance (element-wise 1e-5 + 1e-5 |ref|), else exact.
+        None (default) = exact for untiled layers AND for tiled layers keyed by permutations only (north_star: "bit-exact for the
+        permutation-only key"), 'auto' for tiled layers whose keys carry float coefficients.
         Raises ValueError for layer types that cannot be keyed (the reference's behaviour, keynet/layer.py:72-79)."""
         super(KeyedLayer, self).__init__()
         self._layertype = str(type(module))

@@ -147,8 +147,11 @@ class KeyedModel(object):
         matrix cores by a CALIBRATION decision (exact='auto': the float-key contract) reads one float per keyed layer back at the end of
         every forward -- max |x| of each such layer, gathered on the device inside the producing kernels (kn_spmm_screen) -- and, when a
         layer's input has outgrown its calibration by more than KeyedLayer.RESCREEN_FACTOR, re-calibrates that layer on this batch and runs
-        the batch again, so the 1e-5 agreement with the reference's arithmetic holds for every call, as it does in the reference
-        (keynet/sparse.py:488-492 is the same arithmetic every time); the first forward of an 'auto' layer calibrates it (host reads).
+        the batch again.  What that checks (and no more): the batch maximum of each screened layer's input against the maximum the
+        decision was calibrated on, with the 2x headroom every accepted decision has (element-wise |d| <= 1e-5 + 1e-5 |ref|, measured on up to 256
+        columns of the calibration batch; an unmeasured dense layer is accepted only with its worst-case bound at half the tolerance); NaN activations
+        are not screened.  The reference applies one arithmetic on every call (keynet/sparse.py:488-492): only the 'exact' contract IS that arithmetic.
+        The first forward of an 'auto' layer calibrates it (host reads).
         `overlap`: run the batch as two half-batch column windows on two side streams, one kernel apart (see _forward_overlapped);
         None = automatically for device-resident feature-major batches that are a multiple of 256 images, False = never.
         Memory: the overlapped forward keeps two ping-pong workspaces of max_rows x N floats per (device, N) plan (VGG-16 at N = 256:

@@ -82,7 +82,7 @@ def test_permutation_only_tiled_keynet_is_bit_exact_by_default(golden):
     assert not rep['undecided'] and not rep['switched'] and any(r['screened'] for r in rep['layers'])      # conv layers on the matrix cores, screened
 
 
-@pytest.mark.parametrize('kind', ['csr', 'csr-pool-256', 'csr-pool-half-wave', 'csr-grouped', 'conv-mfma-256', 'conv-mfma-narrow', 'conv-exact', 'dense'])
+@pytest.mark.parametrize('kind', ['csr', 'csr-pool-256', 'csr-pool-half-wave', 'csr-grouped', 'conv-mfma-256', 'conv-mfma-128-window', 'conv-mfma-narrow', 'conv-exact', 'dense'])
 def test_spmm_screen_reports_max_abs_output(kind):
     """kn_spmm_screen: same Y as kn_spmm bit for bit, and the slot holds max |Y| exactly -- folded into the tile stores of the matrix-core
     kernels (whole 256-column tiles), one reduction pass behind every other kernel; the slot is only ever raised."""
@@ -115,7 +115,7 @@ def test_spmm_screen_reports_max_abs_output(kind):
         assert W._dense_device_op(dev()) is not None
     else:
         from keynet_amd import direct as kdirect
-        (cin, cout, hw) = (16, 64, 6)
+        (cin, cout, hw) = (16, 128 if kind == 'conv-mfma-128-window' else 64, 6)      # (128 x 128 tiles: a half-batch window of 128 columns keeps max |y| in the store epilogue)
         w = (rng.randn(cout, cin, 3, 3) / 12).astype(np.float32)
         b = rng.randn(cout).astype(np.float32)
         (eo, ei, et) = ([], [], [])
@@ -125,7 +125,7 @@ def test_spmm_screen_reports_max_abs_output(kind):
         taps = np.stack([w[:, :, i, j] for i in range(3) for j in range(3)])
         W = ksp.Conv2dTiledMatrix.fromtaps((cin, hw, hw), (cout, hw, hw), taps, np.concatenate(eo).astype(np.int32), np.concatenate(ei).astype(np.int32),
                                            np.concatenate(et).astype(np.int32), None, np.concatenate((np.repeat(b, hw * hw), [1.0])).astype(np.float32))
-        (n, exact) = ({'conv-mfma-256': 256, 'conv-mfma-narrow': 24, 'conv-exact': 256}[kind], kind == 'conv-exact')
+        (n, exact) = ({'conv-mfma-256': 256, 'conv-mfma-128-window': 128, 'conv-mfma-narrow': 24, 'conv-exact': 256}[kind], kind == 'conv-exact')
     X = rng.randn(W.shape[1], n).astype(np.float32) * 3
     X[-1] = 1
     xd = torch.as_tensor(X).to(dev())

@@ -14,6 +14,18 @@ def test_sharded_forward_equals_single_process(n):
     assert all(r[3] == (n, 5) for r in res)
 
 
+def test_sharded_forward_on_eight_ranks_ragged():
+    """BASELINE configs[4] is an 8-rank job: eight gloo processes, a ragged total of 61 rows (shards of 8 and 7), gathered logits bit-equal to the
+    single-process forward on every rank, rank-major, one all_gather_into_tensor per forward (tests/test_dist_gpu.py: the same with the real kernels)."""
+    n = 61
+    res = dist_harness.run('standin', n, world_size=8)
+    assert [r[0] for r in res] == list(range(8)) and all(r[1] for r in res)
+    bounds = [r[2] for r in res]
+    assert bounds[0][0] == 0 and bounds[-1][1] == n and all(bounds[k][1] == bounds[k + 1][0] for k in range(7))
+    assert sorted(set(hi - lo for (lo, hi) in bounds)) == [7, 8]
+    assert all(r[3] == (n, 5) and len(r[6]) == 1 for r in res)
+
+
 def test_shard_bounds_cover_and_balance():
     for n in (0, 1, 7, 256, 2048, 2049):
         for ws in (1, 2, 4, 8):

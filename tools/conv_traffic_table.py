@@ -17,10 +17,12 @@ def last_forward(d, counter):
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'convtaps_mfma_kernel' in r['Kernel_Name']]
     t = max(glob.glob(d + '/*/*kernel_trace.csv'), key=os.path.getmtime)
     dur = {r['Dispatch_Id']: int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in csv.DictReader(open(t))}
-    # one forward = 12 conv-taps launches (conv1_2 .. conv5_3; conv1_1 is the small-K kernel), in dispatch order: forward 0 calibrates the contract, 1 warms up,
-    # forward 2 is the first timed step (behind the timed steps bench.py launches single layers for its per-layer table: not forwards)
+    # A forward starts with conv1_2's launch (the only 64-channel layer of 16-channel chunks: the 64 x 256 tile); behind it the other eleven conv layers run as two
+    # half-batch windows each (the overlapped forward) and fc6-8 as split-K launches of the same kernel.  Forward 0 calibrates the contract, 1 warms up, forward 2
+    # is the first timed step; behind the timed steps bench.py launches single layers for its per-layer table (not forwards: they follow the last marker).
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    rows = rows[24:36]
+    marks = [i for (i, r) in enumerate(rows) if '<64, 256, 16' in r['Kernel_Name']]
+    rows = rows[marks[2]:marks[3]]
     return (sum(float(r['Counter_Value']) for r in rows) * 1024, sum(dur.get(r['Dispatch_Id'], 0) for r in rows) * 1e-6, len(rows))
 
 
