@@ -502,12 +502,15 @@ def roofline_of(table, workload, batch, mode):
                      'from K = 1 matrix instructions with a zero accumulator still pay the adds on the same lanes: DESIGN.md section 8)')
 
 
-def exact_parity(knet, x_cipher, n_img=8, n_pix=4):
-    """Checker for the exact leg: the order-preserving kernels on the REAL conv1_2 and conv4_2 operators against the CPU oracle
-    (oracle/: scipy csr_matvecs restated) on sampled output rows, bit for bit, with the key-net's own activations as input."""
+def exact_parity(knet, x_cipher, n_img=8, n_pix=4, layers=('conv1_1', 'conv1_2', 'pool3_3', 'conv4_2', 'conv5_2', 'fc6')):
+    """Checker for the exact leg: the order-preserving kernels AS TIMED -- launched on the whole batch -- on one real operator of each kernel family
+    (first-layer conv, 64- and 512-channel conv pipelines, a keyed pooling layer = loose CSR rows, a keyed Linear = one big pattern group) against
+    the CPU oracle (oracle/: scipy csr_matvecs restated) on sampled output rows, the first `n_img` batch columns, bit for bit, chained layer to
+    layer with the key-net's own activations as input."""
     import oracle
+    import scipy.sparse
     rng = np.random.RandomState(1)
-    y = x_cipher[:n_img]
+    y = x_cipher
     checked = []
     children = list(knet._keynet.named_children())
     for (i, (name, c)) in enumerate(children):
@@ -515,20 +518,35 @@ def exact_parity(knet, x_cipher, n_img=8, n_pix=4):
             continue
         fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
         out = c.forward(y, fuse_relu=fuse)
-        if name in ('conv1_2', 'conv4_2') and isinstance(c.W, ksp.Conv2dTiledMatrix) and c.W._taps is not None:
-            (Cout, Hout, Wout) = c.W._outshape
-            pix = np.sort(rng.choice(Hout * Wout, size=n_pix, replace=False))
-            M = c.W.rows_csr(pix)
-            ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), y.t().contiguous().cpu().numpy())
+        if name in layers:
+            W = c.W
+            xh = y.t()[:, :n_img].contiguous().cpu().numpy()
+            if isinstance(W, ksp.Conv2dTiledMatrix) and W._taps is not None:
+                (Cout, Hout, Wout) = W._outshape
+                pix = np.sort(rng.choice(Hout * Wout, size=n_pix, replace=False))
+                M = W.rows_csr(pix)
+                rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
+            else:
+                full = W.tocsr() if isinstance(W, ksp.TiledMatrix) else W._matrix.tocsr()
+                rows = np.unique(np.concatenate((rng.choice(full.shape[0] - 1, size=min(300, full.shape[0] - 1), replace=False), [full.shape[0] - 1])))
+                if isinstance(W, ksp.TiledMatrix):
+                    M = full[rows]
+                else:                                             # stored (unsorted) order of the keyed Linear's rows, untouched
+                    (ip, ix, dt) = (full.indptr, full.indices, full.data)
+                    sel = np.concatenate([np.arange(ip[r], ip[r + 1]) for r in rows])
+                    M = scipy.sparse.csr_matrix((dt[sel], ix[sel], np.concatenate(([0], np.cumsum(ip[rows + 1] - ip[rows])))), shape=(len(rows), full.shape[1]))
+            ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), xh)
             if fuse:
                 ref = np.maximum(ref, 0)
-            rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
-            got = out.t()[torch.as_tensor(rows, device=out.device)].cpu().numpy()
-            checked.append({'layer': name, 'rows': int(len(rows)), 'images': n_img, 'bit_equal': bool(np.array_equal(got, ref))})
+            got = out.t()[torch.as_tensor(rows, device=out.device)][:, :n_img].cpu().numpy()
+            with torch.cuda.device(out.device):
+                plan = W._device_op(out.device).plan(int(y.shape[0]), 2 | (1 if fuse else 0)).split(' grid=')[0] if hasattr(W, '_device_op') else ''
+            checked.append({'layer': name, 'rows': int(len(rows)), 'images': n_img, 'batch_columns_launched': int(y.shape[0]), 'kernel': plan[:80],
+                            'bit_equal': bool(np.array_equal(got, ref))})
         y = out
-        if name == 'conv4_2':
+        if name == layers[-1]:
             break
-    return {'check': 'exact-mode kernels vs the CPU oracle (scipy csr_matvecs restated) on sampled output rows of real layers', 'layers': checked,
+    return {'check': 'exact-mode kernels, launched on the whole batch, vs the CPU oracle (scipy csr_matvecs restated) on sampled output rows of real layers', 'layers': checked,
             'ok': bool(checked) and all(r['bit_equal'] for r in checked)}
 
 

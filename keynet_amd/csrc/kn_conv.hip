@@ -150,7 +150,8 @@ __device__ __forceinline__ void decode_conv_item(const ConvArgs& p, const int64_
 template <int MT, int NB, int KC, int WM, int WN, int MODE>
 __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int o, const int m0, const int b0, float* lds) {
     constexpr bool FAST = MODE >= 1;
-    constexpr bool SPTR = MODE == 2;
+    constexpr bool SPTR = MODE >= 2;
+    constexpr bool GROUPS = MODE == 3;               // SPTR over pixels with more than 64 slots: slot groups (its own instantiation: the single-group walk pays nothing for it)
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
     static_assert(!SPTR || KC == 16, "the scalar-pointer loader is built for 16-row chunks of whole channels");
     constexpr int TM = MT / WM / 32;
@@ -319,7 +320,8 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
     int dtab_a_lo = 0, dtab_a_hi = 0, dtab_b_lo = 0, dtab_b_hi = 0;
     int g_slot = 0;                                   // the loader's position inside its current GROUP of <= 64 slots (lane s of the tables = slot g_base + s)
     int g_base = 0, g_n = 0, g_row = 0;               // first slot / size of that group, channel chunk the loader is in
-    float cf_pend = 1.0f;                             // coefficient of the chunk most recently requested (= the one the next LDS store writes)
+    float cf_pend = 1.0f;                             // GROUPS: coefficient of the chunk most recently requested (= the one the next LDS store writes)
+    int st_slot = 0;                                  // one group: slot of the chunk the next LDS store writes (non-unit coefficients)
     float ctab = 1.0f;                                // lane s: coefficient of slot g_base + s
     const int n_slots_u = __builtin_amdgcn_readfirstlane(n_slots);
     auto uni64 = [](const char* q) {                 // readfirstlane on an already-scalar value is free; it keeps loop-carried pointers in SGPR pairs
@@ -369,9 +371,11 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             // (the tables are replaced HERE, before this chunk's loads are issued and after the previous chunk's have been consumed -- never with tile loads
             // in flight: vector code between an asm-issued load and its wait invites the compiler to copy a destination register that has not landed yet,
             // tests/test_isa_lint.py.  One memory round trip, once per 64 * cpk chunks.)
-            if (g_switch) {
-                sptr_group(g_base + g_n < n_slots_u ? g_base + g_n : 0);
-                g_switch = false;
+            if constexpr (GROUPS) {
+                if (g_switch) {
+                    sptr_group(g_base + g_n < n_slots_u ? g_base + g_n : 0);
+                    g_switch = false;
+                }
             }
             if (!KN_ABL(p, 5)) {
 #pragma unroll
@@ -382,13 +386,17 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
                 for (int i = 0; i < BL; i++) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rb[i]) : "v"(b_voff), "s"(reinterpret_cast<uint64_t>(sb[i])));
             }
             if (KN_ABL(p, 4)) return;
-            if (!p.unit_coef) cf_pend = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), g_slot));
+            if constexpr (GROUPS) {
+                if (!p.unit_coef) cf_pend = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), g_slot));
+            }
             const int64_t da = ((int64_t)__builtin_amdgcn_readlane(dtab_a_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_a_lo, g_slot);
             const int64_t db = ((int64_t)__builtin_amdgcn_readlane(dtab_b_hi, g_slot) << 32) | (uint32_t)__builtin_amdgcn_readlane(dtab_b_lo, g_slot);
             const bool wrap = (g_slot + 1 == g_n);
             g_slot = wrap ? 0 : g_slot + 1;
-            g_row = wrap ? g_row + 1 : g_row;
-            g_switch = n_slots_u > 64 && wrap && g_row == cpk;       // (wave-uniform; a single group never switches: the round-2 walk)
+            if constexpr (GROUPS) {
+                g_row = wrap ? g_row + 1 : g_row;
+                g_switch = wrap && g_row == cpk;                        // (wave-uniform)
+            }
 #pragma unroll
             for (int i = 0; i < AL; i++) sa[i] = uni64(sa[i] + da);
 #pragma unroll
@@ -433,7 +441,16 @@ __device__ __forceinline__ void convtaps_mfma_tile(const ConvArgs& p, const int 
             // float keys whose entries carry a coefficient (photometric gains: a_out[o] / a_in[i] per (output, input) pixel pair): the
             // activation tile of the chunk is scaled by its slot's coefficient on the way to LDS, as the generic loader does per element
             if (!p.unit_coef) {
-                const float cf = cf_pend;              // (recorded when the chunk was requested: exactly one chunk waits in registers at a time)
+                // GROUPS: the coefficient recorded when the chunk was requested (exactly one chunk waits in registers at a time; the tables may have moved on
+                // to the next group since).  One group: read from the table at the store's own cursor, as in round 2 (kept literally: written with the
+                // recorded value the compiler turns this branch into eight selects per chunk of every unit-coefficient launch: -1.5 % on the 128 x 128 layers).
+                float cf;
+                if constexpr (GROUPS) {
+                    cf = cf_pend;
+                } else {
+                    cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ctab), st_slot));
+                    st_slot = (st_slot + 1 == n_slots_u) ? 0 : st_slot + 1;
+                }
 #pragma unroll
                 for (int i = 0; i < BL; i++) rb[i] = rb[i] * cf;
             }
@@ -1680,7 +1697,7 @@ static void launch_conv(ConvArgs a, const Tuning& tune, hipStream_t s) {
     if constexpr (KC == 16) sptr = fast_shape && a.Cin % 16 == 0 && 4 * ((int64_t)(1024 / NB) * a.HiWi * a.ldx + NB) < (int64_t)1 << 31 && !tune.no_sptr;
     a.tail_main = (int32_t)chunk;
     if constexpr (MT == 128 && NB == 128 && KC == 16) {
-        if ((fast || sptr) && a.wide_store && !tune.no_tail_split) {
+        if ((fast || sptr) && a.wide_store && !tune.no_tail_split && a.max_slots <= MAX_FAST_SLOTS) {
             // resident workgroups per XCD of the instantiation that is actually launched (the two loader modes may differ in registers)
             static const int64_t slots_free_1 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 1, true>);
             static const int64_t slots_free_2 = xcd_slots(convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, true>);
@@ -1724,6 +1741,10 @@ static void launch_conv(ConvArgs a, const Tuning& tune, hipStream_t s) {
     }
     const int64_t grid = 8 * chunk;
     if constexpr (KC == 16) {
+        if (sptr && a.max_slots > MAX_FAST_SLOTS) {      // pixels with more than 64 slots: the slot-group instantiation (no tail split: such launches are long)
+            KN_LAUNCH(D("sptr(wave-uniform pointers, slot groups)", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 3, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
+            return;
+        }
         if (sptr) {
             KN_LAUNCH(D("sptr(wave-uniform pointers)", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 2, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
             return;

@@ -1262,7 +1262,7 @@ def test_convtaps_slot_groups_beyond_64_slots(Cin, Cout, H, k, n_vecs, unit):
     assert slots.max() > 64 and slots.min() < slots.max()                     # border pixels have fewer: groups of every size, pixels with one group too
     with torch.cuda.device(dev()):
         plan = W._device_op(dev()).plan(n_vecs, 0)
-    assert 'sptr(wave-uniform pointers)' in plan and ('+coef' in plan) == (not unit), plan
+    assert 'sptr(wave-uniform pointers, slot groups)' in plan and ('+coef' in plan) == (not unit), plan
     X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
     X[-1] = 1.0
     xd = torch.as_tensor(X).to(dev())
