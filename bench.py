@@ -642,10 +642,11 @@ def run_secondary(args):
     bench (its own host phase, scipy baseline, device phase, oracle parity) BEFORE this process touches the GPU; the child's JSON line is
     condensed into `secondary`.  (A child process, not an exec: the parent goes on to the VGG legs.)"""
     out = {}
-    for (wl, steps, extra) in (('lenet', max(args.steps, 200), ['--graph-leg']), ('allconv', max(args.steps, 10), [])):
+    # (LeNet: a forward is 37 us -- three warm-up steps are 0.1 ms, not enough for the GPU to leave its idle clock: 2 000 warm-up steps = 75 ms)
+    for (wl, steps, warm, extra) in (('lenet', max(args.steps, 200), max(args.warmup, 2000), ['--graph-leg']), ('allconv', max(args.steps, 10), max(args.warmup, 3), [])):
         t0 = time.time()
         child_detail = os.path.join(ROOT, 'bench_detail_%s.json' % wl)
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', str(steps), '--warmup', str(max(args.warmup, 3)), '--layer-iters', '3',
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', wl, '--steps', str(steps), '--warmup', str(warm), '--layer-iters', '3',
                '--no-secondary', '--cpu-budget', '8', '--detail', child_detail] + extra
         env = dict(os.environ)
         for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):

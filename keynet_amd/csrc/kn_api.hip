@@ -30,7 +30,7 @@ Tuning tuning_from_env() {
     static const Knob knobs[] = {
         {"KN_NO_SPTR", &Tuning::no_sptr}, {"KN_NO_SMALLK_PIPE", &Tuning::no_smallk_pipe}, {"KN_NO_GROUP_PIPE", &Tuning::no_group_pipe},
         {"KN_NO_BIG_GROUPS", &Tuning::no_big_groups}, {"KN_NO_EXACT_TABLE", &Tuning::no_exact_table}, {"KN_GROUP_MFMA", &Tuning::group_mfma},
-        {"KN_BIG_MFMA16", &Tuning::big_mfma16}, {"KN_MF_NRB", &Tuning::mf_nrb}, {"KN_TABLE_NRB", &Tuning::table_nrb},
+        {"KN_BIG_MFMA16", &Tuning::big_mfma16}, {"KN_MF_NRB", &Tuning::mf_nrb}, {"KN_TABLE_NRB", &Tuning::table_nrb}, {"KN_NO_FILL_EXACT", &Tuning::no_fill_exact},
 #ifdef KN_ABLATION
         {"KN_OCC", &Tuning::occ}, {"KN_NO_TAIL_SPLIT", &Tuning::no_tail_split}, {"KN_NO_SMALLK", &Tuning::no_smallk}, {"KN_EXACT_PIPE", &Tuning::exact_pipe},
         {"KN_EXACT_COB_GROUPS", &Tuning::exact_cob_groups}, {"KN_EXACT_XD", &Tuning::exact_xd}, {"KN_EXACT_VEC", &Tuning::exact_vec}, {"KN_MF_PF", &Tuning::mf_pf},
@@ -53,7 +53,7 @@ std::string Tuning::describe() const {
     };
     add("no_sptr", no_sptr, d.no_sptr); add("no_smallk_pipe", no_smallk_pipe, d.no_smallk_pipe); add("no_group_pipe", no_group_pipe, d.no_group_pipe);
     add("no_big_groups", no_big_groups, d.no_big_groups); add("no_exact_table", no_exact_table, d.no_exact_table); add("group_mfma", group_mfma, d.group_mfma);
-    add("big_mfma16", big_mfma16, d.big_mfma16); add("mf_nrb", mf_nrb, d.mf_nrb); add("table_nrb", table_nrb, d.table_nrb);
+    add("big_mfma16", big_mfma16, d.big_mfma16); add("mf_nrb", mf_nrb, d.mf_nrb); add("table_nrb", table_nrb, d.table_nrb); add("no_fill_exact", no_fill_exact, d.no_fill_exact);
     add("occ", occ, d.occ); add("no_tail_split", no_tail_split, d.no_tail_split); add("no_smallk", no_smallk, d.no_smallk); add("exact_pipe", exact_pipe, d.exact_pipe);
     add("exact_cob_groups", exact_cob_groups, d.exact_cob_groups); add("exact_xd", exact_xd, d.exact_xd); add("exact_vec", exact_vec, d.exact_vec); add("mf_pf", mf_pf, d.mf_pf);
     add("table_window", table_window, d.table_window); add("table_strip", table_strip, d.table_strip); add("no_patch", no_patch, d.no_patch); add("conv_ball", conv_ball, d.conv_ball);
@@ -250,6 +250,13 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     }
     c.max_slots = mx;
     c.nslots = (int64_t)order.size();
+    // record offsets of the filled-in order-preserving kernel (convtaps_exact_fill_kernel): every pixel's slot list padded to a multiple of 8 records
+    std::vector<int32_t> fill_ptr;
+    if ((c.has_dups || mx > 64) && !c.tune.no_fill_exact && ntaps * c.cin_pad * c.cout_pad < ((int64_t)1 << 29) && (int64_t)order.size() + 8 * HoWo < ((int64_t)1 << 31)) {
+        fill_ptr.assign((size_t)HoWo + 1, 0);
+        for (int64_t o = 0; o < HoWo; o++) fill_ptr[(size_t)o + 1] = fill_ptr[(size_t)o] + (pix_ptr[(size_t)o + 1] - pix_ptr[(size_t)o] + 7) / 8 * 8;
+        c.fill_n = fill_ptr[(size_t)HoWo];
+    }
     // Processing order of the output pixels (kn::locality_order): two pixels are neighbours when they share an input pixel;
     // balls of 64 are, for a keyed 3x3 conv, roughly 8x8 patches of the un-keyed image.  One patch = the workgroups resident
     // on one XCD at a time (32 CUs x 4 workgroups / 2 Cout tiles), so the gathered activation rows of a patch (a ~10x10
@@ -277,7 +284,19 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
         std::memcpy(&h->h_lastcol[2 * k], &rr, 4);
         h->h_lastcol[2 * k + 1] = b.last_vals[k];
     }
-    h->nnz_expanded = (int64_t)nent * Cout * Cin + (int64_t)b.last_rows.size();
+    // nnz of the expansion = what the reference's csr holds: one stored entry per (output pixel, input pixel) PAIR and channel pair -- several slots on one pair
+    // (a filled-in operator) are one stored non-zero
+    int64_t n_pairs = 0;
+    if (order.size() == nent) {
+        for (size_t k = 0; k < order.size(); k++)
+            if (k == 0 || b.ent_out[order[k - 1]] != b.ent_out[order[k]] || b.ent_in[order[k - 1]] != b.ent_in[order[k]]) n_pairs++;
+    } else {                                               // (entries of all-zero taps were left out of the slot lists but are stored by the reference)
+        std::vector<int64_t> key(nent);
+        for (size_t e = 0; e < nent; e++) key[e] = (int64_t)b.ent_out[e] * HiWi + b.ent_in[e];
+        std::sort(key.begin(), key.end());
+        n_pairs = (int64_t)(std::unique(key.begin(), key.end()) - key.begin());
+    }
+    h->nnz_expanded = n_pairs * Cout * Cin + (int64_t)b.last_rows.size();
     h->nnz_stored = b.nnz_stored > 0 ? b.nnz_stored : ntaps * Cout * Cin + (int64_t)nent + (int64_t)b.last_rows.size();
 
     // small-K pipeline descriptors (layout: kn_conv.hip SK_DESC_HDR): eligible when one pixel's whole contraction (slots x Cin + bias
@@ -317,7 +336,7 @@ static int convtaps_create_impl(ConvBuild& b, kn_operator** out) {
     if ((!sk_desc.empty() && (rc = upload(&c.sk_desc, sk_desc.data(), sk_desc.size()))) || (rc = upload(&c.tapsT, tapsT.data(), tapsT.size())) || (rc = upload(&c.pix_ptr, pix_ptr.data(), pix_ptr.size())) ||
         (rc = upload(&c.slot_in, slot_in.data(), slot_in.size())) || (rc = upload(&c.slot_tap, slot_tap.data(), slot_tap.size())) ||
         (rc = upload(&c.slot_coef, slot_coef.data(), slot_coef.size())) || (rc = upload(&c.pix_order, pix_order.data(), pix_order.size())) ||
-        (rc = upload(&c.lastcol, lastcol.data(), lastcol.size())))
+        (rc = upload(&c.lastcol, lastcol.data(), lastcol.size())) || (!fill_ptr.empty() && (rc = upload(&c.fill_ptr, fill_ptr.data(), fill_ptr.size()))))
         return rc;
     *out = h.release();
     return KN_OK;
@@ -914,6 +933,11 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
         if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr && plan_sink() == nullptr) {
             std::lock_guard<std::mutex> g(h->lazy_mu);           // bf16 planes of the taps, once (not capturable: like any first use)
             rc = convtaps_build_bf16(h->ct, h->h_taps);
+            if (rc) return rc;
+        }
+        if ((flags & KN_FLAG_EXACT) && h->ct.fill_rec == nullptr && plan_sink() == nullptr && convtaps_fill_ok(h->ct)) {
+            std::lock_guard<std::mutex> g(h->lazy_mu);           // record lists of the filled-in order-preserving kernel, once (built on the device, on this stream)
+            rc = convtaps_build_fill(h->ct, s);
             if (rc) return rc;
         }
         rc = convtaps_spmm(h->ct, h->rows, h->cols, x_dev, ldx, n_vecs, y_dev, ldy, flags, s, absmax, &fused);

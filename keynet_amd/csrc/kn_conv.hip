@@ -1297,6 +1297,275 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
     }
 }
 
+// ---- KN_FLAG_EXACT on FILLED-IN operators (round 5) ------------------------------------------------------------------------------------
+// A float key whose inverse is dense inside its blocks (the reference's doubly-stochastic keys, test/test_keynet.py:116-129) fills the keyed conv in:
+// 500 - 5 400 slots per output pixel instead of 9, and one (output pixel, input pixel) pair is hit by several taps -- ONE stored non-zero of the
+// reference's matrix, whose value is the f32 sum of its terms fl(coef * tap) in entry order.  convtaps_exact_kernel above forms those stored values on
+// every lane (the value of an entry does not depend on the batch column: 64 lanes repeat the same multiplies and adds) and waits for every load; here
+//   * lane l forms the stored value of output channel co0 + (l & 31) only: one 128-byte load of tapsT[tap][ci][co0 ..], one v_mul_f32 by the slot's
+//     coefficient, one v_add_f32 per further term of the column -- each value is formed once per 64 batch columns instead of 64 times;
+//   * the 32 x 64 rounded products of a stored column come from ONE matrix instruction with a zero accumulator (v_mfma_f32_32x32x1_2b_f32: bit-identical
+//     to v_mul_f32, kn_csr_mfma.hip) and 16 packed adds put them on the running sums -- separate rounding of product and sum, the expansion's column order
+//     (input channel outer, the pixel's input pixels ascending inner): the reference's arithmetic, bit for bit;
+//   * the walk is scalar: the pixel's slot list is a list of 16-byte records {input pixel, tap offset, coefficient, first | last slot of its column}
+//     (convtaps_fill_records_kernel, padded to a multiple of 8 with records that change nothing) fetched four at a time by s_load_dwordx4, one batch
+//     ahead; the operand loads of a slot (activation row segment + value row) run PF = 8 slots ahead in a register ring with counted vmcnt waits.
+// One wavefront = one output pixel x 32 output channels x 64 batch columns; no LDS, no barriers.
+// TREG (operators with at most 16 taps: every conv window up to 4 x 4): the lane's value row lives in REGISTERS -- 16 VGPRs hold tapsT[0 .. ntaps)[ci][co0 + (l & 31)],
+// reloaded when the walk enters the next input channel -- and a slot picks its tap by the scalar index mode (s_set_gpr_idx_on): no value-row load per slot, half the
+// vector-memory instructions (the CU's one address unit serves four SIMDs).
+struct FillRec {
+    int32_t in, tapoff;     // tapoff: offset of the tap's plane in tapsT (floats), or the tap index (TREG)
+    float coef;
+    int32_t flags;          // bit 0: first slot of a stored column, bit 1: last
+};
+
+__global__ __launch_bounds__(256) void convtaps_fill_records_kernel(const int32_t* __restrict__ pix_ptr, const int32_t* __restrict__ fill_ptr, const int32_t* __restrict__ slot_in,
+                                                                    const int32_t* __restrict__ slot_tap, const float* __restrict__ slot_coef, int unit_coef, int tap_stride /* 1: tap index (TREG) */,
+                                                                    int HoWo, FillRec* __restrict__ rec) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= HoWo) return;
+    const int lane = threadIdx.x & 63;
+    const int s_beg = pix_ptr[o], n = pix_ptr[o + 1] - s_beg;
+    const int r_beg = fill_ptr[o], n_pad = fill_ptr[o + 1] - r_beg;
+    for (int k = lane; k < n_pad; k += 64) {
+        FillRec r = {0, 0, 0.0f, 0};                       // padding: a slot that is neither first nor last adds 0 * tap to a value nobody reads
+        if (k < n) {
+            const int s = s_beg + k;
+            r.in = slot_in[s];
+            r.tapoff = slot_tap[s] * tap_stride;
+            r.coef = unit_coef ? 1.0f : slot_coef[s];
+            r.flags = ((k == 0 || slot_in[s - 1] != r.in) ? 1 : 0) | ((k == n - 1 || slot_in[s + 1] != r.in) ? 2 : 0);
+        }
+        rec[r_beg + k] = r;
+    }
+}
+
+#pragma clang fp contract(off)
+template <bool TREG>
+__global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p, const int32_t* __restrict__ fill_ptr, const FillRec* __restrict__ rec, int n_cc, int n_ct,
+                                                                     int64_t n_wg) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x32 __attribute__((ext_vector_type(32)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int PF = 8;                                  // slots in flight per wavefront (ring of operand registers) = one unrolled loop body
+    constexpr int LPS = TREG ? 1 : 2;                      // vector loads per slot
+    // workgroup -> XCD x = blockIdx & 7 owns a contiguous range of the work (pixels in processing order: the 196 pixels of a key block read the same input pixels)
+    const int64_t chunk = (n_wg + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (wg >= n_wg || (blockIdx.x >> 3) >= chunk) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t wi = wg * 4 + wave;                      // (pixel, channel block, column tile), column tile fastest
+    const int per_pix = n_cc * n_ct;
+    if (wi >= (int64_t)p.n_pix * per_pix) return;          // (wave-uniform; no barriers in this kernel)
+    const int pi = (int)(wi / per_pix);
+    const int rem = (int)(wi - (int64_t)pi * per_pix);
+    const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
+    const int co0 = __builtin_amdgcn_readfirstlane((rem / n_ct) * 32);
+    const int64_t c0 = (int64_t)(rem % n_ct) * 64;
+    const int64_t c = c0 + lane;
+    const bool active = c < p.n_vecs;
+    const int r_beg = __builtin_amdgcn_readfirstlane(fill_ptr[o]);
+    const int n_pad = __builtin_amdgcn_readfirstlane(fill_ptr[o + 1]) - r_beg;         // multiple of 8
+
+    f32x2 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] = f32x2{0.0f, 0.0f};
+
+    if (n_pad > 0) {
+        auto uni = [](const uint64_t v) {
+            return ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+        };
+        const uint64_t rbase = uni(reinterpret_cast<uint64_t>(rec + r_beg));
+        const uint64_t xbase = uni(reinterpret_cast<uint64_t>(p.X));
+        const uint64_t abase = uni(reinterpret_cast<uint64_t>(p.tapsT + co0));
+        const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);                 // lane's byte offset inside an activation row (inactive lanes: a valid address, result unused)
+        const uint32_t a_off = 4u * (uint32_t)(lane & 31);                       // lane's byte offset inside the 32 values of a value row
+        const uint32_t ldx_b = 4u * (uint32_t)p.ldx;                             // (HiWi * ldx * 4 < 2^32: checked by the launcher)
+        const uint64_t ci_step = (uint64_t)(uint32_t)p.HiWi * ldx_b;             // bytes between the planes of two input channels
+        const int n_bat = n_pad >> 2;                      // record batches (4 slots) per input channel; even
+        // fetch cursor (wave-uniform): batch index inside the pixel's list, input channel (as activation-row and value-row offsets)
+        int bq = 0;                                        // batch whose records are loaded next
+        int ci_left = p.Cin - 1;                           // input channels behind the one the fetch cursor is in
+        int bf = 0;                                        // batch the vector fetches read next
+        uint64_t x_ci = xbase;                             // activation plane of the fetch cursor's input channel
+        uint32_t ci_a = 0;                                 // ci * cout_pad of the fetch cursor
+        i32x4 R0[4], R1[4];                                // two record batches
+        auto load_batch = [&](i32x4 (&R)[4]) {             // s_load the four records of batch bq, advance bq (past the pixel's last batch: its first again)
+            const uint64_t a = rbase + 64ull * (uint64_t)(uint32_t)bq;
+            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(R[0]) : "s"(a));
+            asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=&s"(R[1]) : "s"(a));
+            asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=&s"(R[2]) : "s"(a));
+            asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=&s"(R[3]) : "s"(a));
+            bq = (bq + 1 == n_bat) ? 0 : bq + 1;
+        };
+        auto batch_landed = [&](i32x4 (&R)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R[0]), "+s"(R[1]), "+s"(R[2]), "+s"(R[3])); };
+        float xa[PF], xb[PF], cfr[PF];
+        int flr[PF], tpr[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            xa[q] = xb[q] = 0.0f;
+            cfr[q] = 0.0f;
+            flr[q] = tpr[q] = 0;
+        }
+        // the vector loads of one slot into ring position q (activation row segment; value row unless TREG); its coefficient, flags and tap ride along in scalar registers
+        auto fetch = [&](float& rb, float& ra, float& cf, int& fl, int& tp, const i32x4 r) {
+            const uint32_t xoff = (uint32_t)r.x * ldx_b + b_off;                  // (one scalar multiply + one vector add: the 64-bit scalar add-with-carry it replaces cost two issue slots of the scalar unit)
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(xoff), "s"(x_ci));
+            if constexpr (!TREG) {
+                const uint64_t aaddr = abase + 4ull * (uint64_t)(ci_a + (uint32_t)r.y);
+                asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra) : "v"(a_off), "s"(aaddr));
+            }
+            tp = r.y;
+            const int cbits = r.z;                         // (through a scalar: __builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler)
+            cf = __builtin_bit_cast(float, cbits);
+            fl = r.w;
+        };
+        auto batch_done = [&]() {                          // the fetch cursor leaves a batch: next batch, next input channel behind the pixel's last one (past the end: the last channel again)
+            if (++bf == n_bat) {
+                bf = 0;
+                if (ci_left > 0) {
+                    ci_left--;
+                    x_ci += ci_step;
+                    ci_a += (uint32_t)p.cout_pad;
+                }
+            }
+        };
+        auto landed = [&](float& rb, float& ra) {
+            if constexpr (TREG) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rb) : "n"(LPS * (PF - 1)));
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb), "+v"(ra) : "n"(LPS * (PF - 1)));
+        };
+        // prologue: slots 0 .. 7 in flight, the records of slots 8 .. 11 on their way
+        load_batch(R0);
+        batch_landed(R0);
+        load_batch(R1);
+        fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], R0[0]);
+        fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], R0[1]);
+        fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], R0[2]);
+        fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], R0[3]);
+        batch_done();
+        batch_landed(R1);
+        load_batch(R0);
+        fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], R1[0]);
+        fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], R1[1]);
+        fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], R1[2]);
+        fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], R1[3]);
+        batch_done();
+        batch_landed(R0);                                  // (no scalar load is in flight across the loop's back edge: the compiler may copy a loop-carried register tuple there)
+
+        f32x32 d;                                          // the products of the last finished column, not yet on the running sums
+#pragma unroll
+        for (int q = 0; q < 32; q++) d[q] = 0.0f;
+        f32x32 zero;
+#pragma unroll
+        for (int q = 0; q < 32; q++) zero[q] = 0.0f;
+        float arun = 0.0f;                                 // stored value of the column being formed (this lane's output channel)
+        // one slot: its term joins the column's value; behind the column's last term the PREVIOUS column's products go onto the running sums (16 packed adds) and this
+        // column's products are formed (one matrix instruction, zero accumulator) -- the adds of column k sit behind the matrix instruction of column k by at least one slot
+        f32x16 At;                                         // TREG: this lane's value row, one register per tap, for the input channel the walk is in
+#pragma unroll
+        for (int q = 0; q < 16; q++) At[q] = 0.0f;
+        const int nb8 = n_pad >> 3;                        // loop bodies per input channel
+        int body_left = 0;                                 // bodies until the walk enters the next input channel
+        const float* a_ci = p.tapsT + co0 + (lane & 31);   // TREG: tapsT[0][ci][co0 + (l & 31)] of the channel the walk enters next
+        auto consume = [&](float& rb, float& ra, const float cf, const int fl, const int tp) {
+            landed(rb, ra);
+            const float av = TREG ? At[tp] : ra;           // (TREG: scalar index mode, no memory access)
+            const float t = cf * av;                       // fl(coef * tap): the term as the reference stores it (coef == 1: the tap itself)
+            arun = arun + t;                               // (the column's first term joins +0.0: the same value bit for bit but for the sign of a zero, which no sum that starts at +0.0 can show)
+            if (fl & 2) {
+                acc[0] = acc[0] + f32x2{d[0], d[1]};       // (compiler-visible: the hazard recognizer spaces this first reader of the matrix instruction's result; the rest follow it)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 1; q < 16; q++) {
+                    const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                    asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[q]) : "v"(p2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                d = __builtin_amdgcn_mfma_f32_32x32x1f32(arun, rb, zero, 0, 0, 0);
+                arun = 0.0f;
+            }
+        };
+        const int n_it = (n_pad >> 3) * p.Cin;
+        for (int it = 0; it < n_it; it++) {
+            if constexpr (TREG) {
+                if (body_left == 0) {                      // the walk enters an input channel: its value row into the registers (the compiler's own loads and waits)
+                    body_left = nb8;
+                    const int tap_stride = p.cin_pad * p.cout_pad;
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        if (q < p.ntaps) At[q] = a_ci[(int64_t)q * tap_stride];
+                    a_ci += p.cout_pad;
+                    asm volatile("" : "+v"(At));           // the compiler's wait for these loads stays inside this block (a loop-carried pending load would put vmcnt(0) in front of every body)
+                }
+                body_left--;
+            }
+            // slots 0 .. 3 of this body; their ring positions are refilled from batch R0 (landed: loaded half a body ago), R1's next batch leaves now
+            load_batch(R1);
+            consume(xb[0], xa[0], cfr[0], flr[0], tpr[0]);
+            fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], R0[0]);
+            consume(xb[1], xa[1], cfr[1], flr[1], tpr[1]);
+            fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], R0[1]);
+            consume(xb[2], xa[2], cfr[2], flr[2], tpr[2]);
+            fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], R0[2]);
+            consume(xb[3], xa[3], cfr[3], flr[3], tpr[3]);
+            fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], R0[3]);
+            batch_done();
+            batch_landed(R1);
+            load_batch(R0);
+            consume(xb[4], xa[4], cfr[4], flr[4], tpr[4]);
+            fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], R1[0]);
+            consume(xb[5], xa[5], cfr[5], flr[5], tpr[5]);
+            fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], R1[1]);
+            consume(xb[6], xa[6], cfr[6], flr[6], tpr[6]);
+            fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], R1[2]);
+            consume(xb[7], xa[7], cfr[7], flr[7], tpr[7]);
+            fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], R1[3]);
+            batch_done();
+            batch_landed(R0);
+        }
+        // the products still pending; everything in flight lands (re-loads of valid rows, never used)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] = acc[q] + f32x2{d[2 * q], d[2 * q + 1]};
+        asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q]));
+    }
+    // epilogue: bias column last (separate multiply and add, skipped where the stored entry is absent), ReLU, store.
+    // D layout: register 16 * blk + r of lane l = (channel 8 * (r / 4) + 4 * (l / 32) + r % 4, column 32 * blk + l % 32).
+    const int half = lane >> 5;
+    const int64_t colo = c0 + (lane & 31);
+    float xl[2] = {0.0f, 0.0f};
+    if (p.lastcol) {
+#pragma unroll
+        for (int blk = 0; blk < 2; blk++)
+            if (colo + 32 * blk < p.n_vecs) xl[blk] = p.X[p.last_in_row * p.ldx + colo + 32 * blk];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int m = co0 + 8 * (r / 4) + 4 * half + (r % 4);
+        if (m < p.Cout) {
+            const int64_t row = (int64_t)m * p.HoWo + o;
+            const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++) {
+                const int64_t cc = colo + 32 * blk;
+                if (cc < p.n_vecs) {
+                    float v = acc[(16 * blk + r) / 2][(16 * blk + r) % 2];
+                    if (lc != 0.0f) {
+                        const float bp = lc * xl[blk];
+                        v = v + bp;
+                    }
+                    if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+                    p.Y[row * p.ldy + cc] = v;
+                }
+            }
+        }
+    }
+}
+
 // Software-pipelined instantiation of the order-preserving path for the common operator shape: unit coefficients
 // (identity / permutation keys) and no (output, input) pixel pair hit twice, so the contraction is a plain double loop
 // "ci ascending, slot ascending" with ONE stored value per step.  The slot table lives in two VGPRs (lane s = slot s,
@@ -1636,7 +1905,7 @@ __global__ __launch_bounds__(256) void conv_lastrow_kernel(const float* __restri
 }
 
 void convtaps_free(ConvTapsDev& c) {
-    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent, c.ex_ptr, c.ex_tab, c.ex_order};
+    void* ptrs[] = {c.tapsT, c.pix_ptr, c.slot_in, c.slot_tap, c.slot_coef, c.pix_order, c.lastcol, c.sk_desc, c.tapsB, c.zero_ent, c.ex_ptr, c.ex_tab, c.ex_order, c.fill_ptr, c.fill_rec};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c = ConvTapsDev();
@@ -1754,6 +2023,26 @@ static void launch_conv(ConvArgs a, const Tuning& tune, hipStream_t s) {
     else KN_LAUNCH(D("generic", false), (convtaps_mfma_kernel<MT, NB, KC, WM, WN, 0, false>), dim3((unsigned)grid), dim3(256), pad, s, a);
 }
 
+// Filled-in operators under KN_FLAG_EXACT: does this operator take convtaps_exact_fill_kernel?  (fill_ptr was laid out at create: convtaps_create_impl.)
+bool convtaps_fill_ok(const ConvTapsDev& A) { return A.fill_ptr != nullptr && A.fill_n > 0 && !A.tune.no_fill_exact; }
+
+// ... and its record lists, built on the device from the slot lists at the first kn_spmm that needs them (16 bytes per slot: VGG-16 under doubly-stochastic
+// keys 0.4 - 4 GB per layer that runs in the reference's order)
+int convtaps_build_fill(ConvTapsDev& A, hipStream_t s) {
+    if (A.fill_rec || !convtaps_fill_ok(A)) return KN_OK;
+    int32_t* d = nullptr;
+    KN_HIP(hipMalloc(reinterpret_cast<void**>(&d), (size_t)A.fill_n * sizeof(FillRec)));
+    const int HoWo = (int)(A.Hout * A.Wout);
+    hipLaunchKernelGGL(convtaps_fill_records_kernel, dim3((unsigned)((HoWo + 3) / 4)), dim3(256), 0, s, A.pix_ptr, A.fill_ptr, A.slot_in, A.slot_tap, A.slot_coef, A.unit_coef ? 1 : 0,
+                       A.ntaps <= 16 ? 1 : (int)(A.cin_pad * A.cout_pad), HoWo, reinterpret_cast<FillRec*>(d));
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(d);
+        return fail(KN_ERR_HIP, "convtaps_fill_records_kernel launch failed");
+    }
+    A.fill_rec = d;
+    return KN_OK;
+}
+
 // Can this operator / operand take convtaps_bf16x3_kernel?  (The planes must exist: convtaps_build_bf16 at first use, kn_api.hip.)
 bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy) {
     const bool wide = A.Cout > 64;
@@ -1834,6 +2123,7 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
     a.unit_coef = A.unit_coef ? 1 : 0;
     a.vec_ok = (n_vecs % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x) % 16 == 0) ? 1 : 0;
     a.n_pix = a.HoWo;
+    a.ntaps = (int32_t)A.ntaps;
     a.last_in_row = A.Cin * A.Hin * A.Win;
 
     a.stamps = nullptr;
@@ -1884,6 +2174,8 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         }
         // four activation rows in flight when the batch spans several 256-column tiles (the rows of a [D, 4096] block are L2 misses; at one tile --
         // VGG-16 at 256 images -- three rows in flight measured 2-3 % slower than two).  Tuning::exact_xd = 2 | 4 overrides (diagnostic build).
+        // filled-in operators (more than 64 slots per pixel, or several slots on one pixel pair): convtaps_exact_fill_kernel (its records exist from the first kn_spmm on)
+        const bool fill = !pipe && !table && convtaps_fill_ok(A) && (A.fill_rec != nullptr || plan_sink() != nullptr) && (int64_t)a.HiWi * ldx * 4 < ((int64_t)1 << 32);
         bool xd4 = n_ct >= 4;
         if (A.tune.exact_xd > 0) xd4 = A.tune.exact_xd == 4;
         if (table) {
@@ -1899,6 +2191,15 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         else if (pipe && rbx == 16) KN_LAUNCH("convtaps_exact_pipe_kernel<16,coef>", (convtaps_exact_pipe_kernel<16, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef>", (convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
+        else if (fill) {
+            const int n_cc = (int)((A.Cout + 31) / 32), n_ctf = (int)((n_vecs + 63) / 64);
+            const int64_t n_wg = ((int64_t)a.n_pix * n_cc * n_ctf + 3) / 4;
+            KN_REQUIRE(n_wg + 8 < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "grid too large for the filled-in order-preserving kernel");
+            const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? "<taps in registers>" : "") + " (stored values formed per lane, products on the matrix pipe, " +
+                                  std::to_string(A.fill_n) + " slot records)";
+            if (A.ntaps <= 16) KN_LAUNCH(d, convtaps_exact_fill_kernel<true>, dim3((unsigned)(((n_wg + 7) / 8) * 8)), dim3(256), 0, s, a, A.fill_ptr, reinterpret_cast<const FillRec*>(A.fill_rec), n_cc, n_ctf, n_wg);
+            else KN_LAUNCH(d, convtaps_exact_fill_kernel<false>, dim3((unsigned)(((n_wg + 7) / 8) * 8)), dim3(256), 0, s, a, A.fill_ptr, reinterpret_cast<const FillRec*>(A.fill_rec), n_cc, n_ctf, n_wg);
+        }
         else if (v4) KN_LAUNCH("convtaps_exact_kernel<vec=4>", convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else KN_LAUNCH("convtaps_exact_kernel<vec=1>", convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         if (A.has_last) {

@@ -136,6 +136,7 @@ struct Tuning {
     int big_mfma16 = -1;      // KN_BIG_MFMA16=0|1    a keyed Linear's 16-row chunks on the matrix pipe: never / always (-1: the dispatch rule)
     int mf_nrb = 1;           // KN_MF_NRB=1|2|3      32-row blocks per chunk of the matrix-pipe grouped kernel
     int table_nrb = 0;        // KN_TABLE_NRB=1|2|3   32-channel blocks per workgroup of the table kernel (0: the rule)
+    int no_fill_exact = 0;    // KN_NO_FILL_EXACT=1   filled-in conv operators (> 64 slots per pixel, or several slots on one (output, input) pixel pair) under KN_FLAG_EXACT: the generic kernel instead of convtaps_exact_fill_kernel
     // ---- diagnostic build only ----
     int occ = 0;              // KN_OCC               workgroups per CU cap of the 128 x 128 conv-taps launch (0: the rule)
     int no_tail_split = 0;    // KN_NO_TAIL_SPLIT
@@ -245,6 +246,11 @@ struct ConvTapsDev {
     int32_t* ex_ptr = nullptr;          // [HoWo + 1]
     int32_t* ex_tab = nullptr;          // [ex_ptr[HoWo]][2]
     int32_t* ex_order = nullptr;        // [HoWo] processing order of the pixels for the table kernel (strips, kn_convtaps_drop_zero_entries)
+    // filled-in operators under KN_FLAG_EXACT (kn_conv.hip, convtaps_exact_fill_kernel): per-pixel record lists {input pixel, tap offset, coefficient, first / last slot of
+    // a stored column}, each padded to a multiple of 8 records; fill_ptr at create, the records on the device at the first kn_spmm that asks for them
+    int32_t* fill_ptr = nullptr;        // [HoWo + 1] record offsets, or null when the operator is not eligible
+    int32_t* fill_rec = nullptr;        // [fill_n][4]
+    int64_t fill_n = 0;
     // bf16x3 path (kn_conv.hip, convtaps_bf16x3_kernel): the taps as three bf16 planes, built at the first kn_spmm that asks for them
     uint16_t* tapsB = nullptr;
     int64_t tapsB_plane = 0;
@@ -342,6 +348,8 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
 int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, hipStream_t s);
 void chain_free(ChainDev* c);
 int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps);
+int convtaps_build_fill(ConvTapsDev& A, hipStream_t s);
+bool convtaps_fill_ok(const ConvTapsDev& A);
 bool convtaps_bf16x3_ok(const ConvTapsDev& A, const float* x, int64_t ldx, int64_t n_vecs, const float* y, int64_t ldy);
 void csr_free(CsrDev& c);
 void convtaps_free(ConvTapsDev& c);

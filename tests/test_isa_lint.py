@@ -18,7 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'keynet_amd', 'csrc')
 
 PIPELINED = {
-    'kn_conv.hip': [r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn20convtaps_mfma_kernelILi\d+ELi\d+ELi16ELi\dELi\dELi2E'],
+    'kn_conv.hip': [r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn20convtaps_mfma_kernelILi\d+ELi\d+ELi16ELi\dELi\dELi2E',
+                    (r'_ZN2kn26convtaps_exact_fill_kernel', r'global_load_dword (v\d+), v\d+, s\[')],      # (pattern, what ITS asm-issued loads look like)
     'kn_csr.hip': [r'_ZN2kn21csr_group_pipe_kernel'],
     'kn_csr_mfma.hip': [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel'],
 }
@@ -52,6 +53,9 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
         assert int(m.group(1)) == 0, 'a kernel of %s uses scratch' % src
     checked = 0
     for pat in PIPELINED[src]:
+        load_re = ASM_LOAD.get(src, ASM_LOAD['default'])
+        if isinstance(pat, tuple):
+            (pat, load_re) = pat
         names = re.findall(r'^(%s[^\n:]*):' % pat, s, re.M)
         assert names, 'no kernel matches %s in %s' % (pat, src)
         for name in names:
@@ -64,7 +68,7 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
             # fixed point).  A register copy (v_mov / v_accvgpr) out of an owned register is the bug.  (Until round 4 the check took every register that is
             # EVER a load destination in the kernel as owned throughout a loop body; with more code paths per kernel the allocator re-uses such registers for
             # constants after their loads have long landed, which that rule flagged.)
-            pat_load = re.compile(ASM_LOAD.get(src, ASM_LOAD['default']))
+            pat_load = re.compile(load_re)
             labels = {l[:-1]: i for (i, l) in enumerate(lines) if l.endswith(':')}
             state_at = {}                                          # label -> tuple of register-sets, oldest load first
             n_loads = sum(1 for l in lines if pat_load.match(l))
@@ -129,6 +133,35 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
     assert checked >= len(PIPELINED[src])
 
 
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+def test_no_use_of_a_scalar_register_owned_by_a_scalar_load_in_flight(tmp_path):
+    """convtaps_exact_fill_kernel fetches its slot records with asm-issued s_load_dwordx4 one batch ahead and waits with an explicit s_waitcnt lgkmcnt(0).
+    The compiler takes the destination tuple as defined the moment the load is ISSUED: a copy of it ahead of the wait (seen once: loop-carried tuples
+    were moved at the loop header while their load was still in flight -- stale records, wild addresses) is the scalar twin of the bug the test above
+    looks for.  Between every such load and the next lgkmcnt(0) nothing may read or write its destination registers."""
+    s = _isa('kn_conv.hip', tmp_path)
+    names = re.findall(r'^(_ZN2kn26convtaps_exact_fill_kernel[^\n:]*):', s, re.M)
+    assert len(names) == 2, names
+    for name in names:
+        body = s[s.index(name + ':'):]
+        body = body[:body.index('.Lfunc_end')]
+        owned = set()
+        n_loads = 0
+        for l in (x.split(';')[0].strip() for x in body.split('\n')[1:]):
+            if not l or l.endswith(':') or l.startswith('.'):
+                continue
+            if l.startswith('s_waitcnt') and 'lgkmcnt(0)' in l:
+                owned = set()
+                continue
+            m = re.match(r's_load_dwordx4 s\[(\d+):(\d+)\]', l)
+            if m:
+                owned |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                n_loads += 1
+                continue
+            assert not (_regs(l, 's') & owned), (name, l)
+        assert n_loads >= 12, (name, n_loads)
+
+
 # ---- the bit-exact contract in the ISA -----------------------------------------------------------------------------------------------------
 # The order-preserving kernels must round every product and every sum separately (scipy's csr_matvecs: `y += a * x` compiled without
 # contraction; oracle/kn_oracle.c).  That hangs on -ffp-contract=off + `#pragma clang fp contract(off)`: one flag regression would pass every
@@ -141,7 +174,8 @@ ORDER_PRESERVING = {
     'kn_csr_f64.hip': [r'_ZN2kn'],
     'kn_csr_mfma.hip': [r'_ZN2kn'],
     'kn_chain.hip': [r'_ZN2kn12chain_kernel'],
-    'kn_conv.hip': [r'_ZN2kn21convtaps_exact_kernel', r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn26convtaps_zero_guard_kernel', r'_ZN2kn19conv_lastrow_kernel'],
+    'kn_conv.hip': [r'_ZN2kn21convtaps_exact_kernel', r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn26convtaps_exact_fill_kernel', r'_ZN2kn26convtaps_zero_guard_kernel',
+                    r'_ZN2kn19conv_lastrow_kernel'],
 }
 
 

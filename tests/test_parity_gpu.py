@@ -1287,6 +1287,111 @@ def test_convtaps_slot_groups_beyond_64_slots(Cin, Cout, H, k, n_vecs, unit):
     assert close_conditioned(yg.T, ref.T, (M.shape, M.indptr, M.indices, M.data), X.T)
 
 
+@pytest.mark.parametrize('Cin,Cout,H,k,n_vecs,unit,has_last', [
+    (4, 32, 8, 3, 64, False, True),        # several taps on one (output, input) pixel pair, float coefficients: 9 - 14 slots per pixel, one 64-column tile
+    (3, 40, 8, 3, 100, False, True),       # Cout not a multiple of 32 (second channel block half empty), ragged column tile
+    (5, 64, 10, 9, 64, True, True),        # 81 slots per pixel (two and a bit record batches of 8 per 16), unit coefficients, no pair hit twice
+    (2, 33, 10, 9, 256, False, False),     # > 64 slots AND duplicate pairs, four column tiles, no bias column
+    (6, 96, 6, 5, 1, False, True),         # one batch column
+    (16, 128, 6, 3, 192, False, True),     # VGG-like channel counts, three column tiles
+])
+def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has_last):
+    """Filled-in operators in the reference's order (the reference's doubly-stochastic VGG-16, test/test_keynet.py:116-129: 500 - 5 400 slots per
+    output pixel, a pixel pair hit by several taps = ONE stored non-zero whose value is the f32 sum of its terms in entry order): convtaps_exact_fill_kernel
+    -- stored values formed once per wavefront, products on the matrix pipe, sums on the vector ALU -- is bit-equal to the oracle on the whole expansion
+    (scipy's COO -> CSR sums the duplicates in the same order) and to the generic order-preserving kernel (KN_NO_FILL_EXACT=1, a fresh handle), ReLU on and off,
+    and through a column window of a wider block."""
+    import os
+    rng = np.random.RandomState(3 * Cin + Cout + k + n_vecs)
+    W = _random_convtaps(rng, Cin, Cout, H, k, 1, unit, has_last)
+    t = W._taps
+    key = t['ent_out'].astype(np.int64) * (H * H) + t['ent_in']
+    dups = len(np.unique(key)) < len(key)
+    slots = int(np.bincount(t['ent_out']).max())
+    assert dups == (not unit) and (dups or slots > 64), (dups, slots)
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+    assert 'convtaps_exact_fill_kernel' in plan, plan
+    wide = n_vecs + 37
+    X = rng.randn(W.shape[1], wide).astype(np.float32)
+    if has_last:
+        X[-1] = 1.0
+    xd = torch.as_tensor(X).to(dev())
+    M = W.tosparse('csr')
+    M.sort_indices()
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    for relu in (False, True):
+        r = np.maximum(ref, 0) if relu else ref
+        ye = W.torchdot(xd[:, :n_vecs].contiguous(), relu=relu, exact=True).cpu().numpy()
+        assert np.array_equal(ye, r[:, :n_vecs]), (relu, np.abs(ye - r[:, :n_vecs]).max())
+    # a column window of the wider block through the C ABI (ldx = ldy = wide, window at column 5)
+    yw = torch.full((W.shape[0], wide), -7.0, dtype=torch.float32, device=dev())
+    with torch.cuda.device(dev()):
+        W._device_op(dev()).spmm(xd.data_ptr() + 4 * 5, wide, n_vecs, yw.data_ptr() + 4 * 5, wide, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+    yw = yw.cpu().numpy()
+    assert np.array_equal(yw[:, 5:5 + n_vecs], ref[:, 5:5 + n_vecs]) and np.all(yw[:, :5] == -7.0) and np.all(yw[:, 5 + n_vecs:] == -7.0)
+    os.environ['KN_NO_FILL_EXACT'] = '1'
+    try:
+        Wg = copy.deepcopy(W)
+        Wg._op = None
+        with torch.cuda.device(dev()):
+            pg = Wg._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        yg = Wg.torchdot(xd[:, :n_vecs].contiguous(), exact=True).cpu().numpy()
+    finally:
+        del os.environ['KN_NO_FILL_EXACT']
+    assert 'convtaps_exact_kernel' in pg and 'no_fill_exact=1' in pg, pg
+    assert np.array_equal(yg, ref[:, :n_vecs])
+
+
+def test_convtaps_exact_fill_kernel_sums_a_pairs_terms_in_entry_order():
+    """Up to six terms on one (output, input) pixel pair (the doubly-stochastic VGG-16 has nine where a pixel's own key block is concerned): the stored value of
+    the pair is fl(...fl(fl(c1 w1) + fl(c2 w2)) + ... ) in ENTRY order (scipy's own COO -> CSR conversion sorts with an unstable sort, so with three or more
+    terms it defines no order: the factored operator's entry order is the contract, kn_export_csr and the generic kernel follow it).  The reference here is
+    built without the kernel's help: per pair the sequential float32 sum of its terms becomes the single tap of an equivalent duplicate-free operator, whose
+    canonical CSR goes through the oracle."""
+    rng = np.random.RandomState(11)
+    (Cin, Cout, H, n_vecs) = (3, 48, 6, 96)
+    HW = H * H
+    taps = (rng.randn(9, Cout, Cin) / 3).astype(np.float32)
+    (eo, ei, et, ec) = ([], [], [], [])
+    for o in range(HW):
+        for i in rng.choice(HW, size=rng.randint(1, 9), replace=False):
+            k = rng.randint(1, 7)
+            for t in rng.choice(9, size=k, replace=False):          # NOT ascending: entry order, not tap order
+                eo.append(o); ei.append(i); et.append(t); ec.append(np.float32(rng.randn()))
+    (eo, ei, et, ec) = (np.array(eo, np.int32), np.array(ei, np.int32), np.array(et, np.int32), np.array(ec, np.float32))
+    lastcol = np.concatenate((rng.randn(Cout * HW), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, eo, ei, et, ec, lastcol)
+    with torch.cuda.device(dev()):
+        plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        assert W._device_op(dev()).nnz_expanded() == len(set(zip(eo.tolist(), ei.tolist()))) * Cout * Cin + int(np.count_nonzero(lastcol))
+    assert 'convtaps_exact_fill_kernel<taps in registers>' in plan, plan
+    # the equivalent duplicate-free operator: one tap per pair, value = the terms' sequential float32 sum in entry order
+    order = np.lexsort((np.arange(len(eo)), ei, eo))                # stable: by (out, in), entry order inside a pair
+    (pairs, vals) = ([], [])
+    for e in order:
+        term = (ec[e] * taps[et[e]]).astype(np.float32) if ec[e] != 1.0 else taps[et[e]]
+        if pairs and pairs[-1] == (eo[e], ei[e]):
+            vals[-1] = (vals[-1] + term).astype(np.float32)
+        else:
+            pairs.append((eo[e], ei[e]))
+            vals.append(term.copy())
+    Wd = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), np.stack(vals), np.array([q[0] for q in pairs], np.int32), np.array([q[1] for q in pairs], np.int32),
+                                        np.arange(len(pairs), dtype=np.int32), None, lastcol)
+    M = Wd.tosparse('csr')
+    M.sort_indices()
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    X[-1] = 1.0
+    ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+    y = W.torchdot(torch.as_tensor(X).to(dev()), exact=True).cpu().numpy()
+    assert np.array_equal(y, ref), np.abs(y - ref).max()
+    # kn_export_csr: the same stored values
+    E = W._device_op(dev()).export_csr() if hasattr(W._device_op(dev()), 'export_csr') else None
+    if E is not None:
+        (ip, ix, dt) = E
+        assert np.array_equal(ip, M.indptr) and np.array_equal(ix, M.indices) and np.array_equal(dt, M.data.astype(np.float32))
+
+
 @pytest.mark.parametrize('case', range(10))
 def test_convtaps_random_shapes(case):
     """Randomised conv-taps operators (odd channel counts, stride 2, 1x1 / 3x3 / 5x5 windows, several float-coefficient
