@@ -372,7 +372,7 @@ def layer_table(knet, batch):
             op = c.W._device_op()
             (r, cdim) = op.shape()
             nnz_exp = op.nnz_expanded()
-            kind = 'convexact' if exact else ('smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps')
+            kind = 'convexact' if exact else ('convsplit' if contract == 'split' else ('smallk' if _takes_small_k_kernel(c.W, batch) else 'convtaps'))
             wbytes = 4 * c.W.nnz()             # taps + entries + last column actually read
         elif isinstance(c.W, ksp.FactoredSparseMatrix):
             # an untiled keyed conv whose stored CSR is provably the expansion of its factored form: runs the order-preserving conv pipeline from
@@ -392,7 +392,13 @@ def layer_table(knet, batch):
         plan = (c.W._dense_device_op() if kind == 'dense' else op).plan(batch, flags)
         if 'bf16x3' in plan:
             kind = 'convbf16x3'
-        rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch,
+        flops_exec = None
+        if kind == 'convsplit':                # the split application (Conv2dTiledMatrix._split_ops): spatial CSR per input channel, then an ntaps-slot conv-taps operator
+            (opK, op2) = c.W._split_ops()
+            t = c.W._taps
+            plan = '%d x [%s]; %s' % (c.W._inshape[0], opK.plan(batch, 2), op2.plan(batch, flags & 1))
+            flops_exec = 2.0 * batch * (len(t['ent_out']) * c.W._inshape[0] + len(t['taps']) * c.W._outshape[1] * c.W._outshape[2] * c.W._inshape[0] * c.W._outshape[0])
+        rows.append(dict(name=name, kind=kind, rows=r, cols=cdim, nnz=nnz_exp, flops=2.0 * nnz_exp * batch, flops_executed=flops_exec,
                          bytes=float(wbytes) + 4.0 * batch * (r + cdim), layer=c, plan=plan,
                          fuse=(i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)))
     return rows
@@ -471,6 +477,12 @@ def roofline_of(table, workload, batch, mode):
         return dict(bound='mfma', kernel='convtaps_bf16x3_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=peak, unit='TFLOP/s (f32-equivalent)', frac=ach / peak, traffic=None,
                     algorithmic_flops=sum(r['flops'] for r in dom), algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
                     note='peak = six v_mfma_f32_32x32x16_bf16 per f32 product block at 16x the f32-input MFMA rate: 157.3 * 16 / 6')
+    if kind == 'convsplit':
+        ach = sum(r['flops_executed'] for r in dom) / dom_ms / 1e9
+        return dict(bound='mfma', kernel='split application of filled-in conv layers: spatial CSR kernels per input channel + convtaps_mfma_kernel (%d layers/forward)' % len(dom), achieved=ach,
+                    peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s (executed)', frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=None, algorithmic_flops=sum(r['flops'] for r in dom),
+                    executed_flops=sum(r['flops_executed'] for r in dom), algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
+                    note='algorithmic_flops = the stored entries of the fused operator the reference applies; the split application executes executed_flops for the same product')
     if kind in ('convtaps', 'dense'):
         dom = kinds.get('convtaps', []) or dom
         dom_ms = sum(r['ms'] for r in dom)

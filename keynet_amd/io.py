@@ -11,7 +11,7 @@ Schema (also the schema of tests/golden/*.npz, written by tests/golden/make_gold
     convtaps:     inshape, outshape, taps, ent_out, ent_in, ent_tap, ent_coef, lastcol [, tileshape]
     L.<name>.exact                   (save_keynet only) the layer's arithmetic contract IN FORCE when it was saved, as a string: 'exact' = the
                                      reference's accumulation order and rounding, 'mfma' = f32 matrix cores, 'bf16x3' = f32 products emulated
-                                     on the bf16 matrix pipe, 'auto' = not decided yet (float-key tolerance 1e-5, decided at the first forward);
+                                     on the bf16 matrix pipe, 'split' = a filled-in conv applied as spatial mixing then channel mixing, 'auto' = not decided yet (float-key tolerance 1e-5, decided at the first forward);
                                      absent (golden files) = the default.  (Older archives hold a bool, or the string 'auto'.)
     L.<name>.exact_decl              (save_keynet only) the contract the layer was DECLARED with (what exact_mode(None) returns to)
     L.<name>.contract_record         (save_keynet only) JSON of the calibration record behind a decided 'auto' layer (measured difference,
@@ -118,7 +118,7 @@ def operator_to_arrays(W, p, out):
 
 
 def _contract_from_array(a, what):
-    """'exact' / 'mfma' / 'auto' / 'bf16x3' (or a bool of an older archive) -> True / False / 'auto' / 'bf16x3'; anything else is refused."""
+    """'exact' / 'mfma' / 'auto' / 'bf16x3' / 'split' (or a bool of an older archive) -> True / False / 'auto' / 'bf16x3' / 'split'; anything else is refused."""
     if a.dtype.kind in 'US':
         v = str(a)
         if v not in CONTRACTS:

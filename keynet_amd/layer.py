@@ -91,11 +91,11 @@ def _contract(exact, bit_exact_default):
     return bool(exact)
 
 
-CONTRACTS = ('exact', 'mfma', 'auto', 'bf16x3')
+CONTRACTS = ('exact', 'mfma', 'auto', 'bf16x3', 'split')
 
 
 def contract_name(c):
-    """True / False / 'auto' / 'bf16x3' -> 'exact' / 'mfma' / 'auto' / 'bf16x3' (the on-disk and reporting vocabulary)."""
+    """True / False / 'auto' / 'bf16x3' / 'split' -> 'exact' / 'mfma' / 'auto' / 'bf16x3' / 'split' (the on-disk and reporting vocabulary)."""
     return c if isinstance(c, str) else ('exact' if c else 'mfma')
 
 
@@ -222,17 +222,20 @@ class KeyedLayer(nn.Module):
             if absmax is not None:
                 _absmax_into(y.t(), absmax)
             return y
+        if exact == 'split' and not (isinstance(self.W, ksp.Conv2dTiledMatrix) and self.W._taps is not None):
+            exact = False                                         # (forced with exact_mode('split') on an operator that has no split form: the matrix cores)
         y = self.W.torchdot(x_affine.t(), relu=(fuse_relu or self.iskeyedrelu()), exact=exact, absmax=absmax).t()
         return y
 
     # -- float-key contract: decided by calibration, re-screened on every forward --------------------------------------
     RESCREEN_FACTOR = 2.0        # a layer is re-calibrated when max |x| exceeds the calibrated value by more than this factor
+    ALLOW_SPLIT = True           # calibration offers the split application to filled-in conv operators (set False to put the fused kernels side by side with it)
 
     def screened(self):
         """Runs this layer on a re-ordering kernel (matrix cores) BY A CALIBRATION DECISION?  Then every forward must check that the
         decision still covers its input (a layer forced there with exact_mode(False) / 'bf16x3' is the caller's responsibility)."""
         rec = getattr(self, '_contract_record', None)
-        return getattr(self, '_exact', True) in (False, 'bf16x3') and rec is not None and rec.get('max_abs_x') is not None
+        return getattr(self, '_exact', True) in (False, 'bf16x3', 'split') and rec is not None and rec.get('max_abs_x') is not None
 
     def rescreen(self, xmax):
         """max |x| of a later batch against the calibrated one: True = the decision does not cover this batch (re-calibrate).  The measured
@@ -299,15 +302,30 @@ class KeyedLayer(nn.Module):
                     self._contract_record = dict(layer=self._repr, decided='bf16x3', measured_bf16x3_vs_exact=meas, tol=tol_b, gate_ratio=ratio, max_abs_diff=dmax,
                                                  max_abs_y=ymax_b, measured_on_columns=cols, measured_from_column=c0, max_abs_x=xmax)
                     return W.torchdot(xt, relu=relu, exact='bf16x3').t()
-        y = W.torchdot(xt, relu=relu, exact=False)
         asum = getattr(self, '_abs_rowsum', None)
         if asum is None:
             asum = self._abs_rowsum = W.max_abs_rowsum()
-        ymax = float(y.abs().max())
         bound = 2.0 * EPS32 * asum * xmax
+        # first candidate for a FILLED-IN factored conv (a key whose inverse is dense inside its blocks: 500 - 5 400 slots per output pixel): the split
+        # application -- spatial mixing per tap, then channel mixing (Conv2dTiledMatrix._split_ops: 1/10 - 1/30 of the fused operator's multiply-adds).
+        # Another association of the same sum: measured against the order-preserving kernel and accepted by the rule the matrix-core kernel is held to below.
+        ye_win = None
+        if isinstance(W, ksp.Conv2dTiledMatrix) and W.split_capable() and self.ALLOW_SPLIT:
+            ye_win = W.torchdot(xt[:, win], relu=relu, exact=True)
+            ys = W.torchdot(xt, relu=relu, exact='split')
+            (ratio_s, meas_s, tol_s, dmax_s) = gate(ys[:, win], ye_win)
+            if ratio_s <= 0.5 and (bound <= FLOAT_KEY_ATOL or ratio_s <= 0.25):
+                self._exact = 'split'
+                self._contract_record = dict(layer=self._repr, decided='split', max_abs_rowsum=asum, max_abs_x=xmax, max_abs_y=float(ys.abs().max()), tol=tol_s, bound=bound,
+                                             measured_split_vs_exact=meas_s, gate_ratio=ratio_s, max_abs_diff=dmax_s, measured_on_columns=cols, measured_from_column=c0,
+                                             fill_factor=W.fill_factor())
+                return ys.t()
+            del ys
+        y = W.torchdot(xt, relu=relu, exact=False)
+        ymax = float(y.abs().max())
         (ratio, measured, tol, dmax) = (None, None, FLOAT_KEY_ATOL, None)
         if isinstance(W, ksp.Conv2dTiledMatrix) or not (bound <= FLOAT_KEY_ATOL / self.RESCREEN_FACTOR):
-            ye = W.torchdot(xt[:, win], relu=relu, exact=True)
+            ye = ye_win if ye_win is not None else W.torchdot(xt[:, win], relu=relu, exact=True)
             (ratio, measured, tol, dmax) = gate(y[:, win].to(ye.device), ye)
             del ye
         # (a difference that is not finite -- Inf / NaN activations -- cannot be bounded: the reference's order it is)

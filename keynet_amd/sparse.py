@@ -115,6 +115,8 @@ class SparseMatrix(object):
         d = dict(self.__dict__)
         d['_op'] = None   # device handles do not pickle; rebuilt lazily
         d['_op_dense'] = None
+        if '_op_split' in d:
+            d['_op_split'] = None
         return d
 
     def __add__(self, other):
@@ -574,15 +576,92 @@ class Conv2dTiledMatrix(TiledMatrix):
 
     def torchdot(self, x, relu=False, exact=False, absmax=None):
         """[cols, N] -> [rows, N].  exact=False: f32 MFMA path (f32-input matrix instructions, exact f32 products); exact=True: the
-        reference's accumulation order and rounding (order-preserving kernel on the factored operator); exact='bf16x3': f32 products
+        reference's accumulation order and rounding (order-preserving kernel on the factored operator); exact='split': a filled-in factored
+        operator applied as spatial mixing per tap, then channel mixing (see _split_ops: another association of the sum, tolerance contract only); exact='bf16x3': f32 products
         emulated on the bf16 matrix pipe (three-way exact split, six of nine cross products, f32 accumulate: KN_FLAG_BF16X3) where the
         operator and batch qualify, else the f32 MFMA path."""
         if isinstance(x, np.ndarray):
             x = torch.as_tensor(x)
         if isinstance(exact, str):
-            assert exact == 'bf16x3', "exact must be True, False or 'bf16x3'"
+            assert exact in ('bf16x3', 'split'), "exact must be True, False, 'bf16x3' or 'split'"
+            if exact == 'split':
+                return self._torchdot_split(x, relu=relu, absmax=absmax)
             return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=False, extra_flags=_capi.KN_FLAG_BF16X3, absmax=absmax)
         return _run_torchdot(self._device_op, self.shape, x, relu=relu, exact=exact, absmax=absmax)
+
+    # ---- the SPLIT application of a filled-in operator (tolerance contract only) -----------------------------------------------------
+    # A factored keyed conv is  sum_t F_t (x) K_t  with F_t the Cout x Cin matrix of tap t and K_t = a_out S_t a_in^-1 the HoWo x HiWi spatial
+    # matrix of its entries (keynet_amd/direct.py).  The fused operator the reference stores costs  slots x Cin x Cout  multiply-adds per output
+    # pixel and batch column; under a key whose inverse is dense inside its blocks (doubly-stochastic keys: 500 - 5 400 slots per pixel instead
+    # of 9) that is 60x the un-keyed layer.  The same product in two steps --
+    #     Z_t[ci] = K_t X[ci]                  (spatial mixing: one CSR of all taps' entries, applied to every input channel's plane)
+    #     Y       = sum_t F_t Z_t              (channel mixing: an ordinary ntaps-slot conv-taps operator on Z, matrix cores, wave-uniform loaders)
+    # -- costs  slots x Cin + ntaps x Cin x Cout.  It holds nothing the fused factored form does not hold (the same taps, the same entries), but it
+    # is another association of the sum: NOT the reference's arithmetic, so it is a candidate of the float-key contract only (KeyedLayer._calibrate
+    # measures it against the order-preserving kernel like the matrix-core kernel; layers that fail run in the reference's order as before).
+    SPLIT_MIN_FILL = 2.0        # slots per (output pixel, tap) from which the split application is offered
+    SPLIT_Z_BYTES = 8 << 30     # the intermediate Z is produced in column windows of at most this size
+
+    def fill_factor(self):
+        """Entries per (output pixel, tap) of a factored operator: 1 for identity / permutation keys, 55 - 600 under doubly-stochastic keys."""
+        t = self._taps
+        if t is None or len(t['taps']) == 0:
+            return 0.0
+        return len(t['ent_out']) / float(len(t['taps']) * self._outshape[1] * self._outshape[2])
+
+    def split_capable(self):
+        return self._taps is not None and self.fill_factor() >= self.SPLIT_MIN_FILL
+
+    def _split_ops(self, device=None):
+        """(spatial CSR [ntaps * HoWo, HiWi], channel-mixing conv-taps operator on Z [Cin, ntaps, HoWo] -> [Cout, Hout, Wout]) resident on `device`."""
+        def make():
+            t = self._taps
+            (Cin, Hin, Win) = self._inshape
+            (Cout, Hout, Wout) = self._outshape
+            (HoWo, HiWi, nt) = (Hout * Wout, Hin * Win, len(t['taps']))
+            coef = t['ent_coef'] if t['ent_coef'] is not None else np.ones(len(t['ent_out']), np.float32)
+            K = scipy.sparse.csr_matrix((coef.astype(np.float32), (t['ent_tap'].astype(np.int64) * HoWo + t['ent_out'], t['ent_in'].astype(np.int64))), shape=(nt * HoWo, HiWi))
+            K.sort_indices()
+            assert K.nnz == len(coef), 'an (output pixel, input pixel, tap) triple appears twice'
+            opK = _capi.Operator.csr(K.shape, K.indptr, K.indices, K.data)
+            eo = np.tile(np.arange(HoWo, dtype=np.int32), nt)
+            et = np.repeat(np.arange(nt, dtype=np.int32), HoWo)
+            op2 = _capi.Operator.convtaps((Cin, nt, HoWo), self._outshape, t['taps'], eo, (et.astype(np.int64) * HoWo + eo).astype(np.int32), et, None, t['lastcol'])
+            return (opK, op2)
+        return _on_device(self, '_op_split', make, device)
+
+    def _torchdot_split(self, x, relu=False, absmax=None):
+        assert self.shape[1] == x.shape[0], 'Non-conformal shape for W=%s, x=%s' % (str(self.shape), str(tuple(x.shape)))
+        if not torch.cuda.is_available():
+            raise _capi.KeynetHipError('keynet_amd: no MI355X visible -- the keyed forward has no CPU fallback')
+        src_device = x.device
+        xd = x.detach()
+        xd = xd if xd.dtype == torch.float32 else xd.float()
+        xd = xd if xd.is_cuda else xd.cuda()
+        xd = xd if xd.is_contiguous() else xd.contiguous()
+        (Cin, Hin, Win) = self._inshape
+        (HoWo, HiWi, nt) = (self._outshape[1] * self._outshape[2], Hin * Win, len(self._taps['taps']))
+        has_last = self._taps['lastcol'] is not None
+        n = int(xd.shape[1])
+        zrows = Cin * nt * HoWo + (1 if has_last else 0)
+        win = max(1, min(n, int(self.SPLIT_Z_BYTES // (4 * zrows))))
+        if win < n and win >= 128:
+            win -= win % 128                      # whole tiles of the matrix-core kernel per window
+        y = torch.empty((self.shape[0], n), dtype=torch.float32, device=xd.device)
+        flags = _capi.KN_FLAG_RELU if relu else 0
+        with torch.cuda.device(xd.device):
+            (opK, op2) = self._split_ops(xd.device)
+            st = _stream_ptr()
+            z = torch.empty((zrows, min(win, n)), dtype=torch.float32, device=xd.device)
+            for c0 in range(0, n, win):
+                w = min(win, n - c0)
+                ldz = int(z.shape[1])
+                for ci in range(Cin):             # the spatial CSR on every input channel's plane (rows ci * HiWi ..) -> Z rows ci * ntaps * HoWo ..
+                    opK.spmm(xd.data_ptr() + 4 * (ci * HiWi * n + c0), n, w, z.data_ptr() + 4 * ci * nt * HoWo * ldz, ldz, _capi.KN_FLAG_EXACT, st)
+                if has_last:
+                    z[-1, :w].copy_(xd[-1, c0:c0 + w])
+                op2.spmm(z.data_ptr(), ldz, w, y.data_ptr() + 4 * c0, n, flags, st, absmax_ptr=None if absmax is None else absmax.data_ptr())
+        return y if src_device.type == 'cuda' else y.to(src_device)
 
     def _expand_taps_host(self, pixels=None, channels=None):
         """Canonical CSR of a factored operator -- or of its output rows (co, o) for o in `pixels` only, numbered

@@ -332,6 +332,9 @@ class KeyedModel(object):
                     break
                 fuse = (i + 1 < len(children)) and isinstance(children[i + 1], nn.ReLU)
                 contract = getattr(c, '_exact', True)
+                if contract == 'split':
+                    steps = None                                   # a layer applied in two steps (Conv2dTiledMatrix._split_ops) is not one launch: simple path
+                    break
                 exact = contract is True or contract == 'auto'
                 W = c.W
                 relu = fuse or c.iskeyedrelu()
@@ -485,7 +488,7 @@ class KeyedModel(object):
                     rescreen=bool(self.RESCREEN and os.environ.get('KN_NO_RESCREEN') != '1' and any(r['screened'] for r in rows)),
                     recalibrations=int(self.__dict__.get('_recalibrations', 0)))
 
-    _LEVEL = {'bf16x3': 0, False: 1, True: 2}       # how conservative a decided contract is (sync_contract keeps the maximum over ranks)
+    _LEVEL = {'bf16x3': 0, 'split': 1, False: 2, True: 3}       # how conservative a decided contract is (sync_contract keeps the maximum over ranks)
 
     def sync_contract(self, group=None):
         """COLLECTIVE (every rank of `group` must call it, the same number of times): make the calibration decisions of replicated key-nets

@@ -1392,6 +1392,78 @@ def test_convtaps_exact_fill_kernel_sums_a_pairs_terms_in_entry_order():
         assert np.array_equal(ip, M.indptr) and np.array_equal(ix, M.indices) and np.array_equal(dt, M.data.astype(np.float32))
 
 
+def _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last=True):
+    """A factored conv operator shaped like a keyed conv under a key whose inverse is dense inside its blocks: every output pixel reads `fill` input pixels of
+    its neighbourhood through each of the nine taps, every entry with its own float coefficient (K_t = a_out S_t a_in^-1)."""
+    HW = H * H
+    taps = (rng.randn(9, Cout, Cin) / np.sqrt(9 * Cin)).astype(np.float32)
+    (eo, ei, et, ec) = ([], [], [], [])
+    for t in range(9):
+        for o in range(HW):
+            ins = rng.choice(HW, size=fill, replace=False)
+            eo.append(np.full(fill, o)); ei.append(ins); et.append(np.full(fill, t)); ec.append((rng.randn(fill) / np.sqrt(fill)).astype(np.float32))
+    lastcol = np.concatenate((rng.randn(Cout * HW), [1.0])).astype(np.float32) if has_last else None
+    return ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec), lastcol)
+
+
+@pytest.mark.parametrize('Cin,Cout,H,fill,n_vecs,has_last', [(16, 64, 6, 5, 128, True), (3, 40, 8, 3, 100, True), (32, 128, 4, 6, 256, False)])
+def test_split_application_of_a_filled_in_conv(Cin, Cout, H, fill, n_vecs, has_last):
+    """Conv2dTiledMatrix.torchdot(exact='split') (the reference's doubly-stochastic VGG-16): the factored operator sum_t F_t (x) K_t applied as
+    Z_t = K_t X per input channel, then Y = sum_t F_t Z_t -- the same product in another association, so held to the float-key bound against the order-preserving
+    kernel (bit-exact with the oracle on the whole expansion): ReLU on and off, max |Y| gathered in the second step's epilogue, and the intermediate produced in
+    several column windows."""
+    rng = np.random.RandomState(Cin + Cout + fill)
+    W = _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last)
+    assert W.split_capable() and abs(W.fill_factor() - fill) < 1e-9
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    if has_last:
+        X[-1] = 1.0
+    xd = torch.as_tensor(X).to(dev())
+    ye = W.torchdot(xd, exact=True).cpu().numpy()
+    M = W.tosparse('csr')
+    M.sort_indices()
+    if W._taps['ent_coef'] is not None and len(np.unique(W._taps['ent_out'].astype(np.int64) * H * H + W._taps['ent_in'])) == len(W._taps['ent_out']):
+        assert np.array_equal(ye, oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X))
+    for relu in (False, True):
+        slot = torch.zeros(1, dtype=torch.float32, device=dev())
+        ys = W.torchdot(xd, relu=relu, exact='split', absmax=slot).cpu().numpy()
+        r = np.maximum(ye, 0) if relu else ye
+        assert close_conditioned(ys.T, r.T, (M.shape, M.indptr, M.indices, M.data), X.T), (relu, np.abs(ys - r).max())
+        assert float(slot) == np.abs(ys).max()
+    whole = W.torchdot(xd, exact='split').cpu().numpy()
+    wcols = 128 if n_vecs % 128 == 0 else 48                      # whole 128-column tiles where the batch has them (what the product's window rule keeps), else ragged windows
+    W.SPLIT_Z_BYTES = 4 * (Cin * 9 * H * H + (1 if has_last else 0)) * wcols
+    try:
+        parts = W.torchdot(xd, exact='split').cpu().numpy()
+    finally:
+        del W.SPLIT_Z_BYTES
+    assert np.array_equal(parts, whole)                           # batch columns are independent: windows that keep the kernel instantiation change nothing
+
+
+def test_calibration_takes_the_split_application_for_a_filled_in_layer():
+    """KeyedLayer under the float-key contract ('auto'): a filled-in factored conv is offered the split application first; it is measured against the
+    order-preserving kernel on the calibration batch like the matrix-core kernel, accepted with 2x headroom, recorded, re-screened, and travels with a saved
+    key-net; with ALLOW_SPLIT off the same layer decides between the fused kernels as before."""
+    from keynet_amd.layer import KeyedLayer
+    rng = np.random.RandomState(5)
+    W = _filled_in_convtaps(rng, 16, 64, 6, 5)
+    L = KeyedLayer.fromoperator(W, 'Conv2d', inshape=W._inshape, outshape=W._outshape, exact='auto')
+    x = torch.as_tensor(np.concatenate((rng.randn(128, W.shape[1] - 1), np.ones((128, 1))), axis=1).astype(np.float32)).to(dev())
+    y1 = L.forward(x, fuse_relu=True)
+    assert L._exact == 'split' and L._contract_record['decided'] == 'split' and L._contract_record['gate_ratio'] <= 0.5 and L.screened()
+    ye = W.torchdot(x.t(), relu=True, exact=True).t()
+    assert float((y1 - ye).abs().max()) <= 1e-5 * max(1.0, float(ye.abs().max()))
+    assert torch.equal(L.forward(x, fuse_relu=True), y1)
+    assert not L.rescreen(float(x.abs().max())) and L.rescreen(3 * float(x.abs().max()))
+    KeyedLayer.ALLOW_SPLIT = False
+    try:
+        L2 = KeyedLayer.fromoperator(W, 'Conv2d', inshape=W._inshape, outshape=W._outshape, exact='auto')
+        L2.forward(x, fuse_relu=True)
+    finally:
+        KeyedLayer.ALLOW_SPLIT = True
+    assert L2._exact in (True, False) and L2._contract_record['decided'] in ('exact', 'mfma')
+
+
 @pytest.mark.parametrize('case', range(10))
 def test_convtaps_random_shapes(case):
     """Randomised conv-taps operators (odd channel counts, stride 2, 1x1 / 3x3 / 5x5 windows, several float-coefficient
