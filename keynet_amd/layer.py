@@ -310,7 +310,7 @@ class KeyedLayer(nn.Module):
         # application -- spatial mixing per tap, then channel mixing (Conv2dTiledMatrix._split_ops: 1/10 - 1/30 of the fused operator's multiply-adds).
         # Another association of the same sum: measured against the order-preserving kernel and accepted by the rule the matrix-core kernel is held to below.
         ye_win = None
-        if isinstance(W, ksp.Conv2dTiledMatrix) and W.split_capable() and self.ALLOW_SPLIT:
+        if isinstance(W, ksp.Conv2dTiledMatrix) and self.ALLOW_SPLIT and W.split_capable(n):
             ye_win = W.torchdot(xt[:, win], relu=relu, exact=True)
             ys = W.torchdot(xt, relu=relu, exact='split')
             (ratio_s, meas_s, tol_s, dmax_s) = gate(ys[:, win], ye_win)

@@ -609,8 +609,21 @@ class Conv2dTiledMatrix(TiledMatrix):
             return 0.0
         return len(t['ent_out']) / float(len(t['taps']) * self._outshape[1] * self._outshape[2])
 
-    def split_capable(self):
-        return self._taps is not None and self.fill_factor() >= self.SPLIT_MIN_FILL
+    def split_capable(self, n_vecs=None):
+        """Is the split application worth offering to this operator (at this batch width)?  A filled-in factored operator whose split form is estimated at
+        less than half the fused matrix-core launch: fused = entries x Cin x Cout multiply-adds at ~100 TFLOP/s (filled-in pixels run the slot-group / generic
+        loaders); split = entries x Cin on the CSR kernels (~10 T MAC/s) + ntaps x HoWo x Cin x Cout on the matrix cores (~120 TFLOP/s) + the intermediate
+        written and read once (~3 TB/s).  Givens-rotation keys (2 - 4 entries per pixel and tap) stay fused by this rule: their intermediate costs what the
+        saved multiply-adds give back."""
+        if self._taps is None or self.fill_factor() < self.SPLIT_MIN_FILL:
+            return False
+        if n_vecs is None:
+            return True
+        (Cin, Cout, HoWo) = (self._inshape[0], self._outshape[0], self._outshape[1] * self._outshape[2])
+        (ent, nt, n) = (float(len(self._taps['ent_out'])), float(len(self._taps['taps'])), float(n_vecs))
+        fused = 2.0 * ent * Cin * Cout * n / 100e12
+        split = 2.0 * ent * Cin * n / 10e12 + 2.0 * nt * HoWo * Cin * Cout * n / 120e12 + 2.0 * (4.0 * Cin * nt * HoWo * n) / 3e12
+        return split < 0.5 * fused
 
     def _split_ops(self, device=None):
         """(spatial CSR [ntaps * HoWo, HiWi], channel-mixing conv-taps operator on Z [Cin, ntaps, HoWo] -> [Cout, Hout, Wout]) resident on `device`."""

@@ -1392,7 +1392,7 @@ def test_convtaps_exact_fill_kernel_sums_a_pairs_terms_in_entry_order():
         assert np.array_equal(ip, M.indptr) and np.array_equal(ix, M.indices) and np.array_equal(dt, M.data.astype(np.float32))
 
 
-def _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last=True):
+def _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last=True, gentle=False):
     """A factored conv operator shaped like a keyed conv under a key whose inverse is dense inside its blocks: every output pixel reads `fill` input pixels of
     its neighbourhood through each of the nine taps, every entry with its own float coefficient (K_t = a_out S_t a_in^-1)."""
     HW = H * H
@@ -1401,7 +1401,8 @@ def _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last=True):
     for t in range(9):
         for o in range(HW):
             ins = rng.choice(HW, size=fill, replace=False)
-            eo.append(np.full(fill, o)); ei.append(ins); et.append(np.full(fill, t)); ec.append((rng.randn(fill) / np.sqrt(fill)).astype(np.float32))
+            eo.append(np.full(fill, o)); ei.append(ins); et.append(np.full(fill, t))
+            ec.append(((rng.rand(fill) / fill) if gentle else (rng.randn(fill) / np.sqrt(fill))).astype(np.float32))       # gentle: a well-conditioned averaging key
     lastcol = np.concatenate((rng.randn(Cout * HW), [1.0])).astype(np.float32) if has_last else None
     return ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec), lastcol)
 
@@ -1446,7 +1447,8 @@ def test_calibration_takes_the_split_application_for_a_filled_in_layer():
     key-net; with ALLOW_SPLIT off the same layer decides between the fused kernels as before."""
     from keynet_amd.layer import KeyedLayer
     rng = np.random.RandomState(5)
-    W = _filled_in_convtaps(rng, 16, 64, 6, 5)
+    W = _filled_in_convtaps(rng, 16, 64, 6, 20, gentle=True)
+    assert W.split_capable(128) and not _filled_in_convtaps(rng, 16, 64, 6, 3).split_capable(128)       # the cost rule: offered where the estimate is under half the fused launch
     L = KeyedLayer.fromoperator(W, 'Conv2d', inshape=W._inshape, outshape=W._outshape, exact='auto')
     x = torch.as_tensor(np.concatenate((rng.randn(128, W.shape[1] - 1), np.ones((128, 1))), axis=1).astype(np.float32)).to(dev())
     y1 = L.forward(x, fuse_relu=True)
