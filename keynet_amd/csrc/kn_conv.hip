@@ -1342,13 +1342,14 @@ __global__ __launch_bounds__(256) void convtaps_fill_records_kernel(const int32_
 }
 
 #pragma clang fp contract(off)
-template <bool TREG>
+template <int NT>           // taps held in registers: 16, or 0 = one value-row load per slot (a 9-, 10- or 12-register tap vector measured 119 - 122 VGPRs against 99 with 16: not instantiated)
 __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p, const int32_t* __restrict__ fill_ptr, const FillRec* __restrict__ rec, int n_cc, int n_ct,
                                                                      int64_t n_wg) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x32 __attribute__((ext_vector_type(32)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr bool TREG = NT > 0;
+    typedef float f32xNT __attribute__((ext_vector_type(NT > 0 ? NT : 1)));
     constexpr int PF = 8;                                  // slots in flight per wavefront (ring of operand registers) = one unrolled loop body
     constexpr int LPS = TREG ? 1 : 2;                      // vector loads per slot
     // workgroup -> XCD x = blockIdx & 7 owns a contiguous range of the work (pixels in processing order: the 196 pixels of a key block read the same input pixels)
@@ -1464,9 +1465,9 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         float arun = 0.0f;                                 // stored value of the column being formed (this lane's output channel)
         // one slot: its term joins the column's value; behind the column's last term the PREVIOUS column's products go onto the running sums (16 packed adds) and this
         // column's products are formed (one matrix instruction, zero accumulator) -- the adds of column k sit behind the matrix instruction of column k by at least one slot
-        f32x16 At;                                         // TREG: this lane's value row, one register per tap, for the input channel the walk is in
+        f32xNT At;                                         // TREG: this lane's value row, one register per tap, for the input channel the walk is in
 #pragma unroll
-        for (int q = 0; q < 16; q++) At[q] = 0.0f;
+        for (int q = 0; q < (NT > 0 ? NT : 1); q++) At[q] = 0.0f;
         const int nb8 = n_pad >> 3;                        // loop bodies per input channel
         int body_left = 0;                                 // bodies until the walk enters the next input channel
         const float* a_ci = p.tapsT + co0 + (lane & 31);   // TREG: tapsT[0][ci][co0 + (l & 31)] of the channel the walk enters next
@@ -1495,7 +1496,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
                     body_left = nb8;
                     const int tap_stride = p.cin_pad * p.cout_pad;
 #pragma unroll
-                    for (int q = 0; q < 16; q++)
+                    for (int q = 0; q < NT; q++)
                         if (q < p.ntaps) At[q] = a_ci[(int64_t)q * tap_stride];
                     a_ci += p.cout_pad;
                     asm volatile("" : "+v"(At));           // the compiler's wait for these loads stays inside this block (a loop-carried pending load would put vmcnt(0) in front of every body)
@@ -2197,8 +2198,10 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
             KN_REQUIRE(n_wg + 8 < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "grid too large for the filled-in order-preserving kernel");
             const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? "<taps in registers>" : "") + " (stored values formed per lane, products on the matrix pipe, " +
                                   std::to_string(A.fill_n) + " slot records)";
-            if (A.ntaps <= 16) KN_LAUNCH(d, convtaps_exact_fill_kernel<true>, dim3((unsigned)(((n_wg + 7) / 8) * 8)), dim3(256), 0, s, a, A.fill_ptr, reinterpret_cast<const FillRec*>(A.fill_rec), n_cc, n_ctf, n_wg);
-            else KN_LAUNCH(d, convtaps_exact_fill_kernel<false>, dim3((unsigned)(((n_wg + 7) / 8) * 8)), dim3(256), 0, s, a, A.fill_ptr, reinterpret_cast<const FillRec*>(A.fill_rec), n_cc, n_ctf, n_wg);
+            const dim3 gridf((unsigned)(((n_wg + 7) / 8) * 8));
+            const FillRec* rec = reinterpret_cast<const FillRec*>(A.fill_rec);
+            if (A.ntaps <= 16) KN_LAUNCH(d, convtaps_exact_fill_kernel<16>, gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            else KN_LAUNCH(d, convtaps_exact_fill_kernel<0>, gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
         }
         else if (v4) KN_LAUNCH("convtaps_exact_kernel<vec=4>", convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else KN_LAUNCH("convtaps_exact_kernel<vec=1>", convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
