@@ -625,21 +625,29 @@ class Conv2dTiledMatrix(TiledMatrix):
         split = 2.0 * ent * Cin * n / 10e12 + 2.0 * nt * HoWo * Cin * Cout * n / 120e12 + 2.0 * (4.0 * Cin * nt * HoWo * n) / 3e12
         return split < 0.5 * fused
 
+    def _split_arrays(self):
+        """Host side of the split form: (K, second) with K the scipy CSR [ntaps * HoWo, HiWi] of all taps' entries (row t * HoWo + out, column in, value coef)
+        and `second` the kwargs of the channel-mixing operator Conv2dTiledMatrix.fromtaps(**second) on Z [Cin, ntaps, HoWo]."""
+        t = self._taps
+        (Cin, Hin, Win) = self._inshape
+        (Cout, Hout, Wout) = self._outshape
+        (HoWo, HiWi, nt) = (Hout * Wout, Hin * Win, len(t['taps']))
+        coef = t['ent_coef'] if t['ent_coef'] is not None else np.ones(len(t['ent_out']), np.float32)
+        K = scipy.sparse.csr_matrix((coef.astype(np.float32), (t['ent_tap'].astype(np.int64) * HoWo + t['ent_out'], t['ent_in'].astype(np.int64))), shape=(nt * HoWo, HiWi))
+        K.sort_indices()
+        assert K.nnz == len(coef), 'an (output pixel, input pixel, tap) triple appears twice'
+        eo = np.tile(np.arange(HoWo, dtype=np.int32), nt)
+        et = np.repeat(np.arange(nt, dtype=np.int32), HoWo)
+        second = dict(inshape=(Cin, nt, HoWo), outshape=self._outshape, taps=t['taps'], ent_out=eo, ent_in=(et.astype(np.int64) * HoWo + eo).astype(np.int32), ent_tap=et,
+                      ent_coef=None, lastcol=t['lastcol'])
+        return (K, second)
+
     def _split_ops(self, device=None):
         """(spatial CSR [ntaps * HoWo, HiWi], channel-mixing conv-taps operator on Z [Cin, ntaps, HoWo] -> [Cout, Hout, Wout]) resident on `device`."""
         def make():
-            t = self._taps
-            (Cin, Hin, Win) = self._inshape
-            (Cout, Hout, Wout) = self._outshape
-            (HoWo, HiWi, nt) = (Hout * Wout, Hin * Win, len(t['taps']))
-            coef = t['ent_coef'] if t['ent_coef'] is not None else np.ones(len(t['ent_out']), np.float32)
-            K = scipy.sparse.csr_matrix((coef.astype(np.float32), (t['ent_tap'].astype(np.int64) * HoWo + t['ent_out'], t['ent_in'].astype(np.int64))), shape=(nt * HoWo, HiWi))
-            K.sort_indices()
-            assert K.nnz == len(coef), 'an (output pixel, input pixel, tap) triple appears twice'
+            (K, f) = self._split_arrays()
             opK = _capi.Operator.csr(K.shape, K.indptr, K.indices, K.data)
-            eo = np.tile(np.arange(HoWo, dtype=np.int32), nt)
-            et = np.repeat(np.arange(nt, dtype=np.int32), HoWo)
-            op2 = _capi.Operator.convtaps((Cin, nt, HoWo), self._outshape, t['taps'], eo, (et.astype(np.int64) * HoWo + eo).astype(np.int32), et, None, t['lastcol'])
+            op2 = _capi.Operator.convtaps(f['inshape'], f['outshape'], f['taps'], f['ent_out'], f['ent_in'], f['ent_tap'], f['ent_coef'], f['lastcol'])
             return (opK, op2)
         return _on_device(self, '_op_split', make, device)
 

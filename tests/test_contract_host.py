@@ -159,3 +159,43 @@ def test_keyed_model_pickles_without_device_state(golden):
     assert '_chain_ops' not in k2.__dict__ and '_overlap_plans' not in k2.__dict__
     assert k2.conv1._exact is True and tuple(k2.conv1.W.shape) == tuple(knet.conv1.W.shape) and k2._outshape == knet._outshape
     assert (s2._encryptkey != sensor._encryptkey).nnz == 0
+
+
+def test_split_form_of_a_filled_in_conv_is_the_same_operator():
+    """Conv2dTiledMatrix._split_arrays (host side of the split application): (channel mixing on Z) . (I_Cin (x) K) equals the fused factored
+    operator -- checked on the expansions, in float64, on a small filled-in operator with several taps per pixel pair; the 'split' contract state round-trips
+    through the neutral archive vocabulary; the cost rule offers the split only to operators whose estimate is under half the fused launch."""
+    import scipy.sparse
+    from keynet_amd.layer import CONTRACTS, contract_name
+    rng = np.random.RandomState(3)
+    (Cin, Cout, H, fill) = (3, 5, 4, 6)
+    HW = H * H
+    taps = rng.randn(9, Cout, Cin).astype(np.float32)
+    (eo, ei, et, ec) = ([], [], [], [])
+    for t in range(9):
+        for o in range(HW):
+            ins = rng.choice(HW, size=fill, replace=False)
+            eo.append(np.full(fill, o)); ei.append(ins); et.append(np.full(fill, t)); ec.append(rng.randn(fill).astype(np.float32))
+    lastcol = np.concatenate((rng.randn(Cout * HW), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec), lastcol)
+    assert abs(W.fill_factor() - fill) < 1e-12 and W.split_capable()
+    (K, second) = W._split_arrays()
+    assert K.shape == (9 * HW, HW) and K.nnz == 9 * HW * fill
+    F = ksp.Conv2dTiledMatrix.fromtaps(**second)
+    assert F.shape == (Cout * HW + 1, Cin * 9 * HW + 1) and F.fill_factor() == 1.0 and not F.split_capable()
+    # Z = (I_Cin (x) K) X on the feature rows, the homogeneous row passed through
+    spatial = scipy.sparse.block_diag([scipy.sparse.kron(scipy.sparse.identity(Cin), K.astype(np.float64)), scipy.sparse.identity(1)], format='csr')
+    composed = (F.tosparse('csr').astype(np.float64) @ spatial).toarray()
+    fused = W.tosparse('csr').astype(np.float64).toarray()
+    assert composed.shape == fused.shape and np.allclose(composed, fused, rtol=1e-6, atol=1e-6)
+    assert 'split' in CONTRACTS and contract_name('split') == 'split' and _contract('split', True) == 'split'
+    assert kio._contract_from_array(np.array('split'), 'L.x.exact') == 'split'
+    # the cost rule (keynet_amd.sparse.Conv2dTiledMatrix.split_capable): a VGG-sized layer with 2 entries per (pixel, tap) -- Givens-like -- stays fused, 60 entries are offered
+    class Shape(ksp.Conv2dTiledMatrix):
+        pass
+    def offered(per_tap, n):
+        S = Shape.__new__(Shape)
+        (S._inshape, S._outshape) = ((64, 224, 224), (64, 224, 224))
+        S._taps = dict(taps=np.zeros((9, 1, 1), np.float32), ent_out=np.zeros(9 * 224 * 224 * per_tap, np.int8))
+        return S.split_capable(n)
+    assert offered(60, 64) and offered(60, 256) and not offered(2, 256) and not offered(1, 256)

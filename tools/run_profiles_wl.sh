@@ -11,9 +11,12 @@ REPO=$(pwd)
 mkdir -p "$REPO/$R"
 R="$REPO/$R"
 export TMPDIR=/tmp
-python3 bench.py --workload $WL --steps 20 --warmup 5 --no-secondary --detail "$R/bench_detail.json" $EXTRA > "$R/bench.json" 2> "$R/bench.log"
+# (LeNet: one forward is 37 us -- 25 steps are 1 ms, the GPU has not left its idle clock by then: 2 000 warm-up steps = 75 ms, as the default bench's secondary leg does)
+STEPS=20; WARM=5; SSTEPS=5; SWARM=2
+if [ "$WL" = lenet ]; then STEPS=2000; WARM=2000; SSTEPS=500; SWARM=500; fi
+python3 bench.py --workload $WL --steps $STEPS --warmup $WARM --no-secondary --detail "$R/bench_detail.json" $EXTRA > "$R/bench.json" 2> "$R/bench.log"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-exact-leg $EXTRA > "$R/stats_bench.json" 2> "$R/stats_bench.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --workload $WL --steps $SSTEPS --warmup $SWARM --no-cpu-baseline --no-secondary --no-exact-leg $EXTRA > "$R/stats_bench.json" 2> "$R/stats_bench.log"
 rocprofv3 --kernel-trace --output-format csv -d "$R/trace" -- python3 "$REPO/bench.py" --workload $WL --no-cpu-baseline --no-secondary --trace-layers "$R/layers.json" $EXTRA > /dev/null 2> "$R/trace.log"
 PMC_BENCH="--workload $WL --steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline --no-exact-leg --no-secondary $EXTRA"
 i=0
