@@ -1068,24 +1068,26 @@ def main():
         table = time_layers(x_cipher, layer_table(knet, batch), args.layer_iters)
         nnz_img = float(sum(r['nnz'] for r in table))
         for r in table:
-            log('[bench layer] %-8s %-9s rows=%8d nnz=%12d  %8.3f ms  %7.2f TFLOP/s  %8.1f GB/s(alg)' %
-                (r['name'], r['kind'], r['rows'], r['nnz'], r['ms'], r['flops'] / r['ms'] / 1e9, r['bytes'] / r['ms'] / 1e6))
+            log('[bench layer] %-8s %-9s rows=%8d nnz=%12d  %8.3f ms  %7.2f TFLOP/s  %8.1f GB/s(alg)%s' %
+                (r['name'], r['kind'], r['rows'], r['nnz'], r['ms'], r['flops'] / r['ms'] / 1e9, r['bytes'] / r['ms'] / 1e6,
+                 '' if not r.get('flops_executed') else '  (on the stored entries of the fused operator; the split application executes %.2f TFLOP/s)' % (r['flops_executed'] / r['ms'] / 1e9)))
         roof = roofline_of(table, args.workload, batch, mode)
         total_bytes = sum(r['bytes'] for r in table)
         chain = knet._chain_op(dev) if hasattr(knet, '_chain_op') else None
         if chain is not None:
             # the forward of this key-net is ONE launch of the whole-net kernel (csrc/kn_chain.hip): that launch is the dominant kernel.
             # Algorithmic bytes: every operator once (8 B per stored non-zero) + activations in and out of every layer.
-            for _ in range(5):
+            # (a launch is 37 us: 2 000 untimed launches = 75 ms bring the GPU off its idle clock, as in the timed loop; 5 + 50 launches -- 2 ms -- read 41 us)
+            for _ in range(2000):
                 knet.forward_linear(x_cipher)
             (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             torch.cuda.synchronize()
             e0.record()
-            for _ in range(50):
+            for _ in range(500):
                 knet.forward_linear(x_cipher)
             e1.record()
             torch.cuda.synchronize()
-            ch_ms = e0.elapsed_time(e1) / 50
+            ch_ms = e0.elapsed_time(e1) / 500
             ach = total_bytes / ch_ms / 1e6
             # What really bounds it: bit-exactness with scipy forbids the FMA, so a stored non-zero costs one packed multiply and one
             # packed add per two batch columns, 4 cycles each on one of the CU's four SIMDs; a workgroup owns 4 columns, 256 CUs run a round.
