@@ -1348,6 +1348,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x32 __attribute__((ext_vector_type(32)));
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x16 __attribute__((ext_vector_type(16)));
     constexpr bool TREG = NT > 0;
     typedef float f32xNT __attribute__((ext_vector_type(NT > 0 ? NT : 1)));
     constexpr int PF = 8;                                  // slots in flight per wavefront (ring of operand registers) = one unrolled loop body
@@ -1384,25 +1385,25 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         const uint64_t abase = uni(reinterpret_cast<uint64_t>(p.tapsT + co0));
         const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);                 // lane's byte offset inside an activation row (inactive lanes: a valid address, result unused)
         const uint32_t a_off = 4u * (uint32_t)(lane & 31);                       // lane's byte offset inside the 32 values of a value row
-        const uint32_t ldx_b = 4u * (uint32_t)p.ldx;                             // (HiWi * ldx * 4 < 2^32: checked by the launcher)
+        const uint32_t ldx_b = 4u * (uint32_t)p.ldx;                             // (HiWi * ldx * 4 < 2^32, HiWi and 4 * ldx < 2^24: checked by the launcher)
+        uint32_t ldx_v = ldx_b;                                                  // the same in a vector register: the row offset is ONE v_mad_u32_u24 (a scalar multiply + a vector add cost an issue slot of the scalar unit more)
+        asm volatile("" : "+v"(ldx_v));
         const uint64_t ci_step = (uint64_t)(uint32_t)p.HiWi * ldx_b;             // bytes between the planes of two input channels
         const int n_bat = n_pad >> 2;                      // record batches (4 slots) per input channel; even
         // fetch cursor (wave-uniform): batch index inside the pixel's list, input channel (as activation-row and value-row offsets)
-        int bq = 0;                                        // batch whose records are loaded next
+        uint32_t bq_off = 0;                               // byte offset (inside the pixel's list) of the batch whose records are loaded next
+        const uint32_t list_bytes = 16u * (uint32_t)n_pad;
         int ci_left = p.Cin - 1;                           // input channels behind the one the fetch cursor is in
         int bf = 0;                                        // batch the vector fetches read next
         uint64_t x_ci = xbase;                             // activation plane of the fetch cursor's input channel
         uint32_t ci_a = 0;                                 // ci * cout_pad of the fetch cursor
-        i32x4 R0[4], R1[4];                                // two record batches
-        auto load_batch = [&](i32x4 (&R)[4]) {             // s_load the four records of batch bq, advance bq (past the pixel's last batch: its first again)
-            const uint64_t a = rbase + 64ull * (uint64_t)(uint32_t)bq;
-            asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(R[0]) : "s"(a));
-            asm volatile("s_load_dwordx4 %0, %1, 0x10" : "=&s"(R[1]) : "s"(a));
-            asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=&s"(R[2]) : "s"(a));
-            asm volatile("s_load_dwordx4 %0, %1, 0x30" : "=&s"(R[3]) : "s"(a));
-            bq = (bq + 1 == n_bat) ? 0 : bq + 1;
+        i32x16 R0, R1;                                     // two record batches (four 16-byte records each)
+        auto load_batch = [&](i32x16& R) {                 // ONE s_load of the four records of the next batch (scalar-offset form), advance (past the pixel's last batch: its first again)
+            asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(R) : "s"(rbase), "s"(bq_off));
+            bq_off = (bq_off + 64u == list_bytes) ? 0u : bq_off + 64u;
         };
-        auto batch_landed = [&](i32x4 (&R)[4]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R[0]), "+s"(R[1]), "+s"(R[2]), "+s"(R[3])); };
+        auto batch_landed = [&](i32x16& R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R)); };
+        auto rec_of = [](const i32x16& R, const int k) { return i32x4{R[4 * k], R[4 * k + 1], R[4 * k + 2], R[4 * k + 3]}; };
         float xa[PF], xb[PF], cfr[PF];
         int flr[PF], tpr[PF];
 #pragma unroll
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         }
         // the vector loads of one slot into ring position q (activation row segment; value row unless TREG); its coefficient, flags and tap ride along in scalar registers
         auto fetch = [&](float& rb, float& ra, float& cf, int& fl, int& tp, const i32x4 r) {
-            const uint32_t xoff = (uint32_t)r.x * ldx_b + b_off;                  // (one scalar multiply + one vector add: the 64-bit scalar add-with-carry it replaces cost two issue slots of the scalar unit)
+            const uint32_t xoff = __umul24((uint32_t)r.x, ldx_v) + b_off;         // v_mad_u32_u24: row offset + lane offset in one vector instruction, nothing on the scalar unit
             asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(xoff), "s"(x_ci));
             if constexpr (!TREG) {
                 const uint64_t aaddr = abase + 4ull * (uint64_t)(ci_a + (uint32_t)r.y);
@@ -1434,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
                 }
             }
         };
-        auto landed = [&](float& rb, float& ra) {
+        auto landed = [&](float& rb, float& ra) {           // (one wait per slot: a wait that names two ring positions made the compiler copy one of them ahead of it -- a register still owned by its load)
             if constexpr (TREG) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rb) : "n"(LPS * (PF - 1)));
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb), "+v"(ra) : "n"(LPS * (PF - 1)));
         };
@@ -1442,17 +1443,17 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         load_batch(R0);
         batch_landed(R0);
         load_batch(R1);
-        fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], R0[0]);
-        fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], R0[1]);
-        fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], R0[2]);
-        fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], R0[3]);
+        fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], rec_of(R0, 0));
+        fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], rec_of(R0, 1));
+        fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], rec_of(R0, 2));
+        fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], rec_of(R0, 3));
         batch_done();
         batch_landed(R1);
         load_batch(R0);
-        fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], R1[0]);
-        fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], R1[1]);
-        fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], R1[2]);
-        fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], R1[3]);
+        fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], rec_of(R1, 0));
+        fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], rec_of(R1, 1));
+        fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], rec_of(R1, 2));
+        fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], rec_of(R1, 3));
         batch_done();
         batch_landed(R0);                                  // (no scalar load is in flight across the loop's back edge: the compiler may copy a loop-carried register tuple there)
 
@@ -1506,24 +1507,24 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
             // slots 0 .. 3 of this body; their ring positions are refilled from batch R0 (landed: loaded half a body ago), R1's next batch leaves now
             load_batch(R1);
             consume(xb[0], xa[0], cfr[0], flr[0], tpr[0]);
-            fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], R0[0]);
+            fetch(xb[0], xa[0], cfr[0], flr[0], tpr[0], rec_of(R0, 0));
             consume(xb[1], xa[1], cfr[1], flr[1], tpr[1]);
-            fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], R0[1]);
+            fetch(xb[1], xa[1], cfr[1], flr[1], tpr[1], rec_of(R0, 1));
             consume(xb[2], xa[2], cfr[2], flr[2], tpr[2]);
-            fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], R0[2]);
+            fetch(xb[2], xa[2], cfr[2], flr[2], tpr[2], rec_of(R0, 2));
             consume(xb[3], xa[3], cfr[3], flr[3], tpr[3]);
-            fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], R0[3]);
+            fetch(xb[3], xa[3], cfr[3], flr[3], tpr[3], rec_of(R0, 3));
             batch_done();
             batch_landed(R1);
             load_batch(R0);
             consume(xb[4], xa[4], cfr[4], flr[4], tpr[4]);
-            fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], R1[0]);
+            fetch(xb[4], xa[4], cfr[4], flr[4], tpr[4], rec_of(R1, 0));
             consume(xb[5], xa[5], cfr[5], flr[5], tpr[5]);
-            fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], R1[1]);
+            fetch(xb[5], xa[5], cfr[5], flr[5], tpr[5], rec_of(R1, 1));
             consume(xb[6], xa[6], cfr[6], flr[6], tpr[6]);
-            fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], R1[2]);
+            fetch(xb[6], xa[6], cfr[6], flr[6], tpr[6], rec_of(R1, 2));
             consume(xb[7], xa[7], cfr[7], flr[7], tpr[7]);
-            fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], R1[3]);
+            fetch(xb[7], xa[7], cfr[7], flr[7], tpr[7], rec_of(R1, 3));
             batch_done();
             batch_landed(R0);
         }
@@ -2176,7 +2177,8 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         // four activation rows in flight when the batch spans several 256-column tiles (the rows of a [D, 4096] block are L2 misses; at one tile --
         // VGG-16 at 256 images -- three rows in flight measured 2-3 % slower than two).  Tuning::exact_xd = 2 | 4 overrides (diagnostic build).
         // filled-in operators (more than 64 slots per pixel, or several slots on one pixel pair): convtaps_exact_fill_kernel (its records exist from the first kn_spmm on)
-        const bool fill = !pipe && !table && convtaps_fill_ok(A) && (A.fill_rec != nullptr || plan_sink() != nullptr) && (int64_t)a.HiWi * ldx * 4 < ((int64_t)1 << 32);
+        const bool fill = !pipe && !table && convtaps_fill_ok(A) && (A.fill_rec != nullptr || plan_sink() != nullptr) && (int64_t)a.HiWi * ldx * 4 < ((int64_t)1 << 32) &&
+                          a.HiWi < (1 << 24) && ldx * 4 < ((int64_t)1 << 24);
         bool xd4 = n_ct >= 4;
         if (A.tune.exact_xd > 0) xd4 = A.tune.exact_xd == 4;
         if (table) {

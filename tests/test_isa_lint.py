@@ -135,7 +135,7 @@ def test_no_copy_of_a_register_owned_by_a_load_in_flight(src, tmp_path):
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
 def test_no_use_of_a_scalar_register_owned_by_a_scalar_load_in_flight(tmp_path):
-    """convtaps_exact_fill_kernel fetches its slot records with asm-issued s_load_dwordx4 one batch ahead and waits with an explicit s_waitcnt lgkmcnt(0).
+    """convtaps_exact_fill_kernel fetches its slot records with asm-issued s_load_dwordx16 one batch ahead and waits with an explicit s_waitcnt lgkmcnt(0).
     The compiler takes the destination tuple as defined the moment the load is ISSUED: a copy of it ahead of the wait (seen once: loop-carried tuples
     were moved at the loop header while their load was still in flight -- stale records, wild addresses) is the scalar twin of the bug the test above
     looks for.  Between every such load and the next lgkmcnt(0) nothing may read or write its destination registers."""
@@ -153,13 +153,13 @@ def test_no_use_of_a_scalar_register_owned_by_a_scalar_load_in_flight(tmp_path):
             if l.startswith('s_waitcnt') and 'lgkmcnt(0)' in l:
                 owned = set()
                 continue
-            m = re.match(r's_load_dwordx4 s\[(\d+):(\d+)\]', l)
+            m = re.match(r's_load_dwordx(?:4|8|16) s\[(\d+):(\d+)\]', l)
             if m:
                 owned |= set(range(int(m.group(1)), int(m.group(2)) + 1))
                 n_loads += 1
                 continue
             assert not (_regs(l, 's') & owned), (name, l)
-        assert n_loads >= 12, (name, n_loads)
+        assert n_loads >= 6, (name, n_loads)
 
 
 # ---- the bit-exact contract in the ISA -----------------------------------------------------------------------------------------------------
