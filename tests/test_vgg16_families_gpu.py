@@ -133,3 +133,108 @@ def test_exact_mode_bit_equal_to_oracle(keyed):
         if lname == 'conv3_1':
             break
     assert checked == ['conv1_2', 'conv3_1']
+
+
+# ---- the same doubly-stochastic configuration keyed DIRECTLY (factored operators: what the full-size key-net is made of) --------------------------------
+@pytest.fixture(scope='module')
+def stochastic_direct():
+    """3 x 64 x 64, reduced width, direct keying: every conv operator is taps x entries with float coefficients, up to ~300 slots per output pixel and
+    several taps on one (output, input) pixel pair -- the structure of `bench.py --workload vgg16-stochastic` (500 - 5 400 slots) in a few seconds of keying."""
+    assert torch.cuda.is_available()
+    (kw, atol) = CONFIGS['stochastic']
+    kw = dict(kw, tileshape=(4, 4), blocksize=4)
+    torch.manual_seed(0)
+    net = VGG16(num_classes=10, width=8, fc_width=64, insize=64).eval()
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.Keynet((3, 64, 64), net, direct=True, **kw)
+    return (atol, net, sensor, knet)
+
+
+def test_filled_in_operators_take_the_filled_in_kernels(stochastic_direct):
+    """kn_spmm_plan on the directly keyed doubly-stochastic VGG-16: in the reference's order every conv layer with several taps per pixel pair or
+    more than 64 slots per pixel runs convtaps_exact_fill_kernel (bit-equal to the generic kernel it replaces: a fresh handle under KN_NO_FILL_EXACT=1); on the
+    matrix cores a layer with more than 64 slots per pixel walks its slots group by group on the wave-uniform-pointer loaders."""
+    import copy
+    import os
+    from keynet_amd import _capi
+    (atol, net, sensor, knet) = stochastic_direct
+    dev = torch.device('cuda:0')
+    convs = [(n, c.W) for (n, c) in knet._keynet.named_children() if isinstance(c, KeyedLayer) and isinstance(c.W, ksp.Conv2dTiledMatrix)]
+    assert len(convs) == 13
+    (n_fill, n_groups) = (0, 0)
+    for (n, W) in convs:
+        t = W._taps
+        assert t is not None and t['ent_coef'] is not None, n
+        HiWi = W._inshape[1] * W._inshape[2]
+        dups = len(np.unique(t['ent_out'].astype(np.int64) * HiWi + t['ent_in'])) < len(t['ent_out'])
+        slots = int(np.bincount(t['ent_out']).max())
+        with torch.cuda.device(dev):
+            pe = W._device_op(dev).plan(256, _capi.KN_FLAG_EXACT)
+            pm = W._device_op(dev).plan(256, 0)
+        if dups or slots > 64:
+            assert 'convtaps_exact_fill_kernel<taps in registers>' in pe, (n, pe)
+            n_fill += 1
+        if slots > 64 and W._inshape[0] % 16 == 0:                        # (the wave-uniform-pointer loaders take whole 16-channel chunks: conv1_1 / conv1_2 / conv2_1 of this reduced net keep the generic loader)
+            assert 'slot groups' in pm, (n, pm)
+            n_groups += 1
+    assert n_fill >= 8 and n_groups >= 3, (n_fill, n_groups)
+    # one real filled-in layer, whole: the filled-in kernel against the generic one
+    (n, W) = next((n, W) for (n, W) in convs if n == 'conv2_1')
+    x = torch.randn(W.shape[1], 64, generator=torch.Generator().manual_seed(1)).to(dev)
+    x[-1] = 1.0
+    y = W.torchdot(x, relu=True, exact=True)
+    os.environ['KN_NO_FILL_EXACT'] = '1'
+    try:
+        Wg = copy.deepcopy(W)
+        Wg._op = None
+        yg = Wg.torchdot(x, relu=True, exact=True)
+        with torch.cuda.device(dev):
+            assert 'convtaps_exact_kernel' in Wg._device_op(dev).plan(64, _capi.KN_FLAG_EXACT)
+    finally:
+        del os.environ['KN_NO_FILL_EXACT']
+    assert torch.equal(y, yg)
+
+
+def test_directly_keyed_stochastic_net_meets_the_references_tolerance_fused_and_split(stochastic_direct):
+    """Keyed == plain at the reference's own atol (test/test_keynet.py:116-129: 1e-5) under the float-key contract, twice: as calibration decides by itself (the
+    cost rule offers the split application only where its estimate is under half the fused launch -- not at this size) and with the split application offered to
+    every filled-in layer (what the full-size key-net's eight tolerance layers run): at least one layer then decides 'split', every conv layer as shipped is inside
+    the element-wise gate against the order-preserving kernel, and the logits agree with the fused run to 1e-5."""
+    (atol, net, sensor, knet) = stochastic_direct
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(256, 3, 64, 64, generator=g)
+    xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+    with torch.no_grad():
+        yp = net(x).reshape(256, -1).numpy()
+    knet.exact_mode(None)
+    y_fused = knet.forward_linear(xc)[:, :-1].cpu().numpy()
+    rep = knet.contract_report()
+    assert not rep['undecided'] and float(np.abs(y_fused - yp).max()) <= atol
+    decided_fused = {r['name']: r['exact'] for r in rep['layers']}
+    offered = ksp.Conv2dTiledMatrix.split_capable
+    ksp.Conv2dTiledMatrix.split_capable = lambda self, n_vecs=None: self._taps is not None and self.fill_factor() >= self.SPLIT_MIN_FILL
+    try:
+        knet.exact_mode(None)
+        y_split = knet.forward_linear(xc)[:, :-1].cpu().numpy()
+        rep2 = knet.contract_report()
+        split = [r['name'] for r in rep2['layers'] if r['exact'] == 'split']
+        print('fused decisions:', decided_fused, '| decided split when offered:', split)
+        assert len(split) >= 1 and float(np.abs(y_split - yp).max()) <= atol and float(np.abs(y_split - y_fused).max()) <= 1e-5
+        children = list(knet._keynet.named_children())
+        yin = xc
+        for (i, (lname, c)) in enumerate(children):
+            if not isinstance(c, KeyedLayer):
+                continue
+            fuse = (i + 1 < len(children)) and isinstance(children[i + 1][1], torch.nn.ReLU)
+            out = c.forward(yin, fuse_relu=fuse)
+            if lname in split:
+                ye = c.W.torchdot(yin.t(), relu=fuse, exact=True).t()
+                assert gate(out, ye)[0] <= 1.0, lname
+            yin = out
+        assert torch.equal(knet.forward_linear(xc)[:, :-1].cpu(), torch.as_tensor(y_split))      # decided: the second forward repeats the first
+    finally:
+        ksp.Conv2dTiledMatrix.split_capable = offered
+        knet.exact_mode(None)
