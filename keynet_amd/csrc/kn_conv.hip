@@ -1311,6 +1311,9 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 //     (convtaps_fill_records_kernel, padded to a multiple of 8 with records that change nothing) fetched four at a time by s_load_dwordx4, one batch
 //     ahead; the operand loads of a slot (activation row segment + value row) run PF = 8 slots ahead in a register ring with counted vmcnt waits.
 // One wavefront = one output pixel x 32 output channels x 64 batch columns; no LDS, no barriers.
+// WIDE (64 output channels per wavefront): lane l forms the value of channel co0 + l -- 64 DIFFERENT values per slot for the same four vector instructions and the
+// same scalar bookkeeping -- and behind a column's last term v_permlane32_swap hands the matrix pipe channels 0-31 in both halves of one register and channels 32-63 in
+// both halves of another: two matrix instructions, twice 16 packed adds.  The slot bookkeeping (what separates this kernel from the roof) is paid once per 64 channels.
 // TREG (operators with at most 16 taps: every conv window up to 4 x 4): the lane's value row lives in REGISTERS -- 16 VGPRs hold tapsT[0 .. ntaps)[ci][co0 + (l & 31)],
 // reloaded when the walk enters the next input channel -- and a slot picks its tap by the scalar index mode (s_set_gpr_idx_on): no value-row load per slot, half the
 // vector-memory instructions (the CU's one address unit serves four SIMDs).
@@ -1342,7 +1345,7 @@ __global__ __launch_bounds__(256) void convtaps_fill_records_kernel(const int32_
 }
 
 #pragma clang fp contract(off)
-template <int NT>           // taps held in registers: 16, or 0 = one value-row load per slot (a 9-, 10- or 12-register tap vector measured 119 - 122 VGPRs against 99 with 16: not instantiated)
+template <int NT, bool WIDE> // taps held in registers: 16, or 0 = one value-row load per slot (a 9-, 10- or 12-register tap vector measured 119 - 122 VGPRs against 99 with 16: not instantiated)
 __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p, const int32_t* __restrict__ fill_ptr, const FillRec* __restrict__ rec, int n_cc, int n_ct,
                                                                      int64_t n_wg) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1365,16 +1368,20 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
     const int pi = (int)(wi / per_pix);
     const int rem = (int)(wi - (int64_t)pi * per_pix);
     const int o = __builtin_amdgcn_readfirstlane(p.pix_order[pi]);
-    const int co0 = __builtin_amdgcn_readfirstlane((rem / n_ct) * 32);
+    constexpr int CH = WIDE ? 64 : 32;                     // output channels per wavefront
+    constexpr int NH = WIDE ? 2 : 1;                       // 32-channel halves
+    const int co0 = __builtin_amdgcn_readfirstlane((rem / n_ct) * CH);
     const int64_t c0 = (int64_t)(rem % n_ct) * 64;
     const int64_t c = c0 + lane;
     const bool active = c < p.n_vecs;
     const int r_beg = __builtin_amdgcn_readfirstlane(fill_ptr[o]);
     const int n_pad = __builtin_amdgcn_readfirstlane(fill_ptr[o + 1]) - r_beg;         // multiple of 8
 
-    f32x2 acc[16];
+    f32x2 acc[NH][16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) acc[q] = f32x2{0.0f, 0.0f};
+    for (int h = 0; h < NH; h++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[h][q] = f32x2{0.0f, 0.0f};
 
     if (n_pad > 0) {
         auto uni = [](const uint64_t v) {
@@ -1384,7 +1391,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         const uint64_t xbase = uni(reinterpret_cast<uint64_t>(p.X));
         const uint64_t abase = uni(reinterpret_cast<uint64_t>(p.tapsT + co0));
         const uint32_t b_off = 4u * (uint32_t)(active ? c : c0);                 // lane's byte offset inside an activation row (inactive lanes: a valid address, result unused)
-        const uint32_t a_off = 4u * (uint32_t)(lane & 31);                       // lane's byte offset inside the 32 values of a value row
+        const uint32_t a_off = 4u * (uint32_t)(WIDE ? lane : (lane & 31));       // lane's byte offset inside the 32 (64) values of a value row
         const uint32_t ldx_b = 4u * (uint32_t)p.ldx;                             // (HiWi * ldx * 4 < 2^32, HiWi and 4 * ldx < 2^24: checked by the launcher)
         uint32_t ldx_v = ldx_b;                                                  // the same in a vector register: the row offset is ONE v_mad_u32_u24 (a scalar multiply + a vector add cost an issue slot of the scalar unit more)
         asm volatile("" : "+v"(ldx_v));
@@ -1471,22 +1478,34 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         for (int q = 0; q < (NT > 0 ? NT : 1); q++) At[q] = 0.0f;
         const int nb8 = n_pad >> 3;                        // loop bodies per input channel
         int body_left = 0;                                 // bodies until the walk enters the next input channel
-        const float* a_ci = p.tapsT + co0 + (lane & 31);   // TREG: tapsT[0][ci][co0 + (l & 31)] of the channel the walk enters next
+        const float* a_ci = p.tapsT + co0 + (WIDE ? lane : (lane & 31));   // TREG: tapsT[0][ci][this lane's output channel] of the channel the walk enters next
         auto consume = [&](float& rb, float& ra, const float cf, const int fl, const int tp) {
             landed(rb, ra);
             const float av = TREG ? At[tp] : ra;           // (TREG: scalar index mode, no memory access)
             const float t = cf * av;                       // fl(coef * tap): the term as the reference stores it (coef == 1: the tap itself)
             arun = arun + t;                               // (the column's first term joins +0.0: the same value bit for bit but for the sign of a zero, which no sum that starts at +0.0 can show)
             if (fl & 2) {
-                acc[0] = acc[0] + f32x2{d[0], d[1]};       // (compiler-visible: the hazard recognizer spaces this first reader of the matrix instruction's result; the rest follow it)
-                __builtin_amdgcn_sched_barrier(0);
+                auto add_d = [&](f32x2 (&a)[16]) {         // the products in d onto 32 x 64 running sums
+                    a[0] = a[0] + f32x2{d[0], d[1]};       // (compiler-visible: the hazard recognizer spaces this first reader of the matrix instruction's result; the rest follow it)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 1; q < 16; q++) {
-                    const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
-                    asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[q]) : "v"(p2));
+                    for (int q = 1; q < 16; q++) {
+                        const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                        asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                add_d(acc[NH - 1]);                        // pending: the previous column's (last) block
+                if constexpr (WIDE) {
+                    const unsigned ab = __builtin_bit_cast(unsigned, arun);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(ab, ab, false, false);     // [0]: lanes 0-31 of arun in both halves, [1]: lanes 32-63 in both halves
+                    const unsigned lo_b = sw[0], hi_b = sw[1];
+                    d = __builtin_amdgcn_mfma_f32_32x32x1f32(__builtin_bit_cast(float, lo_b), rb, zero, 0, 0, 0);
+                    add_d(acc[0]);                         // channels 0-31: behind their own matrix instruction (the compiler spaces it; other wavefronts fill the gap)
+                    d = __builtin_amdgcn_mfma_f32_32x32x1f32(__builtin_bit_cast(float, hi_b), rb, zero, 0, 0, 0);
+                } else {
+                    d = __builtin_amdgcn_mfma_f32_32x32x1f32(arun, rb, zero, 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                d = __builtin_amdgcn_mfma_f32_32x32x1f32(arun, rb, zero, 0, 0, 0);
                 arun = 0.0f;
             }
         };
@@ -1530,7 +1549,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         }
         // the products still pending; everything in flight lands (re-loads of valid rows, never used)
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[q] = acc[q] + f32x2{d[2 * q], d[2 * q + 1]};
+        for (int q = 0; q < 16; q++) acc[NH - 1][q] = acc[NH - 1][q] + f32x2{d[2 * q], d[2 * q + 1]};
         asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
         for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q]));
@@ -1546,22 +1565,25 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
             if (colo + 32 * blk < p.n_vecs) xl[blk] = p.X[p.last_in_row * p.ldx + colo + 32 * blk];
     }
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int m = co0 + 8 * (r / 4) + 4 * half + (r % 4);
-        if (m < p.Cout) {
-            const int64_t row = (int64_t)m * p.HoWo + o;
-            const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
+    for (int h = 0; h < NH; h++) {
 #pragma unroll
-            for (int blk = 0; blk < 2; blk++) {
-                const int64_t cc = colo + 32 * blk;
-                if (cc < p.n_vecs) {
-                    float v = acc[(16 * blk + r) / 2][(16 * blk + r) % 2];
-                    if (lc != 0.0f) {
-                        const float bp = lc * xl[blk];
-                        v = v + bp;
+        for (int r = 0; r < 16; r++) {
+            const int m = co0 + 32 * h + 8 * (r / 4) + 4 * half + (r % 4);
+            if (m < p.Cout) {
+                const int64_t row = (int64_t)m * p.HoWo + o;
+                const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
+#pragma unroll
+                for (int blk = 0; blk < 2; blk++) {
+                    const int64_t cc = colo + 32 * blk;
+                    if (cc < p.n_vecs) {
+                        float v = acc[h][(16 * blk + r) / 2][(16 * blk + r) % 2];
+                        if (lc != 0.0f) {
+                            const float bp = lc * xl[blk];
+                            v = v + bp;
+                        }
+                        if (p.relu) v = (v < 0.0f) ? 0.0f : v;
+                        p.Y[row * p.ldy + cc] = v;
                     }
-                    if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-                    p.Y[row * p.ldy + cc] = v;
                 }
             }
         }
@@ -2195,15 +2217,19 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef>", (convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (fill) {
-            const int n_cc = (int)((A.Cout + 31) / 32), n_ctf = (int)((n_vecs + 63) / 64);
+            // 64 output channels per wavefront (the slot bookkeeping once per 64 channels) when that still leaves every SIMD its three wavefronts, else 32
+            const int n_ctf = (int)((n_vecs + 63) / 64);
+            const bool wide = A.ntaps <= 16 && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * n_ctf >= 3 * 1024;
+            const int n_cc = (int)((A.Cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
             const int64_t n_wg = ((int64_t)a.n_pix * n_cc * n_ctf + 3) / 4;
             KN_REQUIRE(n_wg + 8 < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "grid too large for the filled-in order-preserving kernel");
-            const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? "<taps in registers>" : "") + " (stored values formed per lane, products on the matrix pipe, " +
-                                  std::to_string(A.fill_n) + " slot records)";
+            const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? (wide ? "<taps in registers, 64 channels per wavefront>" : "<taps in registers>") : "") +
+                                  " (stored values formed per lane, products on the matrix pipe, " + std::to_string(A.fill_n) + " slot records)";
             const dim3 gridf((unsigned)(((n_wg + 7) / 8) * 8));
             const FillRec* rec = reinterpret_cast<const FillRec*>(A.fill_rec);
-            if (A.ntaps <= 16) KN_LAUNCH(d, convtaps_exact_fill_kernel<16>, gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
-            else KN_LAUNCH(d, convtaps_exact_fill_kernel<0>, gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            if (wide) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, true>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            else if (A.ntaps <= 16) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, false>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            else KN_LAUNCH(d, (convtaps_exact_fill_kernel<0, false>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
         }
         else if (v4) KN_LAUNCH("convtaps_exact_kernel<vec=4>", convtaps_exact_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else KN_LAUNCH("convtaps_exact_kernel<vec=1>", convtaps_exact_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);

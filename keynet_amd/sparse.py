@@ -600,7 +600,8 @@ class Conv2dTiledMatrix(TiledMatrix):
     # is another association of the sum: NOT the reference's arithmetic, so it is a candidate of the float-key contract only (KeyedLayer._calibrate
     # measures it against the order-preserving kernel like the matrix-core kernel; layers that fail run in the reference's order as before).
     SPLIT_MIN_FILL = 2.0        # slots per (output pixel, tap) from which the split application is offered
-    SPLIT_Z_BYTES = 8 << 30     # the intermediate Z is produced in column windows of at most this size
+    SPLIT_Z_BYTES = 32 << 30    # the intermediate Z is produced in column windows of at most this size (VGG-16 conv1_2 at 256 images: 29.6 GB in one window; 74-column windows
+                                # under an 8 GB cap ran ragged tiles on the generic loader: 314 ms against 49 ms per 64 images)
 
     def fill_factor(self):
         """Entries per (output pixel, tap) of a factored operator: 1 for identity / permutation keys, 55 - 600 under doubly-stochastic keys."""
@@ -666,8 +667,8 @@ class Conv2dTiledMatrix(TiledMatrix):
         n = int(xd.shape[1])
         zrows = Cin * nt * HoWo + (1 if has_last else 0)
         win = max(1, min(n, int(self.SPLIT_Z_BYTES // (4 * zrows))))
-        if win < n and win >= 128:
-            win -= win % 128                      # whole tiles of the matrix-core kernel per window
+        if win < n and win >= 64:
+            win -= win % (128 if win >= 128 else 64)      # whole tiles of the matrix-core kernel per window
         y = torch.empty((self.shape[0], n), dtype=torch.float32, device=xd.device)
         flags = _capi.KN_FLAG_RELU if relu else 0
         with torch.cuda.device(xd.device):

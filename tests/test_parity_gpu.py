@@ -1294,6 +1294,8 @@ def test_convtaps_slot_groups_beyond_64_slots(Cin, Cout, H, k, n_vecs, unit):
     (2, 33, 10, 9, 256, False, False),     # > 64 slots AND duplicate pairs, four column tiles, no bias column
     (6, 96, 6, 5, 1, False, True),         # one batch column
     (16, 128, 6, 3, 192, False, True),     # VGG-like channel counts, three column tiles
+    (2, 128, 28, 3, 128, False, True),     # enough work for the 64-channels-per-wavefront form (784 pixels x 2 channel blocks x 2 column tiles)
+    (3, 96, 28, 3, 100, False, False),     # ... with a half-empty second channel block, a ragged column tile and no bias column
 ])
 def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has_last):
     """Filled-in operators in the reference's order (the reference's doubly-stochastic VGG-16, test/test_keynet.py:116-129: 500 - 5 400 slots per
@@ -1311,7 +1313,7 @@ def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has
     assert dups == (not unit) and (dups or slots > 64), (dups, slots)
     with torch.cuda.device(dev()):
         plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
-    assert 'convtaps_exact_fill_kernel' in plan, plan
+    assert 'convtaps_exact_fill_kernel' in plan and ('64 channels per wavefront' in plan) == (H == 28), plan
     wide = n_vecs + 37
     X = rng.randn(W.shape[1], wide).astype(np.float32)
     if has_last:
