@@ -87,9 +87,10 @@ def contract_worker(rank, world_size, port, mode, q):
         from keynet_amd import io as kio
         from keynet_amd.layer import KeyedLayer
         z = np.load(os.path.join(HERE, 'golden', 'mini_tiled_orthogonal.npz'), allow_pickle=False)
-        if mode == 'host':
+        if mode in ('host', 'host_split'):
             knet = kio.keynet_from_arrays(z)
-            plant = [{'conv1': (False, {'decided': 'mfma', 'max_abs_x': 2.0}), 'conv2': ('bf16x3', {'decided': 'bf16x3', 'max_abs_x': 3.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)},
+            plant = [{'conv1': ('split', {'decided': 'split', 'max_abs_x': 2.0}), 'conv2': ('split', {'decided': 'split', 'max_abs_x': 3.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)},
+                     {'conv1': (False, {'decided': 'mfma', 'max_abs_x': 5.0}), 'conv2': ('split', {'decided': 'split', 'max_abs_x': 9.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)}][rank] if mode == 'host_split' else [{'conv1': (False, {'decided': 'mfma', 'max_abs_x': 2.0}), 'conv2': ('bf16x3', {'decided': 'bf16x3', 'max_abs_x': 3.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)},
                      {'conv1': (True, {'decided': 'exact', 'bound': 1.0}), 'conv2': (False, {'decided': 'mfma', 'max_abs_x': 9.0}), 'pool1': (True, None), 'fc1': (True, None), 'pool2': (True, None)}][rank]
             for (n, c) in knet._keynet.named_children():
                 if isinstance(c, KeyedLayer):

@@ -45,3 +45,13 @@ def test_calibration_decisions_are_made_collective():
     assert again0 == [] and again1 == []
     assert not s1_0 and not s1_1                 # conv1 runs in the reference's order everywhere: nothing left to screen
     assert s2_0 and s2_1                         # conv2 stays on the matrix cores, still screened against each rank's own calibration
+
+
+def test_split_decisions_are_made_collective():
+    """The 'split' contract (a filled-in conv applied as spatial mixing then channel mixing) in KeyedModel.sync_contract: it ranks below the fused matrix-core
+    contract (bf16x3 < split < mfma < exact), so a layer one rank runs split and another fused ends fused on both; a layer both run split stays split and screened."""
+    res = dist_harness.run_contract('host_split')
+    ((_, ch0, st0, again0, s1_0, s2_0), (_, ch1, st1, again1, s1_1, s2_1)) = res
+    assert st0 == st1 == {'conv1': False, 'pool1': True, 'conv2': 'split', 'pool2': True, 'fc1': True}
+    assert ch0 == ['conv1'] and ch1 == [] and again0 == [] and again1 == []
+    assert s1_0 and s1_1 and s2_0 and s2_1
