@@ -235,11 +235,13 @@ def _wait_states(l):
 
 
 @pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
-def test_matrix_instruction_results_are_read_after_the_required_wait_states(tmp_path):
-    s = _isa('kn_csr_mfma.hip', tmp_path)
+@pytest.mark.parametrize('src,patterns', [('kn_csr_mfma.hip', [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel']),
+                                          ('kn_conv.hip', [r'_ZN2kn26convtaps_exact_fill_kernel'])])
+def test_matrix_instruction_results_are_read_after_the_required_wait_states(src, patterns, tmp_path):
+    s = _isa(src, tmp_path)
     checked = 0
     worst = {}
-    for (name, lines) in _kernel_bodies(s, [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel']):
+    for (name, lines) in _kernel_bodies(s, patterns):
         labels = {l[:-1]: i for (i, l) in enumerate(lines) if l.endswith(':')}
 
         def first_touch(i, regs, need, seen):
@@ -279,4 +281,7 @@ def test_matrix_instruction_results_are_read_after_the_required_wait_states(tmp_
                         assert d >= need, '%s: result of `%s` is touched after %d wait states, %d required' % (name, l, d, need)
                         worst[op] = min(worst.get(op, 1 << 30), d)
                     checked += 1
-    assert checked >= 100 and worst == MFMA_WAIT, (checked, worst)      # (the closest reader anywhere is a compiler-spaced one, at exactly the compiler's figure)
+    if src == 'kn_csr_mfma.hip':
+        assert checked >= 100 and worst == MFMA_WAIT, (checked, worst)      # (the closest reader anywhere is a compiler-spaced one, at exactly the compiler's figure)
+    else:                                                                   # the filled-in conv kernel: 8 column ends per loop body x (1 or 2) matrix instructions x 3 instantiations
+        assert checked >= 30 and set(worst) == {'v_mfma_f32_32x32x1'} and worst['v_mfma_f32_32x32x1'] >= MFMA_WAIT['v_mfma_f32_32x32x1'], (checked, worst)
