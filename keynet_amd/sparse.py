@@ -765,7 +765,7 @@ class Conv2dTiledMatrix(TiledMatrix):
         return scipy.sparse.csr_matrix((data, indices, indptr.astype(idt)), shape=(rows_n, self.shape[1]))
 
     def _expand_taps_host_coo(self, pixels):
-        """General route of _expand_taps_host (duplicate (out, in) pairs are summed by scipy's COO -> CSR conversion)."""
+        """General route of _expand_taps_host: duplicate (out, in) pairs become one stored entry, their terms summed in float32 in entry order."""
         t = self._taps
         (Cout, Hout, Wout) = self._outshape
         (Cin, Hin, Win) = self._inshape
@@ -790,9 +790,23 @@ class Conv2dTiledMatrix(TiledMatrix):
             rows = np.concatenate((rows, nz))
             cols = np.concatenate((cols, np.full(len(nz), self.shape[1] - 1, dtype=np.int64)))
             vals = np.concatenate((vals, lastv[nz]))
-        M = scipy.sparse.csr_matrix((vals, (rows, cols)), shape=(rows_n, self.shape[1]))
-        M.sort_indices()
-        return M
+        # duplicates -- several taps on one (output, input) pixel pair -- are ONE stored entry: the float32 sum of their terms in ENTRY order (what the device kernels and
+        # kn_export_csr compute).  scipy's own COO -> CSR conversion sums them behind an UNSTABLE sort, which defines no order for three or more terms: summed here.
+        order = np.lexsort((np.arange(len(rows)), cols, rows))                           # by (row, column), entry order inside a pair
+        (r, c, v) = (rows[order], cols[order], vals[order].astype(np.float32))
+        first = np.ones(len(r), dtype=bool)
+        first[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+        seg = np.cumsum(first) - 1                                                      # stored entry of every term
+        rank = np.arange(len(r)) - np.flatnonzero(first)[seg]                           # its position inside the entry
+        acc = v[first].copy()
+        for k in range(1, int(rank.max()) + 1 if len(rank) else 1):                     # one vectorised pass per term position: acc = fl(acc + term_k)
+            sel_k = np.flatnonzero(rank == k)
+            acc[seg[sel_k]] = (acc[seg[sel_k]] + v[sel_k]).astype(np.float32)
+        indptr = np.zeros(rows_n + 1, dtype=np.int64)
+        np.add.at(indptr, r[first] + 1, 1)
+        np.cumsum(indptr, out=indptr)
+        idt = np.int32 if max(len(acc), self.shape[1]) < 2 ** 31 - 1 else np.int64
+        return scipy.sparse.csr_matrix((acc, c[first].astype(idt), indptr.astype(idt)), shape=(rows_n, self.shape[1]))
 
     def rows_csr(self, pixels=None, channels=None):
         """Canonical CSR of the output rows (co, o), o in `pixels` (channel-major: row = co * len(pixels) + index of o), of a

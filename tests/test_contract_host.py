@@ -199,3 +199,36 @@ def test_split_form_of_a_filled_in_conv_is_the_same_operator():
         S._taps = dict(taps=np.zeros((9, 1, 1), np.float32), ent_out=np.zeros(9 * 224 * 224 * per_tap, np.int8))
         return S.split_capable(n)
     assert offered(60, 64) and offered(60, 256) and not offered(2, 256) and not offered(1, 256)
+
+
+def test_host_expansion_sums_a_pairs_terms_in_entry_order():
+    """Conv2dTiledMatrix.tosparse / rows_csr on a factored operator with up to six terms per (output, input) pixel pair: the stored value is the sequential float32 sum of the
+    terms fl(coef * tap) in ENTRY order -- the definition the device kernels (convtaps_exact_fill_kernel, the generic kernel) and kn_export_csr implement; scipy's own duplicate
+    summation sorts unstably and defines no order.  Checked against an explicit per-pair loop, on the whole operator and on a pixel subset."""
+    rng = np.random.RandomState(11)
+    (Cin, Cout, H) = (3, 7, 5)
+    HW = H * H
+    taps = (rng.randn(9, Cout, Cin) * np.array([1e-3, 1, 1e3, 1, 1e-2, 1, 1e2, 1, 1])[:, None, None]).astype(np.float32)      # wide dynamic range: the order of the sum shows
+    (eo, ei, et, ec) = ([], [], [], [])
+    for o in range(HW):
+        for i in rng.choice(HW, size=rng.randint(1, 6), replace=False):
+            for t in rng.choice(9, size=rng.randint(1, 7), replace=False):
+                eo.append(o); ei.append(i); et.append(t); ec.append(np.float32(rng.randn()))
+    (eo, ei, et, ec) = (np.array(eo, np.int32), np.array(ei, np.int32), np.array(et, np.int32), np.array(ec, np.float32))
+    lastcol = np.concatenate((rng.randn(Cout * HW), [1.0])).astype(np.float32)
+    W = ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, eo, ei, et, ec, lastcol)
+    want = {}
+    for e in range(len(eo)):                                                        # entry order
+        term = (ec[e] * taps[et[e]]).astype(np.float32)
+        key = (int(eo[e]), int(ei[e]))
+        want[key] = term if key not in want else (want[key] + term).astype(np.float32)
+    M = W.tosparse('csr')
+    assert M.shape == W.shape and M.nnz == len(want) * Cout * Cin + int(np.count_nonzero(lastcol)) and M.has_sorted_indices
+    D = M.toarray()
+    for ((o, i), V) in want.items():
+        assert np.array_equal(D[o + np.arange(Cout) * HW][:, i + np.arange(Cin) * HW], V), (o, i)
+    assert np.array_equal(D[:, -1], lastcol)
+    px = np.array([3, 11, 24])
+    S = W.rows_csr(px).toarray()
+    rows = (np.arange(Cout)[:, None] * HW + px[None, :]).ravel()
+    assert np.array_equal(S, D[rows])

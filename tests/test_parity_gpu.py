@@ -1387,6 +1387,9 @@ def test_convtaps_exact_fill_kernel_sums_a_pairs_terms_in_entry_order():
     ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
     y = W.torchdot(torch.as_tensor(X).to(dev()), exact=True).cpu().numpy()
     assert np.array_equal(y, ref), np.abs(y - ref).max()
+    Mh = W.tosparse('csr')                                         # the host expansion (Conv2dTiledMatrix._expand_taps_host_coo): the same stored values
+    Mh.sort_indices()
+    assert np.array_equal(Mh.indptr, M.indptr) and np.array_equal(Mh.indices, M.indices) and np.array_equal(Mh.data, M.data.astype(np.float32))
     # kn_export_csr: the same stored values
     E = W._device_op(dev()).export_csr() if hasattr(W._device_op(dev()), 'export_csr') else None
     if E is not None:
@@ -1425,8 +1428,7 @@ def test_split_application_of_a_filled_in_conv(Cin, Cout, H, fill, n_vecs, has_l
     ye = W.torchdot(xd, exact=True).cpu().numpy()
     M = W.tosparse('csr')
     M.sort_indices()
-    if W._taps['ent_coef'] is not None and len(np.unique(W._taps['ent_out'].astype(np.int64) * H * H + W._taps['ent_in'])) == len(W._taps['ent_out']):
-        assert np.array_equal(ye, oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X))
+    assert np.array_equal(ye, oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X))      # (pairs hit by several taps: the host expansion sums in entry order too)
     for relu in (False, True):
         slot = torch.zeros(1, dtype=torch.float32, device=dev())
         ys = W.torchdot(xd, relu=relu, exact='split', absmax=slot).cpu().numpy()
