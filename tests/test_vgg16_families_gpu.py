@@ -195,6 +195,24 @@ def test_filled_in_operators_take_the_filled_in_kernels(stochastic_direct):
     finally:
         del os.environ['KN_NO_FILL_EXACT']
     assert torch.equal(y, yg)
+    # ... and against the CPU oracle on the canonical CSR of sampled output pixels (host expansion: a pair's terms summed in entry order), on three real layers
+    rng = np.random.RandomState(4)
+    for (n, W) in convs:
+        if n not in ('conv1_1', 'conv2_1', 'conv4_1'):
+            continue
+        (Cout, Hout, Wout) = W._outshape
+        ns = np.bincount(W._taps['ent_out'], minlength=Hout * Wout)
+        pix = np.unique(np.concatenate((rng.choice(Hout * Wout, size=2, replace=False), [int(np.argmax(ns))])))
+        M = W.rows_csr(pix)
+        xs = torch.randn(W.shape[1], 8, generator=torch.Generator().manual_seed(2))
+        xs[-1] = 1.0
+        ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), xs.numpy())
+        got = W.torchdot(xs.to(dev), exact=True).cpu().numpy()
+        rows = (np.arange(Cout)[:, None] * Hout * Wout + pix[None, :]).ravel()
+        HiWi = W._inshape[1] * W._inshape[2]
+        (_, cnt) = np.unique(W._taps['ent_out'].astype(np.int64) * HiWi + W._taps['ent_in'], return_counts=True)
+        assert np.array_equal(got[rows], ref), n
+        print(n, 'bit-equal to the oracle on pixels', pix.tolist(), '| terms per stored entry: max', int(cnt.max()), 'mean %.2f' % float(cnt.mean()))
 
 
 def test_directly_keyed_stochastic_net_meets_the_references_tolerance_fused_and_split(stochastic_direct):
