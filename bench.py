@@ -855,6 +855,8 @@ def compact_record(res, detail_path=DETAIL_FILE):
                             'rescreened_every_forward': res['contract'].get('rescreened_every_forward')}
     if isinstance(res.get('end_to_end'), dict):
         line['end_to_end'] = _pick(res['end_to_end'], ('images_per_s', 'ms_per_step', 'encrypt_ms', 'error'))
+    if isinstance(res.get('exact_layers_parity'), dict):
+        line['exact_layers_parity'] = {'bit_equal': res['exact_layers_parity'].get('ok'), 'oracle_checked_layers': [r.get('layer') for r in (res['exact_layers_parity'].get('layers') or [])]}
     if res.get('collective') is not None:
         line['collective'] = _compact_collective(res['collective'])
     if res.get('errors'):
@@ -863,7 +865,7 @@ def compact_record(res, detail_path=DETAIL_FILE):
     line = _num(line)
     s = json.dumps(line, separators=(',', ':'))
     # belt and braces: if a pathological string still pushes the line over the limit, drop optional sections until it fits
-    for k in ('end_to_end', 'contract', 'secondary', 'exact', 'errors'):
+    for k in ('end_to_end', 'exact_layers_parity', 'contract', 'secondary', 'exact', 'errors'):
         if len(s) < LINE_LIMIT:
             break
         line.pop(k, None)
@@ -906,6 +908,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--exact-layers-parity', action='store_true',
+                    help='float-key workloads (vgg16-*): check the layers the contract keeps in the reference\'s order against the CPU oracle on one sampled output pixel each (OPT-IN: the host '
+                         'expansion of a filled-in pixel is 40-90 M stored entries per layer -- minutes of host time at full size; the same check runs on reduced nets in tests/test_vgg16_families_gpu.py)')
     ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'vgg16-givens28', 'vgg16-stochastic', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -1227,6 +1232,13 @@ def main():
         def leg_float_key_parity():
             res['float_key_parity'] = float_key_parity(dev)
 
+        def leg_exact_layers():
+            # float-key workloads: the layers the contract keeps in the reference's order, AS TIMED (whole batch, the key-net's own activations as input), against the CPU oracle
+            # on the canonical CSR of sampled output pixels (Conv2dTiledMatrix.rows_csr: a pixel pair hit by several taps is one stored entry, its terms summed in entry order)
+            names = tuple(r['name'] for r in knet.contract_report()['layers'] if r['exact'] is True and r['calibration'] is not None and r['calibration'].get('decided') == 'exact')
+            if names:
+                res['exact_layers_parity'] = exact_parity(knet, x_cipher, n_img=8, n_pix=1, layers=names)
+
         try:
             single = world == 1 and replay is None
             leg('contract', leg_contract)
@@ -1239,6 +1251,8 @@ def main():
             if args.workload == 'vgg16' and single and not args.exact and not args.no_exact_leg:
                 leg('exact', leg_exact)
                 leg('float_key_parity', leg_float_key_parity)
+            if args.exact_layers_parity and args.workload.startswith('vgg16-') and single and not args.exact:
+                leg('exact_layers_parity', leg_exact_layers)
             if args.experimental and args.workload.startswith('vgg16') and single and not args.exact:
                 leg('experimental_bf16x3', leg_bf16x3)
         finally:
