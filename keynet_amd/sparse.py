@@ -705,8 +705,26 @@ class Conv2dTiledMatrix(TiledMatrix):
         (eo, ei, et) = (pos[t['ent_out'][order]], t['ent_in'][order].astype(np.int64), t['ent_tap'][order])
         coef = None if t['ent_coef'] is None else t['ent_coef'][order]
         if len(eo) > 1 and np.any((eo[1:] == eo[:-1]) & (ei[1:] == ei[:-1])):
-            assert channels is None, 'channel subsets are not supported for operators with duplicate (out, in) pairs'
-            return self._expand_taps_host_coo(pixels)
+            # several taps on one (output, input) pixel pair: ONE stored entry per channel pair, the float32 sum of its terms fl(coef * tap) in entry order.  The selected
+            # pixels' pairs become the taps of an equivalent duplicate-free operator (one [Cout, Cin] matrix per pair, summed one term position at a time), which the
+            # block-copy route below expands -- the per-entry COO route (_expand_taps_host_coo) holds 3 x 8 bytes per stored value and sorts them all.
+            first = np.ones(len(eo), dtype=bool)
+            first[1:] = (eo[1:] != eo[:-1]) | (ei[1:] != ei[:-1])
+            seg = np.cumsum(first) - 1
+            rank = np.arange(len(eo)) - np.flatnonzero(first)[seg]
+            tp = t['taps']
+            def term(idx):
+                v = tp[et[idx]]
+                if coef is None:
+                    return v
+                cf = coef[idx][:, None, None]
+                return np.where(cf == 1.0, v, cf * v).astype(np.float32)
+            V = term(np.flatnonzero(first)).astype(np.float32, copy=True)
+            for k in range(1, int(rank.max()) + 1):
+                idx = np.flatnonzero(rank == k)
+                V[seg[idx]] = (V[seg[idx]] + term(idx)).astype(np.float32)
+            W2 = Conv2dTiledMatrix.fromtaps(self._inshape, self._outshape, V, pixels[eo[first]], ei[first], np.arange(len(V), dtype=np.int32), None, t['lastcol'])
+            return W2._expand_taps_host(pixels, channels)
         Cout = Cout if channels is None else int(channels)                                  # several taps on one (out, in) pair: scipy sums them
         ns = np.bincount(eo, minlength=npx)                                           # slots per selected pixel
         first = np.concatenate(([0], np.cumsum(ns)))[:-1]
