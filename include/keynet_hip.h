@@ -43,7 +43,16 @@ enum kn_status {
 #define KN_FLAG_EXACT  2u  /* demand the reference's accumulation order and mul-then-add rounding (bit-exact with
                               scipy csr_matvecs).  CSR operators always honour it; conv-tap operators switch from the
                               MFMA kernel to an order-preserving VALU kernel that walks the factored operator in the
-                              expansion's column order (no CSR is materialised: works at VGG-16 scale) */
+                              expansion's column order (no CSR is materialised: works at VGG-16 scale).
+                              What "bit-exact" means per operator: a CSR / tiled operator holds the reference's own stored
+                              values, so the result IS scipy's.  A conv-taps operator keyed directly in factored form
+                              (kn_convtaps_create) whose entries carry float coefficients holds the TERMS coef * tap of
+                              every stored value; a pixel pair hit by several taps is one stored value = the f32 sum of
+                              its terms in entry order.  The flag then gives the order-preserving product of THOSE
+                              stored values -- bit-equal to scipy csr_matvecs on kn_export_csr of this handle.  The
+                              reference formed the same values inside scipy's SpGEMM (keynet/layer.py:35) in SpGEMM's
+                              order: they agree to ~2e-6 relative, not bit for bit, which is inside the reference's
+                              1e-5 criterion for float keys and outside "bit-exact with the reference" */
 
 #define KN_FLAG_BF16X3 4u  /* allow a conv-taps operator to form its f32 products on the bf16 matrix pipe: operands split exactly into three
                               bf16 parts, six of the nine cross products kept (the dropped ones are <= 2^-23 of a product), f32 accumulate.

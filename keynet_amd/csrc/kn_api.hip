@@ -930,13 +930,14 @@ static int spmm_impl(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_v
         rc = dense_reduce(ws, n_vecs, outs, S, h->dense_lastcol, x_dev + (h->cols - 1) * ldx, y_dev, ldy, n_vecs, (flags & KN_FLAG_RELU) ? 1 : 0, s);
     } else {
         // KN_FLAG_EXACT is honoured inside convtaps_spmm by the order-preserving kernel on the factored operator
-        if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && h->ct.tapsB == nullptr && plan_sink() == nullptr) {
+        // lazily built side tables: double-checked under Handle::lazy_mu; both builders publish their pointer (release) only after the data is in HBM
+        if ((flags & KN_FLAG_BF16X3) && !(flags & KN_FLAG_EXACT) && __atomic_load_n(&h->ct.tapsB, __ATOMIC_ACQUIRE) == nullptr && plan_sink() == nullptr) {
             std::lock_guard<std::mutex> g(h->lazy_mu);           // bf16 planes of the taps, once (not capturable: like any first use)
             rc = convtaps_build_bf16(h->ct, h->h_taps);
             if (rc) return rc;
         }
-        if ((flags & KN_FLAG_EXACT) && h->ct.fill_rec == nullptr && plan_sink() == nullptr && convtaps_fill_ok(h->ct)) {
-            std::lock_guard<std::mutex> g(h->lazy_mu);           // record lists of the filled-in order-preserving kernel, once (built on the device, on this stream)
+        if ((flags & KN_FLAG_EXACT) && __atomic_load_n(&h->ct.fill_rec, __ATOMIC_ACQUIRE) == nullptr && plan_sink() == nullptr && convtaps_fill_ok(h->ct)) {
+            std::lock_guard<std::mutex> g(h->lazy_mu);           // record lists of the filled-in order-preserving kernel, once (built on the device on this stream, waited for, then published)
             rc = convtaps_build_fill(h->ct, s);
             if (rc) return rc;
         }

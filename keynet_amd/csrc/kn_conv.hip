@@ -2063,7 +2063,13 @@ int convtaps_build_fill(ConvTapsDev& A, hipStream_t s) {
         (void)hipFree(d);
         return fail(KN_ERR_HIP, "convtaps_fill_records_kernel launch failed");
     }
-    A.fill_rec = d;
+    // The records are published only when they EXIST: a second thread / stream that sees the pointer launches convtaps_exact_fill_kernel on its own stream with no
+    // ordering against stream s (round-5 advisor finding).  One host wait per operator lifetime; the caller holds Handle::lazy_mu.
+    if (hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(KN_ERR_HIP, "convtaps_fill_records_kernel failed");
+    }
+    __atomic_store_n(&A.fill_rec, d, __ATOMIC_RELEASE);
     return KN_OK;
 }
 
@@ -2113,8 +2119,8 @@ int convtaps_build_bf16(ConvTapsDev& A, const std::vector<float>& taps /* [ntaps
     uint16_t* d = nullptr;
     int rc = upload(&d, hb.data(), hb.size());
     if (rc) return rc;
-    A.tapsB = d;
     A.tapsB_plane = (int64_t)plane * 2;
+    __atomic_store_n(&A.tapsB, d, __ATOMIC_RELEASE);         // upload() is a synchronous copy: the planes are in HBM before the pointer is visible
     return KN_OK;
 }
 

@@ -39,3 +39,8 @@ KEYGEN_CASES = [
                                         hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1))),
     ('ragged_blocksize', (1, 14, 14), dict(global_geometric='identity', local_geometric='permutation', global_photometric='identity', local_photometric='identity', blocksize=4)),
 ]
+
+# keyword arguments of test/test_keynet.py:116-129 (test_vgg16_stochastic) scaled to MiniNet (2,16,16): tile 4, block 4, two hierarchy levels.
+# make_golden.py f8 hands them to the REFERENCE's keynet.system.Keynet, the tests to keynet_amd.system.Keynet.
+STOCHASTIC_KW = dict(tileshape=(4, 4), global_geometric='hierarchical_permutation', hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1),
+                     local_geometric='doubly_stochastic', alpha=2.0, blocksize=4, local_photometric='uniform_random_affine', beta=1.0, gamma=1.0)

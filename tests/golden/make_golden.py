@@ -17,6 +17,9 @@ Fixtures:
   F6 keygen_cases.npz    (A, Ainv) of keynet.system.keygen for every key family on small shapes (host-keying parity)
   F7 bn_tiny_{perm,identity}.npz  conv -> '<conv>_bn' BatchNorm2d (random running stats) -> dropout -> relu nets: the batch-norm fold
                          (keynet/torch.py:99-113) feeds the stored operators, so its f32 association is part of the contract
+  F8 mini_tiled_stochastic.npz  MiniNet (2,16,16) under the key family of test/test_keynet.py:116-129 (test_vgg16_stochastic:
+                         hierarchical permutation + doubly-stochastic local keys + uniform random affine): FILLED-IN operators
+                         (keynet/sparse.py:335-353 keys, SpGEMM fill-in at keynet/layer.py:35), blocks/tiles dumps, CSR, I/O
 """
 import os
 import sys
@@ -440,6 +443,37 @@ def f7():
     return ms
 
 
+from keygen_case_table import STOCHASTIC_KW  # noqa: E402  (pure data)
+
+
+def f8():
+    """The filled-in key family (test/test_keynet.py:116-129 scaled to MiniNet): the reference's own keyed operators and per-layer outputs."""
+    import warnings
+    torch.manual_seed(0)
+    net = MiniNet().eval()
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = keynet.system.Keynet((2, 16, 16), net, **STOCHASTIC_KW)
+    out = {}
+    manifest = {'layers': {}, 'recipe': 'torch.manual_seed(0); MiniNet(); np.random.seed(0); Keynet((2,16,16), net, %s); torch.manual_seed(1); x=randn(4,2,16,16)'
+                % ', '.join('%s=%r' % kv for kv in STOCHASTIC_KW.items())}
+    state_arrays(net, out)
+    torch.manual_seed(1)
+    x = torch.randn(4, 2, 16, 16)
+    dump_keynet(sensor, knet, net, x, out, manifest)
+    err = np.abs(out['logits_keyed'] - out['logits_plain']).max()
+    print('mini stochastic: |keyed-plain|=%g' % err)
+    assert np.allclose(out['logits_keyed'], out['logits_plain'], atol=1e-5)        # the reference's own criterion for this family (test_keynet.py:128)
+    for (name, rec) in manifest['layers'].items():
+        if out['L.%s.kind' % name] == 'conv2dtiled':
+            # fill-in: stored entries per output row of channel 0 against the 9 taps of the unkeyed operator
+            (ip, shape) = (out['L.%s.indptr' % name], out['L.%s.shape' % name])
+            rec['max_row_nnz'] = int(np.diff(ip).max())
+            print('   %s: nnz %d, longest row %d' % (name, rec['nnz'], rec['max_row_nnz']))
+    return save('mini_tiled_stochastic.npz', out, manifest)
+
+
 from keygen_case_table import KEYGEN_CASES  # noqa: E402  (pure data: names, shapes, keyword arguments)
 
 
@@ -467,12 +501,12 @@ def f6():
 
 if __name__ == '__main__':
     os.chdir('/tmp')
-    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7']
+    which = sys.argv[1:] or ['f1', 'f2', 'f3', 'f4', 'f5', 'f6', 'f7', 'f8']
     mf = os.path.join(HERE, 'MANIFEST.json')
     manifest = json.load(open(mf)) if os.path.exists(mf) else {}
     manifest['_versions'] = {'numpy': np.__version__, 'scipy': scipy.__version__, 'torch': torch.__version__, 'python': sys.version.split()[0]}
     for w in which:
-        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5, 'f6': f6, 'f7': f7}[w]()
+        r = {'f1': f1, 'f2': f2, 'f3': f3, 'f4': f4, 'f5': f5, 'f6': f6, 'f7': f7, 'f8': f8}[w]()
         manifest[w] = r
     with open(mf, 'w') as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -53,10 +53,13 @@ def test_multi_gpu_record_fits_the_line(world):
                          'ranks': [{'rank': k, 'local_rank': k, 'device_index': k, 'device_name': 'AMD Instinct MI355X', 'pid': 100000 + k} for k in range(world)],
                          'op': 'all_gather_into_tensor of [256, 2622] f32 logits per rank', 'bytes_per_rank': 2684928, 'ms_per_call': 0.0731234, 'ms_per_call_wall': 0.08, 'calls_timed': 20,
                          'every_rank_shard_bit_equal_to_its_local_forward': True, 'rank0_shard_bit_equal': True, 'rank0_shard_sha256': 'ab' * 32,
+                         'rank_images_per_s': {'min': 4400.123456789, 'max': 4512.3, 'all': [4400.123456789] * world, 'what': 'x' * 300},
+                         'startup': {'keying_or_loading_s_rank0': 26.0},
                          'peer_shard_recomputed_on_rank0': {'peer_rank': world - 1, 'bit_equal': True}}
     r = check(bench.compact_record(res))
     c = r['collective']
     assert c['ranks_seen'] == world and c['ranks'] == [[k, k] for k in range(world)]
+    assert c['backend'] == 'nccl' and c['bytes_per_rank'] == 2684928 and abs(c['gather_ms'] - 0.0731234) < 1e-6 and c['rank_images_per_s'] == {'min': 4400.12, 'max': 4512.3}
     assert c['peer_shard_recomputed_on_rank0'] == {'peer_rank': world - 1, 'bit_equal': True}
     assert 'pid' not in json.dumps(c) and 'device_name' not in json.dumps(c)
 

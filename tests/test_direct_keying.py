@@ -72,3 +72,45 @@ def test_direct_equals_reference_route_float_keys(golden):
         (D, R) = (np.asarray(c.todense(), dtype=np.float64), np.asarray(ref.todense(), dtype=np.float64))
         scale = np.abs(R).max()
         assert np.abs(D - R).max() <= 2e-6 * scale, (name, np.abs(D - R).max(), scale)
+
+
+def test_direct_equals_reference_route_filled_in_keys(golden):
+    """The doubly-stochastic family (test/test_keynet.py:116-129): one (output pixel, input pixel) pair is hit by several taps, so ONE stored entry of
+    the reference's matrix is a sum of terms coef * tap that scipy's SpGEMM (keynet/layer.py:35) accumulates in ITS order.  The factored operator holds
+    the terms (and forms the entry as their f32 sum in entry order): equal to the reference's stored values up to that re-association, 2e-6 of the
+    largest entry -- NOT bit for bit -- and with the same stored structure (every reference entry is present, no extra ones beyond exact zeros)."""
+    import sys, os, warnings
+    import scipy.sparse
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from keygen_case_table import STOCHASTIC_KW
+    z = golden('mini_tiled_stochastic.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.Keynet((2, 16, 16), net, direct=True, **STOCHASTIC_KW)
+    multi = 0
+    for (name, child) in knet._keynet.named_children():
+        if not isinstance(child, KeyedLayer):
+            continue
+        p = 'L.%s.' % name
+        kind = str(z[p + 'kind'])
+        c = child.W.tocsr() if isinstance(child.W, ksp.TiledMatrix) else child.W._matrix.tocsr()
+        ref = scipy.sparse.csr_matrix((z[p + 'data'], z[p + 'indices'], z[p + 'indptr']), shape=c.shape)
+        (D, R) = (np.asarray(c.todense(), dtype=np.float64), np.asarray(ref.todense(), dtype=np.float64))
+        scale = np.abs(R).max()
+        assert np.abs(D - R).max() <= 2e-6 * scale, (name, np.abs(D - R).max(), scale)
+        if kind == 'conv2dtiled':
+            t = child.W._taps
+            assert t is not None and t['ent_coef'] is not None
+            # several taps per pixel pair: more (pixel, tap) entries than distinct (output pixel, input pixel) pairs
+            pairs = len(set(zip(t['ent_out'].tolist(), t['ent_in'].tolist())))
+            multi += int(len(t['ent_out']) > pairs)
+            # rows_csr (what the GPU tests hand the oracle for a direct operator) against the reference's own stored rows
+            (Cout, Hout, Wout) = child.W._outshape
+            pix = np.arange(0, Hout * Wout, 7)
+            S = child.W.rows_csr(pix)
+            for co in range(Cout):
+                mine = np.asarray(S[co * len(pix):(co + 1) * len(pix)].todense(), dtype=np.float64)
+                assert np.abs(mine - R[co * Hout * Wout + pix]).max() <= 2e-6 * scale, (name, co)
+    assert multi == 2, 'the fixture is meant to exercise pixel pairs hit by several taps'

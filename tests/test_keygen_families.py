@@ -53,6 +53,25 @@ def test_tiled_orthogonal_keynet_matches_reference(golden):
     _check_layers(z, knet)
 
 
+def test_tiled_stochastic_keynet_matches_reference(golden):
+    """The FILLED-IN key family of test/test_keynet.py:116-129 (hierarchical permutation + doubly-stochastic local keys, keynet/sparse.py:335-353,
+    + uniform random affine) through the reference route (Toeplitz -> SpGEMM at keynet/layer.py:35 -> tiler): sensor key, blocks, tiles, channel
+    matrices and the expanded CSR of every layer are the reference's, bit for bit (tests/golden/mini_tiled_stochastic.npz)."""
+    from test_host_keying import _check_layers, _check_sensor
+    from keygen_case_table import STOCHASTIC_KW
+    z = golden('mini_tiled_stochastic.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.Keynet((2, 16, 16), net, **STOCHASTIC_KW)
+    _check_sensor(z, sensor)
+    _check_layers(z, knet)
+    # the premise of the fixture: the conv operators are filled in (187 / 181 stored entries in the longest row against 2*9+1 / 4*9+1 unkeyed)
+    for (name, longest) in (('conv1', 187), ('conv2', 181)):
+        assert int(np.diff(z['L.%s.indptr' % name]).max()) == longest
+
+
 def test_hierarchical_permutation_matrix_is_the_image_permutation():
     """test/test_blockpermute.py:62-73: P.dot(img.flatten()).reshape(shape) == hierarchical_block_permute(img) for the same draws."""
     from keynet_amd import keys as kkeys

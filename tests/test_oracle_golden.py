@@ -4,7 +4,7 @@ import pytest
 import oracle
 
 NETS = ['lenet_perm.npz', 'allconv_tiny_perm.npz', 'mini_tiled_identity.npz', 'mini_tiled_permutation.npz',
-        'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz', 'bn_tiny_perm.npz', 'bn_tiny_identity.npz']
+        'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz', 'mini_tiled_stochastic.npz', 'bn_tiny_perm.npz', 'bn_tiny_identity.npz']
 
 
 @pytest.mark.parametrize('name', NETS)

@@ -18,7 +18,7 @@ from nets import LeNet_AvgPool, MiniNet, TinyAllConv, load_weights, _Chain
 pytestmark = pytest.mark.gpu
 
 EXACT_NETS = ['lenet_perm.npz', 'allconv_tiny_perm.npz', 'bn_tiny_perm.npz', 'bn_tiny_identity.npz']
-TILED_NETS = ['mini_tiled_identity.npz', 'mini_tiled_permutation.npz', 'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz']
+TILED_NETS = ['mini_tiled_identity.npz', 'mini_tiled_permutation.npz', 'mini_tiled_permutation8.npz', 'mini_tiled_orthogonal.npz', 'mini_tiled_stochastic.npz']
 TOL = 1e-5   # north_star: within 1e-5 for float keyed layers (MFMA path); bit-exact elsewhere
 
 
@@ -113,7 +113,7 @@ def test_tiled_keynet_layers(golden, name):
     assert not rep['undecided']
     if 'orthogonal' in name:
         assert rep['switched'], rep                                    # gamma = 100 bias keys: these conv layers cannot hold 1e-5 on re-ordered f32 arithmetic
-    else:
+    elif 'stochastic' not in name:
         assert not rep['switched'], rep                                # identity / permutation keys stay on the matrix cores
 
 
@@ -281,6 +281,58 @@ def test_full_stack_tiled_orthogonal(golden, direct):
     y = knet.forward(xc).reshape(4, 10).cpu().numpy()
     assert np.allclose(y, z['logits_keyed'], atol=1e-4)
     assert np.allclose(y, z['logits_plain'], atol=1e-4)
+
+
+def test_filled_in_key_family_direct_route_against_the_reference(golden):
+    """The FILLED-IN key family (test/test_keynet.py:116-129; doubly-stochastic local keys keynet/sparse.py:335-353; SpGEMM fill-in keynet/layer.py:35) keyed by
+    the DIRECT route (keynet_amd/direct.py: the factored operator holds the terms coef * tap of every stored entry) against the REFERENCE's own per-layer outputs
+    (tests/golden/mini_tiled_stochastic.npz; inputs of every layer = the reference's previous-layer outputs).  What is claimed, and no more:
+      * KN_FLAG_EXACT on a direct-keyed float operator = the order-preserving product of the factored operator's OWN stored values (each the f32 sum of its terms
+        in entry order): bit-equal to the oracle on Conv2dTiledMatrix.rows_csr -- and within the reference's gate (np.allclose(atol=1e-5), element-wise) of the
+        reference's outputs, NOT bit-equal to them: scipy's SpGEMM summed the same terms in another order (2e-6 relative on the stored values, tests/test_direct_keying.py);
+      * the layer's default contract ('auto'), the matrix-core kernel and the split application: inside the same gate of the reference's outputs;
+      * kn_spmm_plan names the kernels this family was built for."""
+    import sys, os, warnings
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from keygen_case_table import STOCHASTIC_KW
+    z = golden('mini_tiled_stochastic.npz')
+    net = load_weights(MiniNet(), z)
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (sensor, knet) = ksys.Keynet((2, 16, 16), net, direct=True, **STOCHASTIC_KW)
+    xc = sensor.fromtensor(torch.as_tensor(z['x_plain']).to(dev())).encrypt().astensor()
+    assert close(xc.cpu().numpy(), z['x_cipher'], tol=1e-6)
+    prev = z['x_cipher']
+    convs = 0
+    for (lname, child) in knet._keynet.named_children():
+        ref = z['Y.%s' % lname]
+        if isinstance(child, KeyedLayer):
+            xin = torch.as_tensor(prev).to(dev())
+            W = child.W
+            if isinstance(W, ksp.Conv2dTiledMatrix):
+                convs += 1
+                assert W._taps is not None and W._taps['ent_coef'] is not None and W.fill_factor() >= ksp.Conv2dTiledMatrix.SPLIT_MIN_FILL and W.split_capable()
+                with torch.cuda.device(dev()):
+                    plan = W._device_op(dev()).plan(int(xin.shape[0]), _capi.KN_FLAG_EXACT)
+                assert 'convtaps_exact_fill_kernel' in plan, plan
+                ye = W.torchdot(xin.t(), exact=True).t().cpu().numpy()
+                assert close(ye, ref), 'order-preserving product of the direct operator, layer %s: %g' % (lname, np.abs(ye - ref).max())
+                M = W.rows_csr()                                                   # every pixel: the whole operator incl. its homogeneous row
+                assert np.array_equal(ye, oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), np.ascontiguousarray(prev.T)).T), lname
+                R = scipy.sparse.csr_matrix((z['L.%s.data' % lname], z['L.%s.indices' % lname], z['L.%s.indptr' % lname]), shape=M.shape)
+                assert abs(M - R).max() <= 2e-6 * abs(R).max()                     # its stored values against the reference's tocsr(): re-associated sums, not bits
+                for (mode, what) in ((False, 'matrix cores'), ('split', 'split application')):
+                    ym = W.torchdot(xin.t(), exact=mode).t().cpu().numpy()
+                    assert close(ym, ref), '%s, layer %s: %g' % (what, lname, np.abs(ym - ref).max())
+            y = child.forward(xin).cpu().numpy()                                  # the layer's default contract
+            assert close(y, ref), 'layer %s under its default contract: %g' % (lname, np.abs(y - ref).max())
+            if isinstance(W, ksp.Conv2dTiledMatrix):
+                assert child._contract_record['decided'] in ('split', 'mfma', 'exact'), child._contract_record
+        prev = ref
+    assert convs == 2
+    out = knet.forward(xc).reshape(4, 10).cpu().numpy()
+    assert np.allclose(out, z['logits_keyed'], atol=1e-5) and np.allclose(out, z['logits_plain'], atol=1e-5)     # the reference's criterion for this family (test_keynet.py:128)
 
 
 def test_challenge_known_answer(golden):
