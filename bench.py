@@ -82,7 +82,7 @@ def main():
     ap.add_argument('--exact-layers-parity', action='store_true',
                     help='float-key workloads (vgg16-*): check the layers the contract keeps in the reference\'s order against the CPU oracle on one sampled output pixel each (OPT-IN: the host '
                          'expansion of a filled-in pixel is 40-90 M stored entries per layer -- minutes of host time at full size; the same check runs on reduced nets in tests/test_vgg16_families_gpu.py)')
-    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'vgg16-givens28', 'vgg16-stochastic', 'lenet', 'allconv'])
+    ap.add_argument('--workload', default='vgg16', choices=['vgg16', 'vgg16-gain', 'vgg16-givens', 'vgg16-givens28', 'vgg16-stochastic', 'vgg16-slice', 'lenet', 'allconv'])
     ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the BASELINE config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--layer-iters', type=int, default=5)
@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--trace-layers', default=None, metavar='FILE', help='profiling aid (run under rocprofv3 --kernel-trace): after the first forward, launch every layer '
                                                                           '8 times back to back with a marker kernel between layers, write the layer list (name, kind, flops, bytes) to FILE and exit; '
                                                                           'tools/trace_layers.py joins it with the kernel trace into a per-layer table')
+    ap.add_argument('--pmc-forward', default=None, metavar='FILE', help='profiling aid (run under rocprofv3 --kernel-trace --pmc <counter>): behind the calibrating forward and two warm ones, launch '
+                                                                        'EXACTLY ONE forward_linear -- the timed step\'s launches, nothing else -- between two marker kernels, write FILE and exit; '
+                                                                        'tools/pmc_forward.py sums the counter over the launches between the markers (`roofline.traffic`: ONE definition)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -204,6 +207,22 @@ def main():
         log('[bench] layer list written to %s' % args.trace_layers)
         return
 
+    if args.pmc_forward:
+        for _ in range(2):
+            knet.forward_linear(x_cipher)
+        torch.cuda.synchronize()
+        marker = torch.zeros(1031, device=dev)
+        marker.add_(1.0)                                       # (one torch elementwise kernel each side: what tools/pmc_forward.py cuts on)
+        knet.forward_linear(x_cipher)                          # the launches of ONE timed step
+        marker.add_(1.0)
+        torch.cuda.synchronize()
+        table = layer_table(knet, batch)
+        json.dump({'workload': desc, 'batch': batch, 'mode': mode, 'forwards_between_markers': 1, 'csrc_sha256': kernel_sources_sha(),
+                   'algorithmic_bytes_per_forward': {k: sum(r['bytes'] for r in table if r['kind'] == k) for k in sorted({r['kind'] for r in table})},
+                   'layers': [{k: r[k] for k in ('name', 'kind', 'rows', 'cols', 'nnz', 'flops', 'bytes', 'plan')} for r in table]}, open(args.pmc_forward, 'w'), indent=1)
+        log('[bench] one forward between markers; layer list written to %s' % args.pmc_forward)
+        return
+
     replay = knet.capture(x_cipher) if args.graph else None
 
     def step():
@@ -303,7 +322,7 @@ def main():
                         note='one launch for the whole key-net, activations in LDS; launch_per_layer_ms = the seven separate kernels it replaces (KN_NO_CHAIN=1)')
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
-            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'vgg16-givens28': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, tile 28: the reference\'s test_vgg16_orthogonal_8)', 'vgg16-stochastic': 'VGG-16 224x224 (float keys: hierarchical permutation + doubly-stochastic blocks + affine photometric: the reference\'s test_vgg16_stochastic)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
+            'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'vgg16-givens28': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, tile 28: the reference\'s test_vgg16_orthogonal_8)', 'vgg16-stochastic': 'VGG-16 224x224 (float keys: hierarchical permutation + doubly-stochastic blocks + affine photometric: the reference\'s test_vgg16_stochastic)', 'vgg16-slice': 'VGG-16 slice 32x32 width 8 (rehearsal workload)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
             'value': batch * world * args.steps / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'mode': mode_desc,

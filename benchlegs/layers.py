@@ -146,7 +146,8 @@ def roofline_of(table, workload, batch, mode):
         ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
         (traffic, tsrc) = committed_traffic(workload, mode) if batch == 256 else (None, 'PMC pass is for 256 images')
         return dict(bound='mfma', kernel='convtaps_mfma_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc,
+                    frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass over ONE marked forward: tools/pmc_forward.py)', traffic_source=tsrc,
+                    traffic_ratio=(traffic / sum(r['bytes'] for r in dom)) if traffic else None,
                     algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
     macs = sum(r['nnz'] for r in dom) * float(batch)
     intensity = 2.0 * macs / sum(r['bytes'] for r in dom)

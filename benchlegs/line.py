@@ -12,7 +12,7 @@ DETAIL_FILE = 'bench_detail.json'
 def _compact_roofline(r):
     if not isinstance(r, dict):
         return r
-    out = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'algorithmic_flops', 'algorithmic_macs', 'ms_per_forward'))
+    out = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_ratio', 'algorithmic_bytes', 'algorithmic_flops', 'algorithmic_macs', 'ms_per_forward'))
     out['kernel'] = _clip(out.get('kernel'), 96)
     return out
 

@@ -84,6 +84,8 @@ def build_workload_shared(name, rank, world, exact=None):
         except (OSError, AssertionError) as e:
             log('[bench rank %d] cannot open rank 0\'s archive (%s): keying locally' % (rank, e))
             f = None
+    if os.environ.get('KN_BENCH_TEST_DIE_BEFORE_BARRIER') == str(rank):
+        os._exit(17)                                         # test-only (tests/test_dist_gpu.py): a loader dies holding the archive; never set by the driver
     _barrier('archive opened')                               # every loader holds the inode now
     if rank == 0:
         os.close(fd)                                         # the archive lives exactly as long as somebody is reading it

@@ -63,6 +63,14 @@ def build_workload(name, rank, exact=None):
                                      local_photometric='uniform_random_affine', beta=1.0, gamma=1.0, memoryorder='channel', exact=exact)
         (inshape, batch, desc) = ((3, 224, 224), 16, 'Keynet(hierarchical_permutation levels 0-2 + doubly_stochastic alpha=2 + uniform_random_affine, tile=blocksize=14) VGG16(2622) '
                                                       '3x224x224: test/test_keynet.py:116-129')
+    elif name == 'vgg16-slice':
+        # cfg5's topology at a size that keys in seconds (the 21 keyed layers of VGG-16 at width 8 on 32 x 32 inputs, tile 8): what the 8-rank rehearsal test of the
+        # tiers runs (tests/test_dist_gpu.py); never a reported number
+        torch.manual_seed(0)
+        net = VGG16(num_classes=10, width=8, fc_width=64, insize=32).eval()
+        np.random.seed(0)
+        (sensor, knet) = ksys.TiledPermutationKeynet((3, 32, 32), net, 8, exact=exact)
+        (inshape, batch, desc) = ((3, 32, 32), 16, 'TiledPermutationKeynet VGG16 slice (width 8, 3x32x32, tile 8): rehearsal workload, not a BASELINE config')
     elif name == 'lenet':
         torch.manual_seed(0)
         net = LeNet_AvgPool().eval()

@@ -31,6 +31,7 @@ Tuning tuning_from_env() {
         {"KN_NO_SPTR", &Tuning::no_sptr}, {"KN_NO_SMALLK_PIPE", &Tuning::no_smallk_pipe}, {"KN_NO_GROUP_PIPE", &Tuning::no_group_pipe},
         {"KN_NO_BIG_GROUPS", &Tuning::no_big_groups}, {"KN_NO_EXACT_TABLE", &Tuning::no_exact_table}, {"KN_GROUP_MFMA", &Tuning::group_mfma},
         {"KN_BIG_MFMA16", &Tuning::big_mfma16}, {"KN_MF_NRB", &Tuning::mf_nrb}, {"KN_TABLE_NRB", &Tuning::table_nrb}, {"KN_NO_FILL_EXACT", &Tuning::no_fill_exact},
+        {"KN_NO_FILL_TILES2", &Tuning::no_fill_tiles2},
 #ifdef KN_ABLATION
         {"KN_OCC", &Tuning::occ}, {"KN_NO_TAIL_SPLIT", &Tuning::no_tail_split}, {"KN_NO_SMALLK", &Tuning::no_smallk}, {"KN_EXACT_PIPE", &Tuning::exact_pipe},
         {"KN_EXACT_COB_GROUPS", &Tuning::exact_cob_groups}, {"KN_EXACT_XD", &Tuning::exact_xd}, {"KN_EXACT_VEC", &Tuning::exact_vec}, {"KN_MF_PF", &Tuning::mf_pf},
@@ -54,6 +55,7 @@ std::string Tuning::describe() const {
     add("no_sptr", no_sptr, d.no_sptr); add("no_smallk_pipe", no_smallk_pipe, d.no_smallk_pipe); add("no_group_pipe", no_group_pipe, d.no_group_pipe);
     add("no_big_groups", no_big_groups, d.no_big_groups); add("no_exact_table", no_exact_table, d.no_exact_table); add("group_mfma", group_mfma, d.group_mfma);
     add("big_mfma16", big_mfma16, d.big_mfma16); add("mf_nrb", mf_nrb, d.mf_nrb); add("table_nrb", table_nrb, d.table_nrb); add("no_fill_exact", no_fill_exact, d.no_fill_exact);
+    add("no_fill_tiles2", no_fill_tiles2, d.no_fill_tiles2);
     add("occ", occ, d.occ); add("no_tail_split", no_tail_split, d.no_tail_split); add("no_smallk", no_smallk, d.no_smallk); add("exact_pipe", exact_pipe, d.exact_pipe);
     add("exact_cob_groups", exact_cob_groups, d.exact_cob_groups); add("exact_xd", exact_xd, d.exact_xd); add("exact_vec", exact_vec, d.exact_vec); add("mf_pf", mf_pf, d.mf_pf);
     add("table_window", table_window, d.table_window); add("table_strip", table_strip, d.table_strip); add("no_patch", no_patch, d.no_patch); add("conv_ball", conv_ball, d.conv_ball);

@@ -531,9 +531,24 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     // (Measured and dropped, round 5: the quad's instructions in a hand-written order -- four products, then the four dependent adds with the quad's LDS reads
     // and value request between them -- changes nothing: 36.9-37.3 against 36.5 us per LeNet forward.  A wavefront ALONE on its SIMD pays ~9 clocks per vector
     // instruction whatever stands between them (tools/micro/dep_chain.hip: 20 instructions of a quad = 190 clocks), so fc1 costs 197 quads x 15 instructions.)
+#if defined(KN_ABLATION) && defined(KN_CHAIN_THIN_SEQ)
+    // DIAGNOSTIC BUILD ONLY, TIMING ONLY (the results are wrong): what the thin walk would cost if its input buffer were laid out in the layer's stored column order
+    // -- activations of quad k at (first entry) + 64 k bytes, read with constant offsets (ds_read2_b64), no column quads at all: 11 vector instructions per quad instead of 15.
+    const uint32_t seq0 = (uint32_t)ldc(0).x;
+    uint32_t seq_trip = seq0;
+    auto xread_seq = [&](const uint32_t a, f32x2 (&xx)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) xx[e] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + a + 16u * (uint32_t)e);
+    };
+#endif
     auto quad = [&](const int i, const int k, const bool refill) {          // i: ring slot (static), k: quad index
+#if defined(KN_ABLATION) && defined(KN_CHAIN_THIN_SEQ)
+        xread_seq(seq_trip + 64u * (uint32_t)(i + 2), x[(i + 2) % 3]);
+        if (i == DV - 1) seq_trip += 64u * DV;
+#else
         cq[(i + 1) & 1] = ldc(k + 3);
         xread(cq[i & 1], x[(i + 2) % 3]);
+#endif
         __builtin_amdgcn_sched_barrier(0);                 // the next quads' LDS reads in flight under this quad's arithmetic
         macs(x[i % 3], v[i]);
         if (refill) v[i] = ldv(k + DV);

@@ -1317,6 +1317,10 @@ __global__ __launch_bounds__(256) void convtaps_exact_kernel(ConvArgs p, int n_c
 // TREG (operators with at most 16 taps: every conv window up to 4 x 4): the lane's value row lives in REGISTERS -- 16 VGPRs hold tapsT[0 .. ntaps)[ci][co0 + (l & 31)],
 // reloaded when the walk enters the next input channel -- and a slot picks its tap by the scalar index mode (s_set_gpr_idx_on): no value-row load per slot, half the
 // vector-memory instructions (the CU's one address unit serves four SIMDs).
+// TILES = 2 (round 6; batches that are whole 128-column tiles): one wavefront = one output pixel x 32 (64) output channels x 128 batch columns.  Lane l loads its two adjacent
+// columns c0 + 2 l, c0 + 2 l + 1 of a slot's activation row with ONE 8-byte load; the stored value of a column -- formed once, as before -- multiplies both column tiles: two (four)
+// matrix instructions and twice the packed adds per stored column for the SAME slot bookkeeping, which is what separates this kernel from the no-FMA roof.
+// Two result blocks alternate, so a block's adds sit behind the next block's matrix instruction instead of waiting for their own.
 struct FillRec {
     int32_t in, tapoff;     // tapoff: offset of the tap's plane in tapsT (floats), or the tap index (TREG)
     float coef;
@@ -1345,7 +1349,7 @@ __global__ __launch_bounds__(256) void convtaps_fill_records_kernel(const int32_
 }
 
 #pragma clang fp contract(off)
-template <int NT, bool WIDE> // taps held in registers: 16, or 0 = one value-row load per slot (a 9-, 10- or 12-register tap vector measured 119 - 122 VGPRs against 99 with 16: not instantiated)
+template <int NT, bool WIDE, int TILES = 1> // TILES: 64-column tiles per wavefront (2: see above); taps held in registers: 16, or 0 = one value-row load per slot (a 9-, 10- or 12-register tap vector measured 119 - 122 VGPRs against 99 with 16: not instantiated)
 __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p, const int32_t* __restrict__ fill_ptr, const FillRec* __restrict__ rec, int n_cc, int n_ct,
                                                                      int64_t n_wg) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1354,6 +1358,8 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
     typedef int i32x16 __attribute__((ext_vector_type(16)));
     constexpr bool TREG = NT > 0;
     typedef float f32xNT __attribute__((ext_vector_type(NT > 0 ? NT : 1)));
+    static_assert(TILES == 1 || TILES == 2, "one or two 64-column tiles per wavefront");
+    typedef std::conditional_t<TILES == 2, f32x2, float> xrow_t;    // a lane's activations of one slot: column c0 + lane, or columns c0 + 2 lane and c0 + 2 lane + 1
     constexpr int PF = 8;                                  // slots in flight per wavefront (ring of operand registers) = one unrolled loop body
     constexpr int LPS = TREG ? 1 : 2;                      // vector loads per slot
     // workgroup -> XCD x = blockIdx & 7 owns a contiguous range of the work (pixels in processing order: the 196 pixels of a key block read the same input pixels)
@@ -1371,17 +1377,19 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
     constexpr int CH = WIDE ? 64 : 32;                     // output channels per wavefront
     constexpr int NH = WIDE ? 2 : 1;                       // 32-channel halves
     const int co0 = __builtin_amdgcn_readfirstlane((rem / n_ct) * CH);
-    const int64_t c0 = (int64_t)(rem % n_ct) * 64;
-    const int64_t c = c0 + lane;
-    const bool active = c < p.n_vecs;
+    const int64_t c0 = (int64_t)(rem % n_ct) * (64 * TILES);
+    const int64_t c = c0 + TILES * lane;
+    const bool active = c < p.n_vecs;                      // (TILES == 2: the launcher guarantees n_vecs % 128 == 0 -- every lane is active)
     const int r_beg = __builtin_amdgcn_readfirstlane(fill_ptr[o]);
     const int n_pad = __builtin_amdgcn_readfirstlane(fill_ptr[o + 1]) - r_beg;         // multiple of 8
 
-    f32x2 acc[NH][16];
+    f32x2 acc[NH][TILES][16];
 #pragma unroll
     for (int h = 0; h < NH; h++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[h][q] = f32x2{0.0f, 0.0f};
+        for (int t = 0; t < TILES; t++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[h][t][q] = f32x2{0.0f, 0.0f};
 
     if (n_pad > 0) {
         auto uni = [](const uint64_t v) {
@@ -1411,18 +1419,21 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         };
         auto batch_landed = [&](i32x16& R) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R)); };
         auto rec_of = [](const i32x16& R, const int k) { return i32x4{R[4 * k], R[4 * k + 1], R[4 * k + 2], R[4 * k + 3]}; };
-        float xa[PF], xb[PF], cfr[PF];
+        float xa[PF], cfr[PF];
+        xrow_t xb[PF];
         int flr[PF], tpr[PF];
 #pragma unroll
         for (int q = 0; q < PF; q++) {
-            xa[q] = xb[q] = 0.0f;
+            xa[q] = 0.0f;
+            xb[q] = xrow_t{};
             cfr[q] = 0.0f;
             flr[q] = tpr[q] = 0;
         }
         // the vector loads of one slot into ring position q (activation row segment; value row unless TREG); its coefficient, flags and tap ride along in scalar registers
-        auto fetch = [&](float& rb, float& ra, float& cf, int& fl, int& tp, const i32x4 r) {
+        auto fetch = [&](xrow_t& rb, float& ra, float& cf, int& fl, int& tp, const i32x4 r) {
             const uint32_t xoff = __umul24((uint32_t)r.x, ldx_v) + b_off;         // v_mad_u32_u24: row offset + lane offset in one vector instruction, nothing on the scalar unit
-            asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(xoff), "s"(x_ci));
+            if constexpr (TILES == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(rb) : "v"(xoff), "s"(x_ci));
+            else asm volatile("global_load_dword %0, %1, %2" : "=&v"(rb) : "v"(xoff), "s"(x_ci));
             if constexpr (!TREG) {
                 const uint64_t aaddr = abase + 4ull * (uint64_t)(ci_a + (uint32_t)r.y);
                 asm volatile("global_load_dword %0, %1, %2" : "=&v"(ra) : "v"(a_off), "s"(aaddr));
@@ -1442,7 +1453,7 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
                 }
             }
         };
-        auto landed = [&](float& rb, float& ra) {           // (one wait per slot: a wait that names two ring positions made the compiler copy one of them ahead of it -- a register still owned by its load)
+        auto landed = [&](xrow_t& rb, float& ra) {           // (one wait per slot: a wait that names two ring positions made the compiler copy one of them ahead of it -- a register still owned by its load)
             if constexpr (TREG) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rb) : "n"(LPS * (PF - 1)));
             else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(rb), "+v"(ra) : "n"(LPS * (PF - 1)));
         };
@@ -1467,6 +1478,9 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         f32x32 d;                                          // the products of the last finished column, not yet on the running sums
 #pragma unroll
         for (int q = 0; q < 32; q++) d[q] = 0.0f;
+        f32x32 d2;                                         // TILES == 2: the second result block (two matrix instructions in flight: a block's adds sit behind the NEXT block's matrix instruction)
+#pragma unroll
+        for (int q = 0; q < 32; q++) d2[q] = 0.0f;
         f32x32 zero;
 #pragma unroll
         for (int q = 0; q < 32; q++) zero[q] = 0.0f;
@@ -1479,32 +1493,57 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
         const int nb8 = n_pad >> 3;                        // loop bodies per input channel
         int body_left = 0;                                 // bodies until the walk enters the next input channel
         const float* a_ci = p.tapsT + co0 + (WIDE ? lane : (lane & 31));   // TREG: tapsT[0][ci][this lane's output channel] of the channel the walk enters next
-        auto consume = [&](float& rb, float& ra, const float cf, const int fl, const int tp) {
+        auto consume = [&](xrow_t& rb, float& ra, const float cf, const int fl, const int tp) {
             landed(rb, ra);
             const float av = TREG ? At[tp] : ra;           // (TREG: scalar index mode, no memory access)
             const float t = cf * av;                       // fl(coef * tap): the term as the reference stores it (coef == 1: the tap itself)
             arun = arun + t;                               // (the column's first term joins +0.0: the same value bit for bit but for the sign of a zero, which no sum that starts at +0.0 can show)
             if (fl & 2) {
-                auto add_d = [&](f32x2 (&a)[16]) {         // the products in d onto 32 x 64 running sums
-                    a[0] = a[0] + f32x2{d[0], d[1]};       // (compiler-visible: the hazard recognizer spaces this first reader of the matrix instruction's result; the rest follow it)
+                auto add_from = [&](f32x2 (&a)[16], const f32x32& dd) {      // the products in dd onto 32 x 64 running sums
+                    a[0] = a[0] + f32x2{dd[0], dd[1]};     // (compiler-visible: the hazard recognizer spaces this first reader of the matrix instruction's result; the rest follow it)
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 1; q < 16; q++) {
-                        const f32x2 p2 = {d[2 * q], d[2 * q + 1]};
+                        const f32x2 p2 = {dd[2 * q], dd[2 * q + 1]};
                         asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(a[q]) : "v"(p2));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                add_d(acc[NH - 1]);                        // pending: the previous column's (last) block
+                auto add_d = [&](f32x2 (&a)[16]) { add_from(a, d); };
+                if constexpr (TILES == 2) {
+                    // two column tiles: the column's stored value (formed ONCE) multiplies both -- 2 (4) matrix instructions per stored column for the same slot bookkeeping.
+                    // Result blocks alternate between d and d2: a block's 16 adds are issued behind the matrix instruction of the NEXT block, the last block's stay pending.
+                    float a_lo = arun, a_hi = arun;
+                    if constexpr (WIDE) {
+                        const unsigned ab = __builtin_bit_cast(unsigned, arun);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(ab, ab, false, false);
+                        const unsigned lo_b = sw[0], hi_b = sw[1];
+                        a_lo = __builtin_bit_cast(float, lo_b);
+                        a_hi = __builtin_bit_cast(float, hi_b);
+                    }
+                    const float rb0 = rb.x, rb1 = rb.y;
+                    add_from(acc[NH - 1][1], d2);          // pending: the previous column's last block
+                    d = __builtin_amdgcn_mfma_f32_32x32x1f32(a_lo, rb0, zero, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_32x32x1f32(a_lo, rb1, zero, 0, 0, 0);
+                    add_from(acc[0][0], d);
+                    if constexpr (WIDE) {
+                        d = __builtin_amdgcn_mfma_f32_32x32x1f32(a_hi, rb0, zero, 0, 0, 0);
+                        add_from(acc[0][1], d2);
+                        d2 = __builtin_amdgcn_mfma_f32_32x32x1f32(a_hi, rb1, zero, 0, 0, 0);
+                        add_from(acc[1][0], d);
+                    }
+                } else {
+                add_d(acc[NH - 1][0]);                     // pending: the previous column's (last) block
                 if constexpr (WIDE) {
                     const unsigned ab = __builtin_bit_cast(unsigned, arun);
                     const auto sw = __builtin_amdgcn_permlane32_swap(ab, ab, false, false);     // [0]: lanes 0-31 of arun in both halves, [1]: lanes 32-63 in both halves
                     const unsigned lo_b = sw[0], hi_b = sw[1];
                     d = __builtin_amdgcn_mfma_f32_32x32x1f32(__builtin_bit_cast(float, lo_b), rb, zero, 0, 0, 0);
-                    add_d(acc[0]);                         // channels 0-31: behind their own matrix instruction (the compiler spaces it; other wavefronts fill the gap)
+                    add_d(acc[0][0]);                      // channels 0-31: behind their own matrix instruction (the compiler spaces it; other wavefronts fill the gap)
                     d = __builtin_amdgcn_mfma_f32_32x32x1f32(__builtin_bit_cast(float, hi_b), rb, zero, 0, 0, 0);
                 } else {
                     d = __builtin_amdgcn_mfma_f32_32x32x1f32(arun, rb, zero, 0, 0, 0);
+                }
                 }
                 arun = 0.0f;
             }
@@ -1548,22 +1587,30 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
             batch_landed(R0);
         }
         // the products still pending; everything in flight lands (re-loads of valid rows, never used)
+        if constexpr (TILES == 2) {
 #pragma unroll
-        for (int q = 0; q < 16; q++) acc[NH - 1][q] = acc[NH - 1][q] + f32x2{d[2 * q], d[2 * q + 1]};
+            for (int q = 0; q < 16; q++) acc[NH - 1][1][q] = acc[NH - 1][1][q] + f32x2{d2[2 * q], d2[2 * q + 1]};
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[NH - 1][0][q] = acc[NH - 1][0][q] + f32x2{d[2 * q], d[2 * q + 1]};
+        }
         asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
         for (int q = 0; q < PF; q++) asm volatile("" : "+v"(xb[q]), "+v"(xa[q]));
     }
     // epilogue: bias column last (separate multiply and add, skipped where the stored entry is absent), ReLU, store.
-    // D layout: register 16 * blk + r of lane l = (channel 8 * (r / 4) + 4 * (l / 32) + r % 4, column 32 * blk + l % 32).
+    // D layout: register 16 * blk + r of lane l = (channel 8 * (r / 4) + 4 * (l / 32) + r % 4, B lane 32 * blk + l % 32); B lane j carries column c0 + j (one tile) or
+    // columns c0 + 2 j + t of tile t (two tiles: a lane's two columns are adjacent in memory).
     const int half = lane >> 5;
-    const int64_t colo = c0 + (lane & 31);
-    float xl[2] = {0.0f, 0.0f};
-    if (p.lastcol) {
+    const int64_t colo = c0 + TILES * (lane & 31);
+    float xl[2][TILES];
 #pragma unroll
-        for (int blk = 0; blk < 2; blk++)
-            if (colo + 32 * blk < p.n_vecs) xl[blk] = p.X[p.last_in_row * p.ldx + colo + 32 * blk];
-    }
+    for (int blk = 0; blk < 2; blk++)
+#pragma unroll
+        for (int t = 0; t < TILES; t++) {
+            xl[blk][t] = 0.0f;
+            if (p.lastcol && colo + TILES * 32 * blk + t < p.n_vecs) xl[blk][t] = p.X[p.last_in_row * p.ldx + colo + TILES * 32 * blk + t];
+        }
 #pragma unroll
     for (int h = 0; h < NH; h++) {
 #pragma unroll
@@ -1574,15 +1621,22 @@ __global__ __launch_bounds__(256, 2) void convtaps_exact_fill_kernel(ConvArgs p,
                 const float lc = p.lastcol ? p.lastcol[row] : 0.0f;
 #pragma unroll
                 for (int blk = 0; blk < 2; blk++) {
-                    const int64_t cc = colo + 32 * blk;
-                    if (cc < p.n_vecs) {
-                        float v = acc[h][(16 * blk + r) / 2][(16 * blk + r) % 2];
+                    float vv[TILES];
+#pragma unroll
+                    for (int t = 0; t < TILES; t++) {
+                        float v = acc[h][t][(16 * blk + r) / 2][(16 * blk + r) % 2];
                         if (lc != 0.0f) {
-                            const float bp = lc * xl[blk];
+                            const float bp = lc * xl[blk][t];
                             v = v + bp;
                         }
                         if (p.relu) v = (v < 0.0f) ? 0.0f : v;
-                        p.Y[row * p.ldy + cc] = v;
+                        vv[t] = v;
+                    }
+                    const int64_t cc = colo + TILES * 32 * blk;
+                    if constexpr (TILES == 2) {
+                        *reinterpret_cast<f32x2*>(p.Y + row * p.ldy + cc) = f32x2{vv[0], vv[1]};       // (n_vecs % 128 == 0, ldy even, Y 8-byte aligned: the launcher's conditions)
+                    } else {
+                        if (cc < p.n_vecs) p.Y[row * p.ldy + cc] = vv[0];
                     }
                 }
             }
@@ -2223,17 +2277,28 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
         else if (pipe && A.unit_coef) KN_LAUNCH("convtaps_exact_pipe_kernel<8>", (convtaps_exact_pipe_kernel<8>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (pipe) KN_LAUNCH("convtaps_exact_pipe_kernel<8,coef>", (convtaps_exact_pipe_kernel<8, true>), dim3((unsigned)grid), dim3(256), 0, s, a, n_cob, n_rb);
         else if (fill) {
-            // 64 output channels per wavefront (the slot bookkeeping once per 64 channels) when that still leaves every SIMD its three wavefronts, else 32
-            const int n_ctf = (int)((n_vecs + 63) / 64);
-            const bool wide = A.ntaps <= 16 && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * n_ctf >= 3 * 1024;
+            // 64 output channels per wavefront (the slot bookkeeping once per 64 channels) when that still leaves every SIMD its three wavefronts, else 32;
+            // two 64-column tiles per wavefront (the bookkeeping once per 128 columns) on batches of whole 128-column tiles when that still leaves every SIMD its two
+            // wavefronts (the two-tile forms hold 128 + 64 result registers: two wavefronts per SIMD).  Tuning::no_fill_tiles2 keeps one tile (parity tests' side-by-side).
+            const bool t2_ok = A.ntaps <= 16 && n_vecs % 128 == 0 && ldx % 2 == 0 && ldy % 2 == 0 && ((uintptr_t)x) % 8 == 0 && ((uintptr_t)y) % 8 == 0 && !A.tune.no_fill_tiles2;
+            const int64_t n_ct2 = n_vecs / 128;
+            const bool wide1 = A.ntaps <= 16 && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * ((n_vecs + 63) / 64) >= 3 * 1024;
+            const bool wide2 = t2_ok && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * n_ct2 >= 2 * 1024;
+            const bool narrow2 = t2_ok && !wide2 && !wide1 && (int64_t)a.n_pix * ((A.Cout + 31) / 32) * n_ct2 >= 2 * 1024;      // (64 channels x one tile is the same work per wavefront: kept where it qualifies)
+            const bool tiles2 = wide2 || narrow2;
+            const int n_ctf = tiles2 ? (int)n_ct2 : (int)((n_vecs + 63) / 64);
+            const bool wide = tiles2 ? wide2 : wide1;
             const int n_cc = (int)((A.Cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
             const int64_t n_wg = ((int64_t)a.n_pix * n_cc * n_ctf + 3) / 4;
             KN_REQUIRE(n_wg + 8 < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "grid too large for the filled-in order-preserving kernel");
-            const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? (wide ? "<taps in registers, 64 channels per wavefront>" : "<taps in registers>") : "") +
+            const std::string d = std::string("convtaps_exact_fill_kernel") + (A.ntaps <= 16 ? (wide ? "<taps in registers, 64 channels per wavefront" : "<taps in registers") : "") +
+                                  (A.ntaps <= 16 ? (tiles2 ? ", two column tiles per wavefront>" : ">") : "") +
                                   " (stored values formed per lane, products on the matrix pipe, " + std::to_string(A.fill_n) + " slot records)";
             const dim3 gridf((unsigned)(((n_wg + 7) / 8) * 8));
             const FillRec* rec = reinterpret_cast<const FillRec*>(A.fill_rec);
-            if (wide) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, true>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            if (tiles2 && wide) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, true, 2>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            else if (tiles2) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, false, 2>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
+            else if (wide) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, true>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
             else if (A.ntaps <= 16) KN_LAUNCH(d, (convtaps_exact_fill_kernel<16, false>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
             else KN_LAUNCH(d, (convtaps_exact_fill_kernel<0, false>), gridf, dim3(256), 0, s, a, A.fill_ptr, rec, n_cc, n_ctf, n_wg);
         }

@@ -137,6 +137,7 @@ struct Tuning {
     int mf_nrb = 1;           // KN_MF_NRB=1|2|3      32-row blocks per chunk of the matrix-pipe grouped kernel
     int table_nrb = 0;        // KN_TABLE_NRB=1|2|3   32-channel blocks per workgroup of the table kernel (0: the rule)
     int no_fill_exact = 0;    // KN_NO_FILL_EXACT=1   filled-in conv operators (> 64 slots per pixel, or several slots on one (output, input) pixel pair) under KN_FLAG_EXACT: the generic kernel instead of convtaps_exact_fill_kernel
+    int no_fill_tiles2 = 0;   // KN_NO_FILL_TILES2=1  ... on batches of whole 128-column tiles: one 64-column tile per wavefront instead of two
     // ---- diagnostic build only ----
     int occ = 0;              // KN_OCC               workgroups per CU cap of the 128 x 128 conv-taps launch (0: the rule)
     int no_tail_split = 0;    // KN_NO_TAIL_SPLIT

@@ -312,8 +312,18 @@ class KeyedLayer(nn.Module):
         ye_win = None
         if isinstance(W, ksp.Conv2dTiledMatrix) and self.ALLOW_SPLIT and W.split_capable(n):
             ye_win = W.torchdot(xt[:, win], relu=relu, exact=True)
-            ys = W.torchdot(xt, relu=relu, exact='split')
-            (ratio_s, meas_s, tol_s, dmax_s) = gate(ys[:, win], ye_win)
+            try:
+                ys = W.torchdot(xt, relu=relu, exact='split')
+                (ratio_s, meas_s, tol_s, dmax_s) = gate(ys[:, win], ye_win)
+            except (torch.cuda.OutOfMemoryError, _capi.KeynetHipError) as e:
+                # the candidate needs a resident spatial CSR, a second operator and the intermediate (several ranks on one device, a smaller device): not offered then --
+                # the fused kernels below need nothing beyond the operator that is already resident (round-5 advisor finding: this used to abort the first forward)
+                if isinstance(e, _capi.KeynetHipError) and 'memory' not in str(e).lower():
+                    raise
+                _log.warning('keynet_amd: %s: the split application does not fit this device now (%s); deciding between the fused kernels', self._repr, str(e)[:120])
+                W._op_split = None
+                torch.cuda.empty_cache()
+                (ys, ratio_s) = (None, float('inf'))
             if ratio_s <= 0.5 and (bound <= FLOAT_KEY_ATOL or ratio_s <= 0.25):
                 self._exact = 'split'
                 self._contract_record = dict(layer=self._repr, decided='split', max_abs_rowsum=asum, max_abs_x=xmax, max_abs_y=float(ys.abs().max()), tol=tol_s, bound=bound,

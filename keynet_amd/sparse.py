@@ -666,7 +666,12 @@ class Conv2dTiledMatrix(TiledMatrix):
         has_last = self._taps['lastcol'] is not None
         n = int(xd.shape[1])
         zrows = Cin * nt * HoWo + (1 if has_last else 0)
-        win = max(1, min(n, int(self.SPLIT_Z_BYTES // (4 * zrows))))
+        cap = self.SPLIT_Z_BYTES
+        with torch.cuda.device(xd.device):
+            (free_b, _) = torch.cuda.mem_get_info()
+            free_b += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()       # what the caching allocator holds but does not use is available too
+        cap = min(cap, max(free_b - 4 * self.shape[0] * n, 0) // 2)                      # the intermediate takes at most half of what is left beside the output block
+        win = max(1, min(n, int(cap // (4 * zrows))))
         if win < n and win >= 64:
             win -= win % (128 if win >= 128 else 64)      # whole tiles of the matrix-core kernel per window
         y = torch.empty((self.shape[0], n), dtype=torch.float32, device=xd.device)

@@ -488,34 +488,38 @@ class KeyedModel(object):
                     rescreen=bool(self.RESCREEN and os.environ.get('KN_NO_RESCREEN') != '1' and any(r['screened'] for r in rows)),
                     recalibrations=int(self.__dict__.get('_recalibrations', 0)))
 
-    _LEVEL = {'bf16x3': 0, 'split': 1, False: 2, True: 3}       # how conservative a decided contract is (sync_contract keeps the maximum over ranks)
+    _LEVEL = {'bf16x3': 0, 'split': 1, False: 2, True: 3}       # codes of a decided contract on the wire (sync_contract); only True (the reference's order) outranks the others
 
     def sync_contract(self, group=None):
         """COLLECTIVE (every rank of `group` must call it, the same number of times): make the calibration decisions of replicated key-nets
         agree.  Each rank decides a layer's contract on the batches IT sees, so one rank may keep a layer on the matrix cores that another
-        rank's larger activations moved to the reference's order; replicas would then no longer be bit-identical.  One all-reduce(MAX) of a
-        small integer per keyed layer: the most conservative decision wins everywhere.  Returns the names of the layers this rank changed
-        (the caller recomputes its current batch when the list is not empty: keynet_amd.dist.sharded_forward does).  Layers still 'auto'
-        (no forward yet) are left alone.  A no-op without an initialised process group."""
+        rank's larger activations moved to the reference's order; replicas would then no longer be bit-identical.  One all-reduce(MAX) of two
+        small integers per keyed layer (the largest and the smallest decided code).  Rule: a layer every deciding rank runs under the SAME
+        contract keeps it; any disagreement ends in the reference's order on every rank -- an exact decision anywhere wins, and two different
+        re-ordering contracts ('split' on one rank, the fused matrix-core kernel on another) are not ordered by conservativeness: a rank's
+        calibration measured ITS kernel on ITS batch only, so neither record covers the other kernel (round-5 advisor finding; until then the
+        ranks moved to the larger code and kept the old record).  Returns the names of the layers this rank changed (the caller recomputes its
+        current batch when the list is not empty: keynet_amd.dist.sharded_forward does).  Layers still 'auto' (no forward yet) are left alone.
+        A no-op without an initialised process group."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return []
         named = [(n, c) for (n, c) in self._keynet.named_children() if isinstance(c, klayer.KeyedLayer)]
         mine = [self._LEVEL.get(getattr(c, '_exact', True), -1) if getattr(c, '_exact', True) != 'auto' else -1 for (_, c) in named]
         dev = torch.device('cpu') if dist.get_backend(group) == 'gloo' else torch.device('cuda', torch.cuda.current_device())
-        t = torch.tensor(mine, dtype=torch.int32, device=dev)
+        t = torch.tensor([mine, [(-m if m >= 0 else -99) for m in mine]], dtype=torch.int32, device=dev)     # row 1: MAX of the negated codes = the smallest decided code
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        agreed = t.tolist()
+        (hi, lo) = (t[0].tolist(), [-v for v in t[1].tolist()])
         changed = []
-        back = {v: k for (k, v) in self._LEVEL.items()}
-        for ((n, c), m, a) in zip(named, mine, agreed):
-            if m >= 0 and a > m:
-                rec = dict(getattr(c, '_contract_record', None) or {})
-                rec.update(decided=klayer.contract_name(back[a]), reason='another rank\'s batch needed the more conservative contract (KeyedModel.sync_contract)')
-                if back[a] is True:
-                    rec.pop('max_abs_x', None)          # nothing left to screen: the reference's order holds for any input
-                (c._exact, c._contract_record) = (back[a], rec)
-                changed.append(n)
+        for ((n, c), m, a, b) in zip(named, mine, hi, lo):
+            if m < 0 or a == b or m == self._LEVEL[True]:
+                continue                                # undecided here / every deciding rank agrees / already in the reference's order
+            rec = dict(getattr(c, '_contract_record', None) or {})
+            rec.update(decided='exact', reason=('another rank\'s batch needed the reference\'s order' if a == self._LEVEL[True] else
+                                                'ranks calibrated onto different re-ordering kernels: no rank\'s record covers the other\'s') + ' (KeyedModel.sync_contract)')
+            rec.pop('max_abs_x', None)                  # nothing left to screen: the reference's order holds for any input
+            (c._exact, c._contract_record) = (True, rec)
+            changed.append(n)
         if changed:
             self.__dict__.pop('_overlap_plans', None)
             self.__dict__.pop('_chain_ops', None)

@@ -95,3 +95,52 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['config']['global_batch'] == 2 * r['config']['images_per_gpu'] and r['value'] > 0 and r['parity']['ok']
+
+
+def _bench(args, extra_env=None, timeout=900):
+    env = dict(os.environ, KN_BENCH_SHARE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _shm_archives():
+    return sorted(n for n in os.listdir('/dev/shm') if n.startswith('keynet_bench')) if os.path.isdir('/dev/shm') else []
+
+
+def test_bench_eight_ranks_share_one_keying_of_a_tiled_vgg():
+    """cfg5's control flow with cfg5's KIND of key-net (21 keyed layers of VGG-16, tiled conv operators; reduced width so that the tier stays short -- the full-size
+    8-rank run is profiles/r06_vgg16_bench_8ranks_one_gpu.json): rank 0 keys ONCE, seven ranks load its anonymous archive (benchlegs/shared.py), every rank uploads and
+    runs its shard on the matrix cores under the calibrated contract, one all-gather per step.  The line validates itself: backend, ranks seen, bytes gathered per rank,
+    the gather's own time, slowest / fastest rank, every shard bit-equal to its rank's local forward and the LAST rank's shard recomputed on rank 0 bit-equal
+    (= loaded operators == keyed operators)."""
+    before = _shm_archives()
+    p = _bench(['--gpus', '8', '--workload', 'vgg16-slice', '--batch', '16', '--steps', '2', '--warmup', '1', '--layer-iters', '1', '--no-cpu-baseline'])
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    r = json.loads(lines[0])
+    c = r['collective']
+    assert r['n_gpus'] == 8 and r['config']['global_batch'] == 128 and r['value'] > 0 and r['parity']['ok'] and r['scaling'] == 'weak'
+    assert c['backend'] == 'gloo' and c['ranks_seen'] == 8 and sorted(x[0] for x in c['ranks']) == list(range(8))
+    assert c['bytes_per_rank'] == 16 * 10 * 4 and c['gather_ms'] > 0
+    assert 0 < c['rank_images_per_s']['min'] <= c['rank_images_per_s']['max']
+    assert c['every_rank_shard_bit_equal_to_its_local_forward'] is True and c['peer_shard_recomputed_on_rank0'] == {'peer_rank': 7, 'bit_equal': True}
+    assert p.stderr.count('loaded rank 0\'s keyed net') == 7 and 'keying locally' not in p.stderr      # seven loaders, nobody fell back to its own keying
+    assert _shm_archives() == before
+
+
+def test_bench_rank_dying_before_the_barrier_fails_the_job_and_leaves_no_archive():
+    """A loader dies holding rank 0's archive, before the barrier (KN_BENCH_TEST_DIE_BEFORE_BARRIER: test-only).  The job must end non-zero -- no line, no hang, no rank
+    re-executed -- and nothing may be left in /dev/shm: the archive is an anonymous file (it never had a name), so there is nothing a killed rank 0 would have to clean up."""
+    import time
+    before = _shm_archives()
+    t0 = time.time()
+    p = _bench(['--gpus', '4', '--workload', 'vgg16-slice', '--batch', '8', '--steps', '1', '--warmup', '0', '--layer-iters', '1', '--no-cpu-baseline'],
+               extra_env={'KN_BENCH_TEST_DIE_BEFORE_BARRIER': '2'}, timeout=600)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert time.time() - t0 < 300
+    assert _shm_archives() == before
+    assert p.stderr.count('keyed vgg16-slice on the host') == 1                # one keying: nobody restarted

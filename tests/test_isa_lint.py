@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, 'keynet_amd', 'csrc')
 
 PIPELINED = {
     'kn_conv.hip': [r'_ZN2kn26convtaps_exact_pipe_kernel', r'_ZN2kn20convtaps_mfma_kernelILi\d+ELi\d+ELi16ELi\dELi\dELi2E',
-                    (r'_ZN2kn26convtaps_exact_fill_kernel', r'global_load_dword (v\d+), v\d+, s\[')],      # (pattern, what ITS asm-issued loads look like)
+                    (r'_ZN2kn26convtaps_exact_fill_kernel', r'global_load_dword(?:x2)? (v\d+|v\[\d+:\d+\]), v\d+, s\[')],      # (pattern, what ITS asm-issued loads look like; two column tiles: 8-byte loads)
     'kn_csr.hip': [r'_ZN2kn21csr_group_pipe_kernel'],
     'kn_csr_mfma.hip': [r'_ZN2kn21csr_group_mfma_kernel', r'_ZN2kn23csr_group_mfma16_kernel'],
 }
@@ -141,7 +141,7 @@ def test_no_use_of_a_scalar_register_owned_by_a_scalar_load_in_flight(tmp_path):
     looks for.  Between every such load and the next lgkmcnt(0) nothing may read or write its destination registers."""
     s = _isa('kn_conv.hip', tmp_path)
     names = re.findall(r'^(_ZN2kn26convtaps_exact_fill_kernel[^\n:]*):', s, re.M)
-    assert len(names) == 3, names                                # (taps in registers: 64 and 32 channels per wavefront; one value-row load per slot)
+    assert len(names) == 5, names                                # (taps in registers: 64 and 32 channels per wavefront, each with one and two column tiles; one value-row load per slot)
     for name in names:
         body = s[s.index(name + ':'):]
         body = body[:body.index('.Lfunc_end')]

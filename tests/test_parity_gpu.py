@@ -1339,22 +1339,27 @@ def test_convtaps_slot_groups_beyond_64_slots(Cin, Cout, H, k, n_vecs, unit):
     assert close_conditioned(yg.T, ref.T, (M.shape, M.indptr, M.indices, M.data), X.T)
 
 
-@pytest.mark.parametrize('Cin,Cout,H,k,n_vecs,unit,has_last', [
-    (4, 32, 8, 3, 64, False, True),        # several taps on one (output, input) pixel pair, float coefficients: 9 - 14 slots per pixel, one 64-column tile
-    (3, 40, 8, 3, 100, False, True),       # Cout not a multiple of 32 (second channel block half empty), ragged column tile
-    (5, 64, 10, 9, 64, True, True),        # 81 slots per pixel (two and a bit record batches of 8 per 16), unit coefficients, no pair hit twice
-    (2, 33, 10, 9, 256, False, False),     # > 64 slots AND duplicate pairs, four column tiles, no bias column
-    (6, 96, 6, 5, 1, False, True),         # one batch column
-    (16, 128, 6, 3, 192, False, True),     # VGG-like channel counts, three column tiles
-    (2, 128, 28, 3, 128, False, True),     # enough work for the 64-channels-per-wavefront form (784 pixels x 2 channel blocks x 2 column tiles)
-    (3, 96, 28, 3, 100, False, False),     # ... with a half-empty second channel block, a ragged column tile and no bias column
+@pytest.mark.parametrize('Cin,Cout,H,k,n_vecs,unit,has_last,form', [
+    (4, 32, 8, 3, 64, False, True, '<taps in registers>'),        # several taps on one (output, input) pixel pair, float coefficients: 9 - 14 slots per pixel, one 64-column tile
+    (3, 40, 8, 3, 100, False, True, '<taps in registers>'),       # Cout not a multiple of 32 (second channel block half empty), ragged column tile
+    (5, 64, 10, 9, 64, True, True, ''),                           # 81 taps (one value-row load per slot), 81 slots per pixel (two and a bit record batches of 8 per 16), unit coefficients, no pair hit twice
+    (2, 33, 10, 9, 256, False, False, ''),                        # > 64 slots AND duplicate pairs, four column tiles, no bias column
+    (6, 96, 6, 5, 1, False, True, ''),                            # one batch column (25 taps)
+    (16, 128, 6, 3, 192, False, True, '<taps in registers>'),     # VGG-like channel counts, three column tiles
+    (2, 128, 28, 3, 128, False, True, '<taps in registers, 64 channels per wavefront>'),     # enough work for the 64-channels-per-wavefront form (784 pixels x 2 channel blocks x 2 column tiles)
+    (3, 96, 28, 3, 100, False, False, '<taps in registers, 64 channels per wavefront>'),     # ... with a half-empty second channel block, a ragged column tile and no bias column
+    (2, 128, 28, 3, 256, False, True, '<taps in registers, 64 channels per wavefront, two column tiles per wavefront>'),       # round 6: 64 channels x 128 columns per wavefront (784 x 2 x 2 wavefronts)
+    (3, 96, 28, 3, 384, False, False, '<taps in registers, 64 channels per wavefront, two column tiles per wavefront>'),       # ... half-empty second channel block, three 128-column tiles, no bias column
+    (3, 32, 28, 3, 384, False, True, '<taps in registers, two column tiles per wavefront>'),                                  # 32 channels x 128 columns per wavefront (one channel block: the 64-channel form does not apply)
+    (2, 24, 30, 3, 512, False, True, '<taps in registers, two column tiles per wavefront>'),                                  # ... a partial channel block, four 128-column tiles
 ])
-def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has_last):
+def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has_last, form):
     """Filled-in operators in the reference's order (the reference's doubly-stochastic VGG-16, test/test_keynet.py:116-129: 500 - 5 400 slots per
     output pixel, a pixel pair hit by several taps = ONE stored non-zero whose value is the f32 sum of its terms in entry order): convtaps_exact_fill_kernel
     -- stored values formed once per wavefront, products on the matrix pipe, sums on the vector ALU -- is bit-equal to the oracle on the whole expansion
     (scipy's COO -> CSR sums the duplicates in the same order) and to the generic order-preserving kernel (KN_NO_FILL_EXACT=1, a fresh handle), ReLU on and off,
-    and through a column window of a wider block."""
+    and through a column window of a wider block.  Round 6: the forms with TWO 64-column tiles per wavefront (batches of whole 128-column tiles) -- bit-equal to the
+    oracle and to the one-tile form of the same operator (KN_NO_FILL_TILES2=1, a fresh handle)."""
     import os
     rng = np.random.RandomState(3 * Cin + Cout + k + n_vecs)
     W = _random_convtaps(rng, Cin, Cout, H, k, 1, unit, has_last)
@@ -1365,8 +1370,9 @@ def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has
     assert dups == (not unit) and (dups or slots > 64), (dups, slots)
     with torch.cuda.device(dev()):
         plan = W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
-    assert 'convtaps_exact_fill_kernel' in plan and ('64 channels per wavefront' in plan) == (H == 28), plan
-    wide = n_vecs + 37
+    assert 'convtaps_exact_fill_kernel' + form + ' (' in plan, plan
+    wide = n_vecs + (37 if n_vecs % 128 else 0)                      # (the two-tile forms need an even leading dimension: their window test keeps ldx = n_vecs + 128)
+    wide = wide if n_vecs % 128 else n_vecs + 128
     X = rng.randn(W.shape[1], wide).astype(np.float32)
     if has_last:
         X[-1] = 1.0
@@ -1378,12 +1384,32 @@ def test_convtaps_exact_fill_kernel_vs_oracle(Cin, Cout, H, k, n_vecs, unit, has
         r = np.maximum(ref, 0) if relu else ref
         ye = W.torchdot(xd[:, :n_vecs].contiguous(), relu=relu, exact=True).cpu().numpy()
         assert np.array_equal(ye, r[:, :n_vecs]), (relu, np.abs(ye - r[:, :n_vecs]).max())
-    # a column window of the wider block through the C ABI (ldx = ldy = wide, window at column 5)
+    # a column window of the wider block through the C ABI (ldx = ldy = wide; window at column 5 -- or, for the two-tile forms, at column 64: 8-byte aligned rows)
+    w0 = 5 if n_vecs % 128 else 64
     yw = torch.full((W.shape[0], wide), -7.0, dtype=torch.float32, device=dev())
     with torch.cuda.device(dev()):
-        W._device_op(dev()).spmm(xd.data_ptr() + 4 * 5, wide, n_vecs, yw.data_ptr() + 4 * 5, wide, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        if 'two column tiles' in form:
+            assert 'two column tiles' in W._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT, ldx=wide, ldy=wide)
+        W._device_op(dev()).spmm(xd.data_ptr() + 4 * w0, wide, n_vecs, yw.data_ptr() + 4 * w0, wide, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
     yw = yw.cpu().numpy()
-    assert np.array_equal(yw[:, 5:5 + n_vecs], ref[:, 5:5 + n_vecs]) and np.all(yw[:, :5] == -7.0) and np.all(yw[:, 5 + n_vecs:] == -7.0)
+    assert np.array_equal(yw[:, w0:w0 + n_vecs], ref[:, w0:w0 + n_vecs]) and np.all(yw[:, :w0] == -7.0) and np.all(yw[:, w0 + n_vecs:] == -7.0)
+    if 'two column tiles' in form:
+        # an odd window start (4-byte aligned rows only): the dispatch must fall back to one tile per wavefront, same bits
+        yo = torch.full((W.shape[0], wide), -7.0, dtype=torch.float32, device=dev())
+        with torch.cuda.device(dev()):
+            W._device_op(dev()).spmm(xd.data_ptr() + 4 * 5, wide, n_vecs, yo.data_ptr() + 4 * 5, wide, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(yo.cpu().numpy()[:, 5:5 + n_vecs], ref[:, 5:5 + n_vecs])
+        os.environ['KN_NO_FILL_TILES2'] = '1'
+        try:
+            W1 = copy.deepcopy(W)
+            W1._op = None
+            with torch.cuda.device(dev()):
+                p1 = W1._device_op(dev()).plan(n_vecs, _capi.KN_FLAG_EXACT)
+            y1 = W1.torchdot(xd[:, :n_vecs].contiguous(), exact=True).cpu().numpy()
+        finally:
+            del os.environ['KN_NO_FILL_TILES2']
+        assert 'convtaps_exact_fill_kernel' in p1 and 'two column tiles' not in p1 and 'no_fill_tiles2=1' in p1, p1
+        assert np.array_equal(y1, ref[:, :n_vecs])
     os.environ['KN_NO_FILL_EXACT'] = '1'
     try:
         Wg = copy.deepcopy(W)
