@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define KN_ABI_VERSION 3
+#define KN_ABI_VERSION 4
 
 enum kn_status {
     KN_OK = 0,
@@ -181,6 +181,14 @@ int kn_spmm(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
  * any other handle: float32 operators return float32. */
 int kn_spmm_f64(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs,
                 double* y_dev, int64_t ldy, uint32_t flags, void* stream);
+
+/* The same operator applied to n_planes independent activation blocks in ONE launch per kernel: block p is X_p = x_dev + p * x_plane_stride (floats), its result
+ * Y_p = y_dev + p * y_plane_stride.  Bit-identical to n_planes kn_spmm calls (same kernels, grid dimension y = plane).  No reference counterpart as a call -- the reference
+ * applies the fused operator (keynet/sparse.py:603-612); this is what the split application of a FILLED-IN conv needs (keynet_amd/sparse.py: the spatial matrix of all taps
+ * applied to every input channel's plane, 64 .. 512 planes per layer -- one launch instead of one per plane).  float32 CSR handles whose rows are pattern groups / loose rows
+ * only; KN_ERR_UNSUPPORTED otherwise (the caller loops over kn_spmm).  Always the stored order (KN_FLAG_EXACT is implied for CSR operators); KN_FLAG_RELU is honoured. */
+int kn_spmm_planes(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t x_plane_stride, int64_t n_planes, int64_t n_vecs,
+                   float* y_dev, int64_t ldy, int64_t y_plane_stride, uint32_t flags, void* stream);
 
 /* kn_spmm that additionally raises *y_absmax_dev (device f32, caller-initialised, e.g. to 0) to max |Y[r, b]| over the block it wrote,
  * stream-ordered.  No reference counterpart: the reference applies ONE arithmetic on every call (keynet/sparse.py:488-492), so its 1e-5

@@ -16,11 +16,11 @@ KN_OK = 0
 KN_FLAG_RELU = 1
 KN_FLAG_EXACT = 2
 KN_FLAG_BF16X3 = 4
-KN_ABI_VERSION = 3
+KN_ABI_VERSION = 4
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_csr_create_f64', 'kn_dtype_bits', 'kn_export_csr_f64', 'kn_spmm_f64', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
+           'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_planes', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -71,6 +71,7 @@ def lib():
         L.kn_spmm.argtypes = [p, p, i64, i64, p, i64, u32, p]
         L.kn_spmm_plan.argtypes = [p, i64, i64, i64, u32, p, i64]
         L.kn_spmm_screen.argtypes = [p, p, i64, i64, p, i64, u32, p, p]
+        L.kn_spmm_planes.argtypes = [p, p, i64, i64, i64, i64, p, i64, i64, u32, p]
         L.kn_absmax.argtypes = [p, i64, i64, i64, p, p]
         L.kn_reserve_workspace.argtypes = [p, i64, p]
         L.kn_relu.argtypes = [p, i64, i64, i64, p]
@@ -246,6 +247,14 @@ class Operator(object):
 
     def reserve_workspace(self, n_vecs, stream):
         check(lib().kn_reserve_workspace(self._h, int(n_vecs), stream))
+
+    def spmm_planes(self, x_ptr, ldx, x_plane_stride, n_planes, n_vecs, y_ptr, ldy, y_plane_stride, flags, stream):
+        """kn_spmm_planes: this CSR operator on n_planes activation blocks in one launch per kernel; False when the operator needs the per-plane loop (KN_ERR_UNSUPPORTED)."""
+        rc = lib().kn_spmm_planes(self._h, x_ptr, int(ldx), int(x_plane_stride), int(n_planes), int(n_vecs), y_ptr, int(ldy), int(y_plane_stride), int(flags), stream)
+        if rc == 6:                                          # KN_ERR_UNSUPPORTED
+            return False
+        check(rc)
+        return True
 
     def plan(self, n_vecs, flags=0, ldx=None, ldy=None):
         """The kernels kn_spmm would launch for this batch width / flags (kn_spmm_plan): '; '-separated descriptions."""

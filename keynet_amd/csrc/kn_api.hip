@@ -958,6 +958,25 @@ int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vec
     return guarded([&]() -> int { return spmm_impl(h, x_dev, ldx, n_vecs, y_dev, ldy, flags, y_absmax_dev, stream); });
 }
 
+int kn_spmm_planes(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t x_plane_stride, int64_t n_planes, int64_t n_vecs, float* y_dev, int64_t ldy, int64_t y_plane_stride,
+                   uint32_t flags, void* stream) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    KN_REQUIRE(h->kind == KIND_CSR, KN_ERR_UNSUPPORTED, "kn_spmm_planes: a float32 CSR operator only (loop over kn_spmm for the others)");
+    if (plan_sink() == nullptr) KN_HOST_ONLY_GUARD();
+    KN_REQUIRE(n_vecs >= 0 && n_vecs < INT32_MAX && n_planes >= 0, KN_ERR_INVALID, "n_vecs / n_planes out of range");
+    if (n_vecs == 0 || n_planes == 0 || h->rows == 0) return KN_OK;
+    KN_REQUIRE(x_dev && y_dev, KN_ERR_INVALID, "NULL activation pointer");
+    KN_REQUIRE(ldx >= n_vecs && ldy >= n_vecs, KN_ERR_SHAPE, "leading dimension smaller than n_vecs");
+    KN_REQUIRE(n_planes == 1 || (x_plane_stride >= h->cols * ldx && y_plane_stride >= h->rows * ldy), KN_ERR_SHAPE, "planes overlap (stride smaller than one block)");
+    KN_REQUIRE(x_dev != y_dev, KN_ERR_INVALID, "x and y alias");
+    int cur = -1;
+    KN_HIP(hipGetDevice(&cur));
+    KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one (create it under the device of x)");
+    return csr_spmm_planes(h->csr, x_dev, ldx, x_plane_stride, n_planes, n_vecs, y_dev, ldy, y_plane_stride, flags, reinterpret_cast<hipStream_t>(stream));
+    });
+}
+
 int kn_spmm_f64(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vecs, double* y_dev, int64_t ldy, uint32_t flags, void* stream) {
     return guarded([&]() -> int {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");

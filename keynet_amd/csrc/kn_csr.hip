@@ -72,7 +72,10 @@ template <int VEC>
 __global__ __launch_bounds__(256) void csr_rows_kernel(const int32_t* __restrict__ row_list, int64_t n_rows,
                                                        const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                        const float* __restrict__ data, const float* __restrict__ X, int64_t ldx,
-                                                       float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu, int64_t n_rb, float* absmax = nullptr) {
+                                                       float* __restrict__ Y, int64_t ldy, int64_t n_vecs, int relu, int64_t n_rb, float* absmax = nullptr,
+                                                       int64_t x_plane = 0, int64_t y_plane = 0) {
+    X += (int64_t)blockIdx.y * x_plane;          // kn_spmm_planes: grid dimension y = independent activation blocks under ONE operator (a single launch: y = 0, nothing moves)
+    Y += (int64_t)blockIdx.y * y_plane;
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
     int64_t item;
     if (!decode_item(n_ct * n_rb, item)) return;
@@ -218,7 +221,9 @@ __global__ __launch_bounds__(256) void csr_group_kernel(int64_t n_work, const in
                                                         const int32_t* __restrict__ grp_rowptr, const int32_t* __restrict__ grp_rows,
                                                         const int64_t* __restrict__ grp_valptr, const float* __restrict__ grp_vals,
                                                         const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
-                                                        int64_t n_vecs, int relu, int64_t n_rb) {
+                                                        int64_t n_vecs, int relu, int64_t n_rb, int64_t x_plane = 0, int64_t y_plane = 0) {
+    X += (int64_t)blockIdx.y * x_plane;          // (kn_spmm_planes, as in csr_rows_kernel)
+    Y += (int64_t)blockIdx.y * y_plane;
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
     int64_t item;
     if (!decode_item(n_ct * n_rb, item)) return;
@@ -953,22 +958,27 @@ __global__ __launch_bounds__(256) void csr_group_pipe_kernel(int64_t n_work, con
     }
 }
 
+struct Planes {            // kn_spmm_planes: n independent activation blocks (block p at x + p * x_stride floats, its result at y + p * y_stride) under one operator, one launch per kernel
+    int64_t n = 1, x_stride = 0, y_stride = 0;
+};
+
 template <int VEC, int RBK>
-static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s, float* absmax = nullptr) {
+static int launch_csr(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, int relu, hipStream_t s, float* absmax = nullptr, const Planes pl = Planes()) {
     const int64_t n_ct = (n_vecs + 64 * VEC - 1) / (64 * VEC);
+    const std::string np = pl.n > 1 ? (" x " + std::to_string(pl.n) + " planes in one launch") : std::string();
     if (A.n_work > 0) {
         const int64_t n_rb = (A.n_work * (RB / RBK) + WAVES - 1) / WAVES;
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
-        KN_LAUNCH("csr_group_kernel<vec=" + std::to_string(VEC) + ",rows=" + std::to_string(RBK) + ">", (csr_group_kernel<VEC, RBK>), dim3((unsigned)grid), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
-                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb);
+        KN_LAUNCH("csr_group_kernel<vec=" + std::to_string(VEC) + ",rows=" + std::to_string(RBK) + ">" + np, (csr_group_kernel<VEC, RBK>), dim3((unsigned)grid, (unsigned)pl.n), dim3(256), 0, s, A.n_work, A.work_grp, A.work_r0, A.grp_colptr, A.grp_cols,
+                           A.grp_rowptr, A.grp_rows, A.grp_valptr, A.grp_vals, x, ldx, y, ldy, n_vecs, relu, n_rb, pl.x_stride, pl.y_stride);
     }
     if (A.n_loose > 0) {
         const int64_t n_rb = (A.n_loose + WAVES - 1) / WAVES;
         const int64_t items = n_ct * n_rb;
         const int64_t grid = ((items + 7) / 8) * 8;
-        KN_LAUNCH("csr_rows_kernel<vec=" + std::to_string(VEC) + ">", csr_rows_kernel<VEC>, dim3((unsigned)grid), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
-                           y, ldy, n_vecs, relu, n_rb, absmax);
+        KN_LAUNCH("csr_rows_kernel<vec=" + std::to_string(VEC) + ">" + np, csr_rows_kernel<VEC>, dim3((unsigned)grid, (unsigned)pl.n), dim3(256), 0, s, A.loose_rows, A.n_loose, A.indptr, A.indices, A.data, x, ldx,
+                           y, ldy, n_vecs, relu, n_rb, absmax, pl.x_stride, pl.y_stride);
     }
     KN_HIP(hipGetLastError());
     return KN_OK;
@@ -1143,6 +1153,39 @@ static int csr_spmm_groups(const CsrDev& A, const float* x, int64_t ldx, int64_t
         return launch_csr<1, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
     }
     return launch_csr<1, 1>(A, x, ldx, n_vecs, y, ldy, relu, s, rows_only_absmax);
+}
+
+// kn_spmm_planes: Y_p = W . X_p for p = 0 .. n_planes - 1 with ONE launch per kernel (grid dimension y = plane) instead of n_planes launches.  What it is for: the split
+// application of a filled-in conv (keynet_amd/sparse.py: the spatial CSR of all taps applied to every input channel's plane -- 64 .. 512 planes, each a launch too small to fill
+// the chip).  Same kernels, same instruction sequence per output element: bit-identical to n_planes kn_spmm calls.  Operators that need more than the grouped / loose-row
+// kernels (big groups, long rows, matrix-pipe groups, patched rows) are refused with KN_ERR_UNSUPPORTED: the caller loops over kn_spmm then.
+int csr_spmm_planes(const CsrDev& A, const float* x, int64_t ldx, int64_t x_stride, int64_t n_planes, int64_t n_vecs, float* y, int64_t ldy, int64_t y_stride, uint32_t flags, hipStream_t s) {
+    KN_REQUIRE(A.n_big == 0 && A.n_long == 0 && A.n_patch == 0, KN_ERR_UNSUPPORTED, "kn_spmm_planes: operator has big / long / patched rows (loop over kn_spmm)");
+    KN_REQUIRE(n_planes >= 1 && n_planes <= 65535, KN_ERR_UNSUPPORTED, "kn_spmm_planes: 1 .. 65535 planes");
+    const int relu = (flags & KN_FLAG_RELU) ? 1 : 0;
+    Planes pl;
+    pl.n = n_planes;
+    pl.x_stride = x_stride;
+    pl.y_stride = y_stride;
+    auto aligned = [&](int v) {
+        return (n_vecs % v == 0) && (ldx % v == 0) && (ldy % v == 0) && (x_stride % v == 0) && (y_stride % v == 0) && (((uintptr_t)x) % (4 * v) == 0) && (((uintptr_t)y) % (4 * v) == 0) &&
+               (v == 1 || 4 * n_vecs >= 3 * ((n_vecs + 64 * v - 1) / (64 * v)) * (64 * v));
+    };
+    const int64_t loose = (A.n_loose + WAVES - 1) / WAVES * WAVES;
+    auto waves = [&](int v, int rbk) { return (A.n_work * (RB / rbk) + loose) * ((n_vecs + 64 * v - 1) / (64 * v)) * n_planes; };
+    constexpr int64_t ENOUGH = 2048;
+#define KN_TRY(V, R) \
+    if (aligned(V) && waves(V, R) >= ENOUGH) return launch_csr<V, R>(A, x, ldx, n_vecs, y, ldy, relu, s, nullptr, pl);
+    KN_TRY(4, 8)
+    KN_TRY(2, 8)
+    KN_TRY(4, 2)
+    KN_TRY(1, 8)
+    KN_TRY(2, 2)
+    KN_TRY(1, 2)
+#undef KN_TRY
+    if (aligned(4) && n_vecs >= 256) return launch_csr<4, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, nullptr, pl);
+    if (aligned(2) && n_vecs >= 128) return launch_csr<2, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, nullptr, pl);
+    return launch_csr<1, 8>(A, x, ldx, n_vecs, y, ldy, relu, s, nullptr, pl);
 }
 
 }  // namespace kn

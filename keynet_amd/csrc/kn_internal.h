@@ -297,6 +297,7 @@ struct kn_operator {
 namespace kn {
 // kernels (kn_csr.hip / kn_conv.hip / kn_elementwise.hip)
 int csr_build_groups(kn_operator* h, const int32_t* indptr, const int32_t* indices, const float* data);
+int csr_spmm_planes(const CsrDev& A, const float* x, int64_t ldx, int64_t x_stride, int64_t n_planes, int64_t n_vecs, float* y, int64_t ldy, int64_t y_stride, uint32_t flags, hipStream_t s);
 int csr_spmm(const CsrDev& A, const float* x, int64_t ldx, int64_t n_vecs, float* y, int64_t ldy, uint32_t flags, hipStream_t s, float* absmax = nullptr,
              bool* absmax_fused = nullptr);
 template <typename TOUT>

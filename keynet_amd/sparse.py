@@ -683,8 +683,11 @@ class Conv2dTiledMatrix(TiledMatrix):
             for c0 in range(0, n, win):
                 w = min(win, n - c0)
                 ldz = int(z.shape[1])
-                for ci in range(Cin):             # the spatial CSR on every input channel's plane (rows ci * HiWi ..) -> Z rows ci * ntaps * HoWo ..
-                    opK.spmm(xd.data_ptr() + 4 * (ci * HiWi * n + c0), n, w, z.data_ptr() + 4 * ci * nt * HoWo * ldz, ldz, _capi.KN_FLAG_EXACT, st)
+                # the spatial CSR on every input channel's plane (rows ci * HiWi ..) -> Z rows ci * ntaps * HoWo ..: ONE launch over all planes (kn_spmm_planes, round 6:
+                # conv1_2 .. conv5_3 of the doubly-stochastic VGG-16 used to issue 64 .. 512 launches of 37 us each per layer and window), else plane by plane
+                if not opK.spmm_planes(xd.data_ptr() + 4 * c0, n, HiWi * n, Cin, w, z.data_ptr(), ldz, nt * HoWo * ldz, _capi.KN_FLAG_EXACT, st):
+                    for ci in range(Cin):
+                        opK.spmm(xd.data_ptr() + 4 * (ci * HiWi * n + c0), n, w, z.data_ptr() + 4 * ci * nt * HoWo * ldz, ldz, _capi.KN_FLAG_EXACT, st)
                 if has_last:
                     z[-1, :w].copy_(xd[-1, c0:c0 + w])
                 op2.spmm(z.data_ptr(), ldz, w, y.data_ptr() + 4 * c0, n, flags, st, absmax_ptr=None if absmax is None else absmax.data_ptr())

@@ -1490,6 +1490,54 @@ def _filled_in_convtaps(rng, Cin, Cout, H, fill, has_last=True, gentle=False):
     return ksp.Conv2dTiledMatrix.fromtaps((Cin, H, H), (Cout, H, H), taps, np.concatenate(eo), np.concatenate(ei), np.concatenate(et), np.concatenate(ec), lastcol)
 
 
+@pytest.mark.parametrize('n_vecs,n_planes,kind', [(64, 5, 'loose'), (256, 3, 'loose'), (128, 4, 'groups'), (100, 7, 'groups'), (64, 2, 'big')])
+def test_spmm_planes_is_n_spmm_calls_in_one_launch(n_vecs, n_planes, kind):
+    """kn_spmm_planes (round 6): one CSR operator on n activation blocks, grid dimension y = block -- bit-identical to n kn_spmm calls and to the oracle per block, ReLU on and off,
+    blocks that are column windows of a wider array (ldx > n_vecs) at plane strides larger than a block; an operator with a big pattern group is refused (the caller loops)."""
+    rng = np.random.RandomState(n_vecs + n_planes)
+    (m, n) = (700, 300)
+    if kind == 'loose':
+        M = scipy.sparse.random(m, n, density=0.03, format='csr', random_state=rng, dtype=np.float32)
+    elif kind == 'groups':                                        # rows in groups of 9 sharing one column sequence (the taps of one output pixel), plus loose rows
+        pats = [np.sort(rng.choice(n, size=rng.randint(5, 40), replace=False)).astype(np.int32) for _ in range(m // 9)]
+        lists = [pats[r // 9] if r // 9 < len(pats) and r % 9 < 8 else rng.choice(n, size=rng.randint(0, 12), replace=False).astype(np.int32) for r in range(m)]
+        indptr = np.concatenate(([0], np.cumsum([len(v) for v in lists]))).astype(np.int32)
+        indices = np.concatenate(lists).astype(np.int32)
+        M = scipy.sparse.csr_matrix((rng.randn(len(indices)).astype(np.float32), indices, indptr), shape=(m, n))
+    else:                                                         # a dense 300 x 2100 block: ONE big pattern group (>= 256 members, >= 2048 stored columns: a keyed Linear)
+        (m, n) = (300, 2100)
+        M = scipy.sparse.csr_matrix(rng.randn(m, n).astype(np.float32))
+    (ip, ix, dt) = (M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float32))
+    op = _capi.Operator.csr((m, n), ip, ix, dt)
+    ld = n_vecs + 32
+    (xs, ys) = (n * ld + 4 * ld, m * ld + 8 * ld)                  # plane strides (floats): blocks do not overlap, padding between them
+    X = rng.randn(n_planes * xs).astype(np.float32)
+    xd = torch.as_tensor(X).to(dev())
+    st = torch.cuda.current_stream().cuda_stream
+    for relu in (0, 1):
+        yd = torch.full((n_planes * ys,), -7.0, dtype=torch.float32, device=dev())
+        with torch.cuda.device(dev()):
+            ok = op.spmm_planes(xd.data_ptr() + 4 * 8, ld, xs, n_planes, n_vecs, yd.data_ptr() + 4 * 8, ld, ys, _capi.KN_FLAG_EXACT | relu, st)
+        if kind == 'big':
+            assert ok is False                                    # refused, nothing launched
+            assert bool((yd == -7.0).all())
+            return
+        assert ok is True
+        y = yd.cpu().numpy()
+        yl = torch.full((n_planes * ys,), -7.0, dtype=torch.float32, device=dev())
+        with torch.cuda.device(dev()):
+            for p in range(n_planes):
+                op.spmm(xd.data_ptr() + 4 * (p * xs + 8), ld, n_vecs, yl.data_ptr() + 4 * (p * ys + 8), ld, _capi.KN_FLAG_EXACT | relu, st)
+        assert np.array_equal(y, yl.cpu().numpy())                # incl. everything outside the windows: untouched
+        for p in range(n_planes):
+            Xp = X[p * xs:p * xs + n * ld].reshape(n, ld)[:, 8:8 + n_vecs]
+            ref = oracle.csr_matvecs((m, n), ip, ix, dt, np.ascontiguousarray(Xp))
+            ref = np.maximum(ref, 0) if relu else ref
+            got = y[p * ys:p * ys + m * ld].reshape(m, ld)
+            assert np.array_equal(got[:, 8:8 + n_vecs], ref), (p, relu)
+            assert np.all(got[:, :8] == -7.0) and np.all(got[:, 8 + n_vecs:] == -7.0)
+
+
 @pytest.mark.parametrize('Cin,Cout,H,fill,n_vecs,has_last', [(16, 64, 6, 5, 128, True), (3, 40, 8, 3, 100, True), (32, 128, 4, 6, 256, False)])
 def test_split_application_of_a_filled_in_conv(Cin, Cout, H, fill, n_vecs, has_last):
     """Conv2dTiledMatrix.torchdot(exact='split') (the reference's doubly-stochastic VGG-16): the factored operator sum_t F_t (x) K_t applied as

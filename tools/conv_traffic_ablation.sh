@@ -19,7 +19,8 @@ PY
 export KEYNET_HIP_LIB=/tmp/libkeynet_hip_abl.so
 B="--steps 2 --warmup 1 --layer-iters 1 --no-cpu-baseline --no-exact-leg --no-secondary"
 cd /tmp
-for V in "base" "KN_CONV_BALL=16" "KN_CONV_BALL=32" "KN_CONV_BALL=128" "KN_CONV_BALL=256" "KN_OCC=3" "KN_OCC=2"; do
+# VARIANTS="base" restricts the table to the shipped setting (the like-for-like row that roofline.traffic -- tools/pmc_forward.py -- must agree with)
+for V in ${VARIANTS:-base KN_CONV_BALL=16 KN_CONV_BALL=32 KN_CONV_BALL=128 KN_CONV_BALL=256 KN_OCC=3 KN_OCC=2}; do
   T=$(echo $V | tr '=' '_')
   if [ "$V" != "base" ]; then export $V; fi
   for C in FETCH_SIZE WRITE_SIZE; do
