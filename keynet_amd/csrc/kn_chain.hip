@@ -60,14 +60,18 @@ struct ChainLayerArg {
     int32_t rpl;                // output rows per lane: 1, or 2 (chain_rows_cl: two rows of one column pattern share every activation read)
     int32_t stage_off;          // float4 index of the LDS area the pool is staged in
     int32_t early;              // 1 = the pool is staged while the PREVIOUS layer runs (layer 0: with the input), 0 = at the start of this layer
+    int32_t seq_len;            // > 0: a SEQUENTIAL thin layer (chain_rows_thin_seq) -- the stored entries of the one column pattern all of these rows share; the
+    int32_t seq_base;           //      layer's input buffer (LDS byte offset seq_base) is laid out in that pattern's order by the layer before it
 };
 
 struct ChainArgs {
     ChainLayerArg L[CHAIN_MAX_LAYERS];
+    ChainLayerArg LX[CHAIN_MAX_LAYERS];                            // the rows of a sequential thin layer that do NOT share its main pattern (a keyed Linear's homogeneous row): general walk, own wavefronts
     const float* X;
     float* Y;
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
+    int32_t rot_mul;                                               // > 0: workgroup g walks a layer's slices rotated by (g * rot_mul) % n_slices (chain_load_meta)
 #ifdef KN_ABLATION
     unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries (tools/chain_stamps.sh), or null
     unsigned long long* wstamps;                                   // [workgroup][12 layers][16 wavefronts][40] inside the walks: 0-7 per walk, 8 + 4 * slice + k per slice
@@ -137,6 +141,11 @@ __device__ __forceinline__ float* chain_lds_base() {
 #define KN_CHAIN_DV 6           // value quads in flight per wavefront of the thin walk (a multiple of 6.  LeNet forward, same box: 6 -> 37.6 us, 12 -> 38.6 us with a few
                                 // spilled address registers, 18 spills the ring itself)
 #endif
+#ifndef KN_CHAIN_SEQ_COLS
+#define KN_CHAIN_SEQ_COLS 2     // batch columns per wavefront of the sequential thin walk: 2 = two wavefronts per slice (one per column pair: fewer vector instructions per wavefront, the
+                                // slice's value stream loaded twice), 4 = one wavefront per slice (the stream loaded once, 21 instead of 11 vector instructions per quad)
+#endif
+static constexpr int CHAIN_SEQ_WPS = KN_CHAIN_SEQ_COLS == 4 ? 1 : 2;      // wavefronts per slice of a sequential thin layer
 static constexpr int CHAIN_D = 4, CHAIN_NP = 2;       // ring depth / next-slice quads requested early (pattern walk, one row per lane)
 static constexpr int CHAIN_D_ROWS = 2;                // ... of the general walk (what takes it are short rows of unrelated patterns -- keyed pooling: 9 entries = 3 quads -- and it
                                                       // holds a column quad per value quad: the register budget of 16 wavefronts per CU is 128)
@@ -154,9 +163,16 @@ struct ChainPre {
 // lane + slice record of slice s for this lane; R = rows per lane of the layer's layout, POOL = columns are read from the pool staged in LDS at
 // float4 index pool4 (then coff is an LDS byte offset), else from memory
 template <int R, bool POOL>
-__device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int s, const int lane, const int pool4) {
+__device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int s, const int lane, const int pool4, const int rot = 0) {
     constexpr int RPS = 64;
-    s = s < L.n_slices ? s : L.n_slices - 1;                    // past the end: the last slice again (unused)
+    // rot: the workgroup's rotation of the layer's slice order (ChainArgs::rot_mul): workgroups that walk one operator in the same order keep asking the L2 for the same lines at
+    // the same time; rotated, the CUs of an XCD read different parts of it.  Which slice a wavefront takes when does not change any result.
+    if (s < L.n_slices) {
+        s += rot;
+        s = s >= L.n_slices ? s - L.n_slices : s;
+    } else {
+        s = L.n_slices - 1;                                      // past the end: the last slice again (unused)
+    }
     const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
     const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(s * RPS + lane));      // (uniform base + 32-bit offset: saddr form)
     ChainMeta m;
@@ -180,12 +196,12 @@ __device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
 template <bool ST, int PART>          // PART: 1 = the lane records, 2 = the first ring, 3 = both
-__device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
+__device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
     constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS;
     if (wave >= L.n_slices) return;
     if (PART & 1) {
-        pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0);
-        pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
+        pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0, rot);
+        pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0, rot);
     }
     if (!(PART & 2)) return;
     const char* const cols_b = reinterpret_cast<const char*>(L.cols);
@@ -198,7 +214,7 @@ __device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int
 }
 
 template <bool ST>
-__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
+__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws, const int rot = 0) {
     constexpr int RPS = 64;                    // rows per slice (wavefront)
     constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS, NP = CHAIN_NP;
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
@@ -227,7 +243,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     for (int s = wave; s < n_slices; s += NW) {
 #pragma unroll
         for (int i = 0; i < NP; i++) fetch(m1, i, cn[i], vn[i]);
-        const ChainMeta m2 = chain_load_meta<1, false>(L, s + 2 * NW, lane, 0);
+        const ChainMeta m2 = chain_load_meta<1, false>(L, s + 2 * NW, lane, 0, rot);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
         f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
         // activations of a quad are read from LDS one quad AHEAD of their use (x double buffer): with two wavefronts on a CU (a Linear) the
@@ -318,12 +334,12 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // the same LDS clocks now carry twice the arithmetic (conv2 12.0 -> see profiles/r05_lenet_chain_breakdown.txt).  Each row still sums its own stored
 // sequence serially, multiply then add: same bits.
 template <bool ST, int R, int PART>
-__device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
+__device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D;      // (R = 2: a quad is 32 bytes per lane -- the same bytes in flight with half the ring)
     if (wave >= L.n_slices) return;
     if (PART & 1) {
-        pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off);
-        pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
+        pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off, rot);
+        pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off, rot);
     }
     if (!(PART & 2)) return;
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
@@ -334,7 +350,7 @@ __device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const 
 }
 
 template <bool ST, int R>
-__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
+__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws, const int rot = 0) {
     constexpr int RPS = 64;
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D, NP = (R == 2) ? 1 : CHAIN_NP;
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
@@ -357,7 +373,7 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
         for (int i = 0; i < NP; i++)
 #pragma unroll
             for (int r = 0; r < R; r++) vn[i][r] = ldv(m1, i, r);
-        const ChainMeta m2 = chain_load_meta<R, true>(L, s + 2 * NW, lane, L.stage_off);
+        const ChainMeta m2 = chain_load_meta<R, true>(L, s + 2 * NW, lane, L.stage_off, rot);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
         f32x2 a01[R], a23[R];
 #pragma unroll
@@ -469,7 +485,8 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
 template <int DV, bool ST, int PART>
 __device__ __forceinline__ void chain_rows_thin_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int RPS = 64;
-    if (wave >= 2 * L.n_slices || !(PART & 1)) return;
+    const int wps = L.seq_len > 0 ? CHAIN_SEQ_WPS : 2;                            // wavefronts per slice
+    if (wave >= wps * L.n_slices || !(PART & 1)) return;
     const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
     const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
     const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(sl * RPS + lane));
@@ -531,24 +548,9 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     // (Measured and dropped, round 5: the quad's instructions in a hand-written order -- four products, then the four dependent adds with the quad's LDS reads
     // and value request between them -- changes nothing: 36.9-37.3 against 36.5 us per LeNet forward.  A wavefront ALONE on its SIMD pays ~9 clocks per vector
     // instruction whatever stands between them (tools/micro/dep_chain.hip: 20 instructions of a quad = 190 clocks), so fc1 costs 197 quads x 15 instructions.)
-#if defined(KN_ABLATION) && defined(KN_CHAIN_THIN_SEQ)
-    // DIAGNOSTIC BUILD ONLY, TIMING ONLY (the results are wrong): what the thin walk would cost if its input buffer were laid out in the layer's stored column order
-    // -- activations of quad k at (first entry) + 64 k bytes, read with constant offsets (ds_read2_b64), no column quads at all: 11 vector instructions per quad instead of 15.
-    const uint32_t seq0 = (uint32_t)ldc(0).x;
-    uint32_t seq_trip = seq0;
-    auto xread_seq = [&](const uint32_t a, f32x2 (&xx)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) xx[e] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + a + 16u * (uint32_t)e);
-    };
-#endif
     auto quad = [&](const int i, const int k, const bool refill) {          // i: ring slot (static), k: quad index
-#if defined(KN_ABLATION) && defined(KN_CHAIN_THIN_SEQ)
-        xread_seq(seq_trip + 64u * (uint32_t)(i + 2), x[(i + 2) % 3]);
-        if (i == DV - 1) seq_trip += 64u * DV;
-#else
         cq[(i + 1) & 1] = ldc(k + 3);
         xread(cq[i & 1], x[(i + 2) % 3]);
-#endif
         __builtin_amdgcn_sched_barrier(0);                 // the next quads' LDS reads in flight under this quad's arithmetic
         macs(x[i % 3], v[i]);
         if (refill) v[i] = ldv(k + DV);
@@ -573,6 +575,100 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     }
 }
 
+// A thin layer walked SEQUENTIALLY (round 6).  All rows of a keyed nn.Linear (but the homogeneous one) share ONE stored column sequence P.  When the layer BEFORE it writes its
+// output row f to LDS position pos(f) with pos(P_k) = k -- its lane records carry positions instead of rows, nothing else changes -- this layer's k-th activation sits at
+// seq_base + 16 k: no column quads, no staged pool, and a quad's four activations are two ds_read2_b64 at constant offsets (the compiler merges the constant-offset reads):
+// 11 vector instructions per quad instead of 15 in a walk that is bound by one wavefront's instruction issue.  Same values, same order, same separate multiply / add per
+// row: bit-identical.  The row's last 1-3 entries (len % 4) are a tail of their own: a padded quad would multiply whatever lies behind the pattern by 0.0f (NaN if it is not
+// finite).  Rows that do not share P run on other wavefronts through the general walk (ChainArgs::LX).
+template <int DV, bool ST>
+__device__ __forceinline__ void chain_rows_thin_seq(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
+    constexpr int RPS = 64, WPS = CHAIN_SEQ_WPS, NC = 4 / WPS;                   // NC batch columns per wavefront
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef float xw_t __attribute__((ext_vector_type(NC)));                     // a wavefront's share of an activation word
+    if (wave >= WPS * L.n_slices) return;
+    const int half = (WPS == 2 && wave >= L.n_slices) ? 1 : 0;
+    const int nq = L.seq_len >> 2, rem = L.seq_len & 3;                           // full quads, tail entries (wave-uniform)
+    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const uint32_t voff = pre.m0.voff;
+    auto ldv = [&](const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + voff); };
+    uint32_t xtrip = (uint32_t)L.seq_base + 8u * (uint32_t)half;                  // LDS byte address of the trip's first activation word (+ 64 per quad, + 16 per entry)
+    auto xread = [&](const uint32_t a, xw_t (&x)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[e] = *reinterpret_cast<const xw_t*>(reinterpret_cast<const char*>(chain_lds) + a + 16u * (uint32_t)e);
+    };
+    f32x2 acc[NC / 2];
+#pragma unroll
+    for (int j = 0; j < NC / 2; j++) acc[j] = f32x2{0.f, 0.f};
+    auto mac1 = [&](const xw_t& xe, const f32x2 vp, const int e) {              // one stored entry: the NC columns' products, then their adds (separate rounding)
+#pragma unroll
+        for (int j = 0; j < NC / 2; j++) {
+            const f32x2 xj = {xe[2 * j], xe[2 * j + 1]};
+            const f32x2 p = (e & 1) ? chain_mul_hi(xj, vp) : chain_mul_lo(xj, vp);
+            acc[j] = acc[j] + p;
+        }
+    };
+    auto macs = [&](const xw_t (&x)[4], const f32x4& vq) {
+        const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
+#pragma unroll
+        for (int e = 0; e < 4; e++) mac1(x[e], vp[e >> 1], e);
+    };
+    f32x4 v[DV];
+#pragma unroll
+    for (int i = 0; i < DV; i++) v[i] = ldv(i);
+    __builtin_amdgcn_sched_barrier(0);
+    CHAIN_WSTAMP(2, true);
+    xw_t x[3][4];                                                                 // activations two quads ahead of the arithmetic, values DV quads ahead (as in chain_rows_thin)
+    xread(xtrip, x[0]);
+    xread(xtrip + 64u, x[1]);
+    static_assert(DV % 3 == 0, "the activation buffers rotate with period 3");
+    auto quad = [&](const int i, const int k, const bool refill) {
+        xread(xtrip + 64u * (uint32_t)(i + 2), x[(i + 2) % 3]);                   // quad k + 2 (reads past the pattern's end land inside LDS and are never used)
+        __builtin_amdgcn_sched_barrier(0);
+        macs(x[i % 3], v[i]);
+        if (refill) v[i] = ldv(k + DV);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int q = 0;
+    for (; q + DV <= nq; q += DV) {
+#pragma unroll
+        for (int i = 0; i < DV; i++) quad(i, q + i, true);
+        xtrip += 64u * DV;
+    }
+    int done = 0;                                                                 // quads of the last, partial trip
+#pragma unroll
+    for (int i = 0; i < DV - 1; i++) {
+        if (q + i < nq) {
+            quad(i, q + i, false);
+            done = i + 1;
+        }
+    }
+    if (rem) {                                                                    // the pattern's last 1-3 entries: quad nq, entries e < rem only
+        // (slot `done` of the ring holds quad nq's values: requested DV quads ago, or by the prologue; its activations were read two quads ago into x[done % 3] -- all three
+        // buffers are indexed statically below)
+#pragma unroll
+        for (int i = 0; i < DV; i++) {
+            if (i == done) {
+                const f32x2 vp[2] = {f32x2{v[i].x, v[i].y}, f32x2{v[i].z, v[i].w}};
+#pragma unroll
+                for (int e = 0; e < 3; e++)
+                    if (e < rem) mac1(x[i % 3][e], vp[e >> 1], e);
+            }
+        }
+    }
+    if (pre.m0.row >= 0) {
+#pragma unroll
+        for (int j = 0; j < NC / 2; j++) {
+            f32x2 t = acc[j];
+            if (L.relu) {                                      // torch relu: NaN stays NaN
+                t.x = (t.x < 0.0f) ? 0.0f : t.x;
+                t.y = (t.y < 0.0f) ? 0.0f : t.y;
+            }
+            *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * pre.m0.row + 2 * (half + j)]) = t;
+        }
+    }
+}
+
 // Column pool of a layer into its LDS staging area: a pattern layer's quads as they are, a thin layer's twice (the second copy with + 8 bytes on every
 // entry: the address of the wavefront's column pair).  `q` = a quad already loaded from L.cols + 4 * i.
 template <bool ST>
@@ -587,11 +683,11 @@ __device__ __forceinline__ void chain_stage_now(const ChainLayerArg& L, const in
 }
 
 template <bool ST, int PART>
-__device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
-    if (L.cols_quads > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST, PART>(L, wave, lane, pre);
-    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2, PART>(L, wave, lane, pre);
-    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1, PART>(L, wave, lane, pre);
-    else chain_rows_pre<ST, PART>(L, wave, lane, pre);
+__device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
+    if (L.cols_quads > 0 || L.seq_len > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST, PART>(L, wave, lane, pre);
+    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2, PART>(L, wave, lane, pre, rot);
+    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1, PART>(L, wave, lane, pre, rot);
+    else chain_rows_pre<ST, PART>(L, wave, lane, pre, rot);
 }
 
 template <bool ST>
@@ -651,12 +747,20 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
             chain_stage_now<ST>(L, tid);
             __syncthreads();
         }
-        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(L, wave, lane, pre);
-        if (KN_CHAIN_PRE == 2) chain_pre<ST, 2>(L, wave, lane, pre);            // (the lane records crossed the barrier; the ring is requested here)
-        if (L.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(L, out_off, wave, lane, pre, ws);
-        else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl<ST, 2>(L, out_off, wave, lane, pre, ws);
-        else if (L.cols_quads < 0) chain_rows_cl<ST, 1>(L, out_off, wave, lane, pre, ws);
-        else chain_rows<ST>(L, out_off, wave, lane, pre, ws);
+        // A sequential thin layer has two parts: wavefronts [0, CHAIN_SEQ_WPS n_slices) walk its main-pattern rows, the ones behind them its rows of other patterns (a keyed Linear's
+        // homogeneous row) as a general-walk layer of their own (a.LX[l]).  One dispatch below serves both: (W, w) = the layer record and wavefront index this wavefront works on.
+        const bool extra = L.seq_len > 0 && wave >= CHAIN_SEQ_WPS * L.n_slices;
+        const ChainLayerArg& W = extra ? a.LX[l] : L;
+        const int w = extra ? wave - CHAIN_SEQ_WPS * L.n_slices : wave;
+        // this workgroup's rotation of the slice order (0 with rot_mul = 0; never with operator words that crossed the barrier: KN_CHAIN_PRE builds)
+        const int rot = (KN_CHAIN_PRE == 0 && a.rot_mul > 0 && W.n_slices > 1) ? (int)(((uint32_t)grp * (uint32_t)a.rot_mul) % (uint32_t)W.n_slices) : 0;
+        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(W, w, lane, pre, rot);
+        if (KN_CHAIN_PRE == 2) chain_pre<ST, 2>(W, w, lane, pre);               // (the lane records crossed the barrier; the ring is requested here)
+        if (W.seq_len > 0) chain_rows_thin_seq<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
+        else if (W.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
+        else if (W.cols_quads < 0 && W.rpl == 2) chain_rows_cl<ST, 2>(W, out_off, w, lane, pre, ws, rot);
+        else if (W.cols_quads < 0) chain_rows_cl<ST, 1>(W, out_off, w, lane, pre, ws, rot);
+        else chain_rows<ST>(W, out_off, w, lane, pre, ws, rot);
         CHAIN_WSTAMP(6, false);
         if (stage_next) chain_stage_now<ST>(a.L[l + 1], tid);
         // the next layer's first operator words: on their way across the barrier.  (A fresh object per layer: what a wavefront without a slice, or a walk
@@ -704,42 +808,84 @@ static int chain_upload(ChainDev* c, const T** dst, const std::vector<T>& h) {
     return KN_OK;
 }
 
+// column patterns of a layer: rows with an identical stored column sequence share one id (pat[r]); pat_rep[id] = a row that carries it
+static void chain_patterns(int64_t rows, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix, std::vector<int32_t>& pat, std::vector<int32_t>& pat_rep) {
+    pat.assign((size_t)rows, -1);
+    pat_rep.clear();
+    std::unordered_map<uint64_t, std::vector<int32_t>> buckets;
+    for (int64_t r = 0; r < rows; r++) {
+        const int32_t s = ip[(size_t)r], e = ip[(size_t)r + 1];
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)(e - s);
+        for (int32_t k = s; k < e; k++) {
+            h ^= (uint64_t)(uint32_t)ix[(size_t)k];
+            h *= 1099511628211ull;
+        }
+        auto& cand = buckets[h];
+        int32_t found = -1;
+        for (int32_t g : cand) {
+            const int32_t rs = ip[(size_t)pat_rep[(size_t)g]], re = ip[(size_t)pat_rep[(size_t)g] + 1];
+            if (re - rs == e - s && (e == s || std::memcmp(ix.data() + rs, ix.data() + s, sizeof(int32_t) * (size_t)(e - s)) == 0)) {
+                found = g;
+                break;
+            }
+        }
+        if (found < 0) {
+            found = (int32_t)pat_rep.size();
+            pat_rep.push_back((int32_t)r);
+            cand.push_back(found);
+        }
+        pat[(size_t)r] = found;
+    }
+}
+
+// Does a layer take the SEQUENTIAL thin walk (chain_rows_thin_seq)?  A keyed nn.Linear behind another layer: (nearly) all rows share ONE stored column sequence P of distinct
+// columns, few enough rows for two wavefronts per slice, a walk long enough to be bound by one wavefront's instruction issue.  pos = where the layer BEFORE it must put each of
+// its output rows: pos[P_k] = k, the features P does not name behind them.
+struct ChainSeqPlan {
+    bool on = false;
+    int32_t len = 0;
+    std::vector<int32_t> pos, main_rows, other_rows;
+};
+static ChainSeqPlan chain_plan_seq(int64_t l, int64_t rows, int64_t cols, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix, const Tuning& tune) {
+    ChainSeqPlan P;
+    if (l == 0 || rows == 0 || tune.chain_no_seq) return P;              // (layer 0 reads the caller's input: staged as it is)
+    std::vector<int32_t> pat, pat_rep;
+    chain_patterns(rows, ip, ix, pat, pat_rep);
+    std::vector<int64_t> cnt(pat_rep.size(), 0);
+    for (int64_t r = 0; r < rows; r++) cnt[(size_t)pat[(size_t)r]]++;
+    const int32_t g = (int32_t)(std::max_element(cnt.begin(), cnt.end()) - cnt.begin());
+    const int32_t rs = ip[(size_t)pat_rep[(size_t)g]], len = ip[(size_t)pat_rep[(size_t)g] + 1] - rs;
+    const int64_t n_main = cnt[(size_t)g], n_other = rows - n_main;
+    const int64_t ns = (n_main + 63) / 64;
+    if (len < 64 || n_other > 64 || CHAIN_SEQ_WPS * ns + (n_other > 0 ? 1 : 0) > CHAIN_THREADS / 64 || ns > 8) return P;
+    std::vector<int32_t> pos((size_t)cols, -1);
+    for (int32_t k = 0; k < len; k++) {
+        const int32_t col = ix[(size_t)(rs + k)];
+        if (col < 0 || col >= cols || pos[(size_t)col] >= 0) return P;   // a column named twice (non-canonical rows may): no sequential layout
+        pos[(size_t)col] = k;
+    }
+    int32_t nxt = len;
+    for (int64_t col = 0; col < cols; col++)
+        if (pos[(size_t)col] < 0) pos[(size_t)col] = nxt++;
+    P.on = true;
+    P.len = len;
+    P.pos = std::move(pos);
+    for (int64_t r = 0; r < rows; r++) (pat[(size_t)r] == g ? P.main_rows : P.other_rows).push_back((int32_t)r);
+    return P;
+}
+
 // one layer: CSR (host copy, stored order) -> the sliced layout above.  in_base / zero_byte: LDS byte offsets of the layer's input buffer
-// and of the always-zero feature.
-static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_t cols, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix,
-                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte, const Tuning& tune, const size_t room_quads) {
+// and of the always-zero feature.  in_pos / out_pos (or null): where the layer's input features / output rows sit inside their LDS buffers when the layer itself / the layer
+// behind it is walked sequentially (chain_plan_seq).
+static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, int64_t rows, int64_t cols, const std::vector<int32_t>& ip, const std::vector<int32_t>& ix,
+                             const std::vector<float>& dt, int relu, int32_t in_base, int32_t zero_byte, const Tuning& tune, const size_t room_quads,
+                             const ChainSeqPlan& plan, const std::vector<int32_t>* out_pos) {
     constexpr int RPS = 64;                      // room_quads: LDS left beside the activations, in 16-byte quads (what a staged column pool may take)
     (void)cols;
-    auto off = [&](int32_t col) { return in_base + 16 * col; };
-    // column patterns: rows with an identical stored column sequence share one copy
-    std::vector<int32_t> pat((size_t)rows, -1);
-    std::vector<int32_t> pat_rep;
-    {
-        std::unordered_map<uint64_t, std::vector<int32_t>> buckets;
-        for (int64_t r = 0; r < rows; r++) {
-            const int32_t s = ip[(size_t)r], e = ip[(size_t)r + 1];
-            uint64_t h = 1469598103934665603ull ^ (uint64_t)(e - s);
-            for (int32_t k = s; k < e; k++) {
-                h ^= (uint64_t)(uint32_t)ix[(size_t)k];
-                h *= 1099511628211ull;
-            }
-            auto& cand = buckets[h];
-            int32_t found = -1;
-            for (int32_t g : cand) {
-                const int32_t rs = ip[(size_t)pat_rep[(size_t)g]], re = ip[(size_t)pat_rep[(size_t)g] + 1];
-                if (re - rs == e - s && (e == s || std::memcmp(ix.data() + rs, ix.data() + s, sizeof(int32_t) * (size_t)(e - s)) == 0)) {
-                    found = g;
-                    break;
-                }
-            }
-            if (found < 0) {
-                found = (int32_t)pat_rep.size();
-                pat_rep.push_back((int32_t)r);
-                cand.push_back(found);
-            }
-            pat[(size_t)r] = found;
-        }
-    }
+    const std::vector<int32_t>* in_pos = plan.on ? &plan.pos : nullptr;
+    auto off = [&](int32_t col) { return in_base + 16 * (in_pos ? (*in_pos)[(size_t)col] : col); };
+    std::vector<int32_t> pat, pat_rep;
+    chain_patterns(rows, ip, ix, pat, pat_rep);
     struct Built {
         std::vector<float> vals;
         std::vector<int32_t> colpool, lane_meta, info;
@@ -749,10 +895,11 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         int longest = 0;
     };
     // R output rows per lane (R = 2: two rows of ONE column pattern; a pattern with an odd number of rows leaves one lane half empty)
-    auto build = [&](const int R) {
+    auto build = [&](const int R, const std::vector<int32_t>* subset = nullptr) {
         Built B;
         std::vector<int32_t> rows_sorted((size_t)rows);
         std::iota(rows_sorted.begin(), rows_sorted.end(), 0);
+        if (subset) rows_sorted = *subset;                       // (a sequential thin layer: its main-pattern rows and the others are laid out separately)
         std::stable_sort(rows_sorted.begin(), rows_sorted.end(), [&](int32_t x, int32_t y) {
             const int32_t lx = ip[(size_t)x + 1] - ip[(size_t)x], ly = ip[(size_t)y + 1] - ip[(size_t)y];
             if (lx != ly) return lx > ly;
@@ -882,6 +1029,46 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
         }
         return B;
     };
+    auto place = [&](Built& X) {                                  // lane records carry the LDS position of an output row (= the row itself unless the next layer is sequential)
+        if (!out_pos) return;
+        for (size_t o = 0; o + 3 < X.lane_meta.size(); o += 4)
+            for (int w : {0, 2})
+                if (X.lane_meta[o + (size_t)w] >= 0) X.lane_meta[o + (size_t)w] = (*out_pos)[(size_t)X.lane_meta[o + (size_t)w]];
+    };
+    auto upload_built = [&](ChainLayerArg& T, const Built& X) -> int {
+        int rc;
+        if ((rc = chain_upload(c, &T.vals, X.vals)) || (rc = chain_upload(c, &T.cols, X.colpool)) || (rc = chain_upload(c, &T.lane_meta, X.lane_meta)) ||
+            (rc = chain_upload(c, &T.slice_info, X.info)))
+            return rc;
+        return KN_OK;
+    };
+    std::memset(&LX, 0, sizeof(LX));
+    if (plan.on) {
+        // sequential thin layer: the rows of the main pattern in slices of their own (values only: their columns are implicit), the others as a general-walk layer
+        Built Bm = build(1, &plan.main_rows);
+        place(Bm);
+        L.n_slices = (int32_t)Bm.n_slices;
+        L.n_rows = (int32_t)rows;
+        L.relu = relu;
+        L.cols_quads = 0;
+        L.rpl = 1;
+        L.stage_off = 0;
+        L.early = 0;
+        L.seq_len = plan.len;
+        L.seq_base = in_base;
+        int rc = upload_built(L, Bm);
+        if (rc) return rc;
+        if (!plan.other_rows.empty()) {
+            Built Bx = build(1, &plan.other_rows);
+            place(Bx);
+            LX.n_slices = (int32_t)Bx.n_slices;
+            LX.n_rows = (int32_t)plan.other_rows.size();
+            LX.relu = relu;
+            LX.rpl = 1;
+            if ((rc = upload_built(LX, Bx))) return rc;
+        }
+        return KN_OK;
+    }
     Built B = build(1);
     // (chain_create drops either choice when the staging area does not fit beside the activations)
     int32_t cols_quads = (B.thin && B.longest >= 64) ? (int32_t)B.pool_quads : (B.all_shared && !tune.chain_no_cl) ? -(int32_t)B.pool_quads : 0;
@@ -905,6 +1092,7 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
             }
         }
     }
+    place(B);
     L.n_slices = (int32_t)B.n_slices;
     L.n_rows = (int32_t)rows;
     L.relu = relu;
@@ -912,11 +1100,9 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, int64_t rows, int64_
     L.rpl = rpl;
     L.stage_off = 0;
     L.early = 0;
-    int rc;
-    if ((rc = chain_upload(c, &L.vals, B.vals)) || (rc = chain_upload(c, &L.cols, B.colpool)) || (rc = chain_upload(c, &L.lane_meta, B.lane_meta)) ||
-        (rc = chain_upload(c, &L.slice_info, B.info)))
-        return rc;
-    return KN_OK;
+    L.seq_len = 0;
+    L.seq_base = 0;
+    return upload_built(L, B);
 }
 
 int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, ChainDev** out, int64_t* rows_out, int64_t* cols_out, int64_t* nnz_out) {
@@ -944,20 +1130,37 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
     }
     std::unique_ptr<ChainDev, void (*)(ChainDev*)> c(new ChainDev(), chain_free);
     std::memset(&c->args, 0, sizeof(ChainArgs));
+    // pass 1: the operators on the host, and which layers are walked sequentially (that decides the LDS order of the layer before them)
+    struct HostCsr {
+        std::vector<int32_t> ip, ix;
+        std::vector<float> dt;
+    };
+    std::vector<HostCsr> H((size_t)n_ops);
+    std::vector<ChainSeqPlan> plans((size_t)n_ops);
     for (int64_t l = 0; l < n_ops; l++) {
         const CsrDev& A = ops[l]->csr;
-        std::vector<int32_t> ip((size_t)A.rows + 1), ix((size_t)A.nnz);
-        std::vector<float> dt((size_t)A.nnz);
-        KN_HIP(hipMemcpy(ip.data(), A.indptr, sizeof(int32_t) * ip.size(), hipMemcpyDeviceToHost));
+        HostCsr& h = H[(size_t)l];
+        h.ip.resize((size_t)A.rows + 1);
+        h.ix.resize((size_t)A.nnz);
+        h.dt.resize((size_t)A.nnz);
+        KN_HIP(hipMemcpy(h.ip.data(), A.indptr, sizeof(int32_t) * h.ip.size(), hipMemcpyDeviceToHost));
         if (A.nnz > 0) {
-            KN_HIP(hipMemcpy(ix.data(), A.indices, sizeof(int32_t) * ix.size(), hipMemcpyDeviceToHost));
-            KN_HIP(hipMemcpy(dt.data(), A.data, sizeof(float) * dt.size(), hipMemcpyDeviceToHost));
+            KN_HIP(hipMemcpy(h.ix.data(), A.indices, sizeof(int32_t) * h.ix.size(), hipMemcpyDeviceToHost));
+            KN_HIP(hipMemcpy(h.dt.data(), A.data, sizeof(float) * h.dt.size(), hipMemcpyDeviceToHost));
         }
-        int rc = chain_build_layer(c.get(), c->args.L[l], A.rows, A.cols, ip, ix, dt, (flags && (flags[l] & KN_FLAG_RELU)) ? 1 : 0,
-                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])), A.tune, (CHAIN_LDS_BYTES - lds) / 16);
+        plans[(size_t)l] = chain_plan_seq(l, A.rows, A.cols, h.ip, h.ix, A.tune);
+    }
+    // pass 2: the layouts
+    for (int64_t l = 0; l < n_ops; l++) {
+        const CsrDev& A = ops[l]->csr;
+        const HostCsr& h = H[(size_t)l];
+        const std::vector<int32_t>* out_pos = (l + 1 < n_ops && plans[(size_t)l + 1].on) ? &plans[(size_t)l + 1].pos : nullptr;
+        int rc = chain_build_layer(c.get(), c->args.L[l], c->args.LX[l], A.rows, A.cols, h.ip, h.ix, h.dt, (flags && (flags[l] & KN_FLAG_RELU)) ? 1 : 0,
+                                   (int32_t)((l & 1) ? 16 * feat[0] : 0), (int32_t)(16 * (feat[0] + feat[1])), A.tune, (CHAIN_LDS_BYTES - lds) / 16, plans[(size_t)l], out_pos);
         if (rc) return rc;
     }
     c->args.n_layers = (int32_t)n_ops;
+    c->args.rot_mul = ops[0]->csr.tune.chain_rot;
     c->args.n_in = (int32_t)ops[0]->cols;
     c->args.n_out = (int32_t)ops[n_ops - 1]->rows;
     c->args.buf1_off = (int32_t)feat[0];
@@ -1018,14 +1221,15 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
         if (n_stamps > (size_t)grid * 16) a.wstamps = a.stamps + (size_t)grid * 16;
     }
 #endif
-    int n_thin = 0, n_cl = 0, n_rpl2 = 0, n_early = 0;
+    int n_thin = 0, n_cl = 0, n_rpl2 = 0, n_early = 0, n_seq = 0;
     for (int l = 0; l < a.n_layers; l++) {
-        n_thin += a.L[l].cols_quads > 0 ? 1 : 0;
+        n_seq += a.L[l].seq_len > 0 ? 1 : 0;
+        n_thin += (a.L[l].cols_quads > 0 || a.L[l].seq_len > 0) ? 1 : 0;
         n_cl += a.L[l].cols_quads < 0 ? 1 : 0;
         n_rpl2 += a.L[l].rpl == 2 ? 1 : 0;
         n_early += (a.L[l].cols_quads != 0 && a.L[l].early) ? 1 : 0;
     }
-    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk, " + std::to_string(n_cl) +
+    const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk -- " + std::to_string(n_seq) + " of them sequentially, " + std::to_string(n_cl) +
                           " with column patterns in LDS), " + std::to_string(n_rpl2) + " with two rows per lane, " + std::to_string(n_early) +
                           " column pools staged a layer early, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way

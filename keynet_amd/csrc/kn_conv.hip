@@ -2285,9 +2285,15 @@ int convtaps_spmm(const ConvTapsDev& A, int64_t rows, int64_t cols, const float*
             const bool wide1 = A.ntaps <= 16 && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * ((n_vecs + 63) / 64) >= 3 * 1024;
             const bool wide2 = t2_ok && A.Cout > 32 && (int64_t)a.n_pix * ((A.Cout + 63) / 64) * n_ct2 >= 2 * 1024;
             const bool narrow2 = t2_ok && !wide2 && !wide1 && (int64_t)a.n_pix * ((A.Cout + 31) / 32) * n_ct2 >= 2 * 1024;      // (64 channels x one tile is the same work per wavefront: kept where it qualifies)
-            const bool tiles2 = wide2 || narrow2;
+            bool tiles2 = wide2 || narrow2;
+            bool wide_sel = tiles2 ? wide2 : wide1;
+            if (A.tune.fill_form > 0 && A.ntaps <= 16) {             // (diagnostic build: force a form where the operands allow it -- tools/fill_bench.py)
+                const bool want2 = A.tune.fill_form >= 3 && t2_ok;
+                tiles2 = want2;
+                wide_sel = (A.tune.fill_form == 2 || A.tune.fill_form == 4) && A.Cout > 32;
+            }
             const int n_ctf = tiles2 ? (int)n_ct2 : (int)((n_vecs + 63) / 64);
-            const bool wide = tiles2 ? wide2 : wide1;
+            const bool wide = wide_sel;
             const int n_cc = (int)((A.Cout + (wide ? 63 : 31)) / (wide ? 64 : 32));
             const int64_t n_wg = ((int64_t)a.n_pix * n_cc * n_ctf + 3) / 4;
             KN_REQUIRE(n_wg + 8 < ((int64_t)1 << 31), KN_ERR_UNSUPPORTED, "grid too large for the filled-in order-preserving kernel");

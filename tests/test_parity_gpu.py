@@ -1145,20 +1145,38 @@ def test_whole_net_kernel_layout_choices_vs_oracle():
                     ref = np.where(ref < 0, np.float32(0), ref)              # torch relu: NaN stays NaN
         assert np.array_equal(yd.cpu().numpy(), ref, equal_nan=True)
 
+    def dense_plus(rows, cols, n_other):
+        """A keyed Linear as the reference stores it: `rows - n_other` rows sharing one permuted column sequence + n_other rows of their own (the homogeneous row ...)."""
+        (ip, ix, dt) = dense(rows - n_other, cols)
+        (ip, ix, dt) = (list(ip), list(ix), list(dt))
+        for _ in range(n_other):
+            c = rng.choice(cols, size=rng.randint(1, 4), replace=False)
+            ix.extend(int(v) for v in c)
+            dt.extend(rng.randn(len(c)).astype(np.float32))
+            ip.append(len(ix))
+        return (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+
+    # (round 6: a thin layer BEHIND another layer is walked sequentially -- the layer before it writes its output in the thin layer's stored column order)
     run([((645, 200), grouped(645, 200, 6, 11, 5), 1), ((130, 645), grouped(130, 645, 16, 50, 2), 0), ((70, 130), dense(70, 130), 1), ((10, 70), dense(10, 70), 0)],
-        '4 operators (2 on the thin walk, 2 with column patterns in LDS)')
+        '4 operators (2 on the thin walk -- 2 of them sequentially, 2 with column patterns in LDS)')
+    # the same with the rows a keyed Linear really has: a homogeneous row (and two more odd ones) beside the shared pattern, pattern lengths 4 k + 1 .. 4 k + 3 (a tail of
+    # 1-3 entries), a Linear of more than 64 main rows (two slices = four sequential wavefronts + one for the odd rows), Inf / NaN activations under the odd rows
+    run([((645, 200), grouped(645, 200, 6, 11, 5), 1), ((131, 645), grouped(131, 645, 16, 50, 2), 0), ((121, 131), dense_plus(121, 131, 1), 1), ((85, 121), dense_plus(85, 121, 3), 1),
+         ((11, 85), dense_plus(11, 85, 1), 0)], '5 operators (3 on the thin walk -- 3 of them sequentially, 2 with column patterns in LDS)')
+    # a Linear as the FIRST operator reads the caller's input as it is: the staged-pool thin walk; the one behind it is sequential
+    run([((70, 130), dense(70, 130), 1), ((10, 70), dense_plus(10, 70, 1), 0)], '2 operators (2 on the thin walk -- 1 of them sequentially, 0 with column patterns in LDS)')
     # 4200 + 4100 features of four columns = 133 KB of activations; 700 patterns of 28 quads = 314 KB: no room for the pool
     run([((4100, 4200), grouped(4100, 4200, 6, 110, 2), 1), ((64, 4100), grouped(64, 4100, 8, 9, 0), 0)],
-        '2 operators (0 on the thin walk, 1 with column patterns in LDS), 0 with two rows per lane')
+        '2 operators (0 on the thin walk -- 0 of them sequentially, 1 with column patterns in LDS), 0 with two rows per lane')
     # conv layers of >= 1024 rows whose patterns hold several rows each: TWO rows per lane (they share every activation read).  Groups of 6 (three
     # lanes per pattern), of 11 (an odd row left over per pattern: a half-empty lane), of 16; 1 .. 9 unrelated rows at the end (lanes of their own, among
     # them the homogeneous row); row lengths that are not a multiple of four; a pooling layer (general walk) and a Linear (thin walk) behind them, so
     # the pools of layers 0, 2 and 3 are staged a layer early and layer 1 runs while layer 2's pool is being written.
     run([((2051, 300), grouped(2051, 300, 6, 11, 5), 1), ((1300, 2051), grouped(1300, 2051, 1, 7, 0), 0), ((1609, 1300), grouped(1609, 1300, 16, 50, 9), 1),
          ((90, 1609), dense(90, 1609), 1), ((10, 90), dense(10, 90), 0)],
-        '5 operators (2 on the thin walk, 2 with column patterns in LDS), 2 with two rows per lane, 4 column pools staged a layer early')
+        '5 operators (2 on the thin walk -- 2 of them sequentially, 2 with column patterns in LDS), 2 with two rows per lane, 2 column pools staged a layer early')
     run([((1500, 257), grouped(1500, 257, 11, 13, 1), 0), ((33, 1500), dense(33, 1500), 0)],
-        '2 operators (1 on the thin walk, 1 with column patterns in LDS), 1 with two rows per lane, 2 column pools staged a layer early')
+        '2 operators (1 on the thin walk -- 1 of them sequentially, 1 with column patterns in LDS), 1 with two rows per lane, 1 column pools staged a layer early')
 
 
 def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
@@ -1169,7 +1187,7 @@ def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
     xc = torch.as_tensor(z['x_cipher']).to(dev())
     chain = knet._chain_op(xc.device)
     assert chain is not None and chain.shape() == (11, 785)
-    assert '7 operators (3 on the thin walk, 2 with column patterns in LDS)' in chain.plan(1024)                       # fc1-fc3: two wavefronts per slice, column pool in LDS
+    assert '7 operators (3 on the thin walk -- 3 of them sequentially, 2 with column patterns in LDS)' in chain.plan(1024)                       # fc1-fc3: two wavefronts per slice, column pool in LDS
     last = 'Y.%s' % [str(n) for n in z['layer_names']][-1]
     assert np.array_equal(knet.forward_linear(xc).cpu().numpy(), z[last])
     assert np.array_equal(knet.forward_linear(xc[:5]).cpu().numpy(), z[last][:5])

@@ -39,7 +39,7 @@ def test_bench_dist_flag_runs_the_rccl_path_on_one_gpu():
     assert len(lines) == 1, p.stdout[-2000:]
     r = json.loads(lines[0])
     c = r['collective']
-    assert r['n_gpus'] == 1 and c['backend'] == 'nccl' and c['ranks_seen'] == 1 and c['ms_per_call'] > 0 and c['bytes_per_rank'] == 4 * 1024 * 10
+    assert r['n_gpus'] == 1 and c['backend'] == 'nccl' and c['ranks_seen'] == 1 and c['gather_ms'] > 0 and c['bytes_per_rank'] == 4 * 1024 * 10 and c['rank_images_per_s']['min'] > 0
     assert c['every_rank_shard_bit_equal_to_its_local_forward'] is True and c['peer_shard_recomputed_on_rank0']['bit_equal'] is True and r['parity']['ok']
     assert c['ranks'] == [[0, 0]] and len(lines[0]) < 4096                 # the compact line: [rank, device_index] pairs, details in bench_detail.json
     full = json.load(open(os.path.join(ROOT, r['detail'])))

@@ -1,16 +1,25 @@
 #!/bin/bash
-# A/B of diagnostic builds of the LeNet whole-net kernel on one box: each argument is a comma-separated list of extra -D defines ("base" = none beyond KN_ABLATION).
-#   gpurun -- 'bash tools/chain_variants.sh base KN_CHAIN_THIN_SEQ > gpurun_out/r06/chain_variants.txt 2>&1'
-# Variant libraries are built under /tmp and never left in the tree; with KN_STAMPS=1 the per-phase stamp table of every variant is printed too.
+# A/B of the LeNet whole-net kernel on one box with the diagnostic build (-DKN_ABLATION, built on demand under /tmp, never left in the tree).  Each argument is a variant:
+#   base                       the shipped configuration
+#   env:KN_CHAIN_NO_SEQ=1      a diagnostic option read at operator create (comma-separated list of assignments)
+#   def:KN_CHAIN_DV=12         extra -D defines (comma-separated): a separate build
+#   gpurun -- 'KN_STAMPS=1 bash tools/chain_variants.sh base env:KN_CHAIN_NO_SEQ=1 > gpurun_out/r06/chain_variants.txt 2>&1'
+# With KN_STAMPS=1 the per-phase stamp table of every variant is printed too.
 set -u
 cd "$(dirname "$0")/.."
+python3 -c "from keynet_amd import build; build.build(out='/tmp/libkn_abl.so', defines=('KN_ABLATION',))" || exit 1
 for V in "$@"; do
-  D="'KN_ABLATION'"
-  if [ "$V" != "base" ]; then for d in ${V//,/ }; do D="$D, '$d'"; done; fi
-  python3 -c "from keynet_amd import build; build.build(out='/tmp/libkn_$V.so', defines=($D,))" || continue
-  for rep in 1 2; do KEYNET_HIP_LIB=/tmp/libkn_$V.so python3 tools/chain_time.py 1024 "$V"; done
+  LIB=/tmp/libkn_abl.so
+  ENVS=""
+  case "$V" in
+    def:*) D="'KN_ABLATION'"; for d in $(echo "${V#def:}" | tr ',' ' '); do D="$D, '$d'"; done
+           LIB="/tmp/libkn_$(echo "$V" | tr -c 'A-Za-z0-9' '_').so"
+           python3 -c "from keynet_amd import build; build.build(out='$LIB', defines=($D,))" || continue ;;
+    env:*) ENVS=$(echo "${V#env:}" | tr ',' ' ') ;;
+  esac
+  for rep in 1 2; do env $ENVS KEYNET_HIP_LIB=$LIB python3 tools/chain_time.py 1024 "$V"; done
   if [ "${KN_STAMPS:-0}" = "1" ]; then
-    KEYNET_HIP_LIB=/tmp/libkn_$V.so KN_CHAIN_STAMPS=/tmp/chain_stamps.bin python3 tools/chain_run.py 1024 > /dev/null
+    env $ENVS KEYNET_HIP_LIB=$LIB KN_CHAIN_STAMPS=/tmp/chain_stamps.bin python3 tools/chain_run.py 1024 > /dev/null
     python3 tools/chain_stamps_report.py /tmp/chain_stamps.bin
   fi
 done

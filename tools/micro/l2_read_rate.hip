@@ -10,11 +10,12 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int UNROLL>
-__global__ __launch_bounds__(1024) void k(const f32x4* __restrict__ a, size_t n4, int reps, float* out) {
+__global__ __launch_bounds__(1024) void k(const f32x4* __restrict__ a, size_t n4, int reps, float* out, int lockstep) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < reps; r++) {
-        // stagger the start per workgroup so that the 32 CUs of an XCD do not all ask for the same line at once (the kernel's workgroups drift apart too)
-        size_t base = ((size_t)blockIdx.x * 4099 + (size_t)r * 977) * 1024 % n4;
+        // staggered: every workgroup starts somewhere else, so the 32 CUs of an XCD do not all ask for the same line at once;
+        // lockstep: all workgroups walk the array from its start together (what workgroups that stream one operator in the same order do until they drift apart)
+        size_t base = lockstep ? 0 : ((size_t)blockIdx.x * 4099 + (size_t)r * 977) * 1024 % n4;
         for (size_t i = 0; i < n4; i += (size_t)1024 * UNROLL) {
             f32x4 v[UNROLL];
 #pragma unroll
@@ -38,22 +39,24 @@ int main() {
         hipMalloc(&a, n4 * 16);
         hipMalloc(&out, 16);
         hipMemset(a, 0, n4 * 16);
+        for (int lockstep : {0, 1})
         for (int wgs : {256, 512}) {
-            const int reps = 40;
-            hipLaunchKernelGGL(k<8>, dim3(wgs), dim3(1024), 0, 0, a, n4, 4, out);
+            const int reps = lockstep ? 1 : 40;                          // (lockstep: ONE pass per launch -- behind the first pass the workgroups have drifted apart; averaged over 40 launches)
+            const int launches = lockstep ? 40 : 1;
+            hipLaunchKernelGGL(k<8>, dim3(wgs), dim3(1024), 0, 0, a, n4, 4, out, lockstep);
             hipDeviceSynchronize();
             hipEvent_t e0, e1;
             hipEventCreate(&e0);
             hipEventCreate(&e1);
             hipEventRecord(e0);
-            hipLaunchKernelGGL(k<8>, dim3(wgs), dim3(1024), 0, 0, a, n4, reps, out);
+            for (int l = 0; l < launches; l++) hipLaunchKernelGGL(k<8>, dim3(wgs), dim3(1024), 0, 0, a, n4, reps, out, lockstep);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            const double total = (double)n4 * 16 * reps * wgs;
-            printf("array %5.1f MB | %3d workgroups x 1024 threads | %6.2f TB/s from L2 (%.1f GB in %.3f ms) | one pass of all workgroups: %.2f us\n", n4 * 16 / 1e6, wgs, total / ms / 1e9, total / 1e9, ms,
-                   1e3 * ms / reps);
+            const double total = (double)n4 * 16 * reps * launches * wgs;
+            printf("array %5.1f MB | %3d workgroups x 1024 threads | %-9s | %6.2f TB/s from L2 (%.1f GB in %.3f ms) | one pass of all workgroups: %.2f us%s\n", n4 * 16 / 1e6, wgs, lockstep ? "lockstep" : "staggered",
+                   total / ms / 1e9, total / 1e9, ms, 1e3 * ms / (reps * launches), lockstep ? " (incl. ~2 us of launch per pass)" : "");
         }
         hipFree(a);
         hipFree(out);
