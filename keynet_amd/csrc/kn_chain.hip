@@ -71,7 +71,6 @@ struct ChainArgs {
     float* Y;
     int64_t ldx, ldy;
     int32_t n_layers, n_vecs, n_in, n_out, buf1_off, zero_off;     // float4 indices: start of the second activation buffer; the always-zero feature
-    int32_t rot_mul;                                               // > 0: workgroup g walks a layer's slices rotated by (g * rot_mul) % n_slices (chain_load_meta)
 #ifdef KN_ABLATION
     unsigned long long* stamps;                                    // [workgroup][16] 100 MHz timestamps at the phase boundaries (tools/chain_stamps.sh), or null
     unsigned long long* wstamps;                                   // [workgroup][12 layers][16 wavefronts][40] inside the walks: 0-7 per walk, 8 + 4 * slice + k per slice
@@ -141,11 +140,10 @@ __device__ __forceinline__ float* chain_lds_base() {
 #define KN_CHAIN_DV 6           // value quads in flight per wavefront of the thin walk (a multiple of 6.  LeNet forward, same box: 6 -> 37.6 us, 12 -> 38.6 us with a few
                                 // spilled address registers, 18 spills the ring itself)
 #endif
-#ifndef KN_CHAIN_SEQ_COLS
-#define KN_CHAIN_SEQ_COLS 2     // batch columns per wavefront of the sequential thin walk: 2 = two wavefronts per slice (one per column pair: fewer vector instructions per wavefront, the
-                                // slice's value stream loaded twice), 4 = one wavefront per slice (the stream loaded once, 21 instead of 11 vector instructions per quad)
-#endif
-static constexpr int CHAIN_SEQ_WPS = KN_CHAIN_SEQ_COLS == 4 ? 1 : 2;      // wavefronts per slice of a sequential thin layer
+// wavefronts per slice of a sequential thin layer: two, one per pair of batch columns (as in chain_rows_thin).  Measured and dropped, round 6: ONE wavefront per slice for all four
+// columns -- the slice's value stream loaded once instead of twice, but 21 instead of 11 vector instructions per quad on a wavefront that is alone on its SIMD: fc1 13.3 against
+// 10.4 us, the LeNet forward 41.8 against 38.4 us (profiles/r06_lenet_chain_breakdown.txt).  The walk below is written for either.
+static constexpr int CHAIN_SEQ_WPS = 2;
 static constexpr int CHAIN_D = 4, CHAIN_NP = 2;       // ring depth / next-slice quads requested early (pattern walk, one row per lane)
 static constexpr int CHAIN_D_ROWS = 2;                // ... of the general walk (what takes it are short rows of unrelated patterns -- keyed pooling: 9 entries = 3 quads -- and it
                                                       // holds a column quad per value quad: the register budget of 16 wavefronts per CU is 128)
@@ -163,16 +161,12 @@ struct ChainPre {
 // lane + slice record of slice s for this lane; R = rows per lane of the layer's layout, POOL = columns are read from the pool staged in LDS at
 // float4 index pool4 (then coff is an LDS byte offset), else from memory
 template <int R, bool POOL>
-__device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int s, const int lane, const int pool4, const int rot = 0) {
+__device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int s, const int lane, const int pool4) {
     constexpr int RPS = 64;
-    // rot: the workgroup's rotation of the layer's slice order (ChainArgs::rot_mul): workgroups that walk one operator in the same order keep asking the L2 for the same lines at
-    // the same time; rotated, the CUs of an XCD read different parts of it.  Which slice a wavefront takes when does not change any result.
-    if (s < L.n_slices) {
-        s += rot;
-        s = s >= L.n_slices ? s - L.n_slices : s;
-    } else {
-        s = L.n_slices - 1;                                      // past the end: the last slice again (unused)
-    }
+    // (Measured and dropped, round 6: every workgroup walking a layer's slices in its own rotated order, so that the CUs of an XCD do not ask the L2 for the same lines at the
+    // same time -- 37.6-38.1 against 37.0 us per LeNet forward on the same box; tools/micro/l2_read_rate.hip shows why: workgroups in lockstep read an L2-resident array at
+    // 26.5 TB/s, staggered ones at 28.4.)
+    s = s < L.n_slices ? s : L.n_slices - 1;                    // past the end: the last slice again (unused)
     const chain_const_i32 si = (chain_const_i32)(uintptr_t)(L.slice_info + 4 * s);
     const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(s * RPS + lane));      // (uniform base + 32-bit offset: saddr form)
     ChainMeta m;
@@ -196,12 +190,12 @@ __device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int
 // Column indices are stored as LDS BYTE offsets of the layer's input buffer (16 * column + buffer base): an activation read is one
 // ds_read_b128 at the loaded value, no address arithmetic.
 template <bool ST, int PART>          // PART: 1 = the lane records, 2 = the first ring, 3 = both
-__device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
+__device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS;
     if (wave >= L.n_slices) return;
     if (PART & 1) {
-        pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0, rot);
-        pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0, rot);
+        pre.m0 = chain_load_meta<1, false>(L, wave, lane, 0);
+        pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
     }
     if (!(PART & 2)) return;
     const char* const cols_b = reinterpret_cast<const char*>(L.cols);
@@ -214,7 +208,7 @@ __device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int
 }
 
 template <bool ST>
-__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws, const int rot = 0) {
+__device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
     constexpr int RPS = 64;                    // rows per slice (wavefront)
     constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS, NP = CHAIN_NP;
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
@@ -243,7 +237,7 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     for (int s = wave; s < n_slices; s += NW) {
 #pragma unroll
         for (int i = 0; i < NP; i++) fetch(m1, i, cn[i], vn[i]);
-        const ChainMeta m2 = chain_load_meta<1, false>(L, s + 2 * NW, lane, 0, rot);
+        const ChainMeta m2 = chain_load_meta<1, false>(L, s + 2 * NW, lane, 0);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
         f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
         // activations of a quad are read from LDS one quad AHEAD of their use (x double buffer): with two wavefronts on a CU (a Linear) the
@@ -334,12 +328,12 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
 // the same LDS clocks now carry twice the arithmetic (conv2 12.0 -> see profiles/r05_lenet_chain_breakdown.txt).  Each row still sums its own stored
 // sequence serially, multiply then add: same bits.
 template <bool ST, int R, int PART>
-__device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
+__device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D;      // (R = 2: a quad is 32 bytes per lane -- the same bytes in flight with half the ring)
     if (wave >= L.n_slices) return;
     if (PART & 1) {
-        pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off, rot);
-        pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off, rot);
+        pre.m0 = chain_load_meta<R, true>(L, wave, lane, L.stage_off);
+        pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
     }
     if (!(PART & 2)) return;
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
@@ -350,7 +344,7 @@ __device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const 
 }
 
 template <bool ST, int R>
-__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws, const int rot = 0) {
+__device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
     constexpr int RPS = 64;
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D, NP = (R == 2) ? 1 : CHAIN_NP;
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
@@ -373,7 +367,7 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
         for (int i = 0; i < NP; i++)
 #pragma unroll
             for (int r = 0; r < R; r++) vn[i][r] = ldv(m1, i, r);
-        const ChainMeta m2 = chain_load_meta<R, true>(L, s + 2 * NW, lane, L.stage_off, rot);
+        const ChainMeta m2 = chain_load_meta<R, true>(L, s + 2 * NW, lane, L.stage_off);
         __builtin_amdgcn_sched_barrier(0);                        // (requested now, not where they are first used)
         f32x2 a01[R], a23[R];
 #pragma unroll
@@ -683,11 +677,11 @@ __device__ __forceinline__ void chain_stage_now(const ChainLayerArg& L, const in
 }
 
 template <bool ST, int PART>
-__device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre, const int rot = 0) {
+__device__ __forceinline__ void chain_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     if (L.cols_quads > 0 || L.seq_len > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST, PART>(L, wave, lane, pre);
-    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2, PART>(L, wave, lane, pre, rot);
-    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1, PART>(L, wave, lane, pre, rot);
-    else chain_rows_pre<ST, PART>(L, wave, lane, pre, rot);
+    else if (L.cols_quads < 0 && L.rpl == 2) chain_rows_cl_pre<ST, 2, PART>(L, wave, lane, pre);
+    else if (L.cols_quads < 0) chain_rows_cl_pre<ST, 1, PART>(L, wave, lane, pre);
+    else chain_rows_pre<ST, PART>(L, wave, lane, pre);
 }
 
 template <bool ST>
@@ -752,15 +746,13 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         const bool extra = L.seq_len > 0 && wave >= CHAIN_SEQ_WPS * L.n_slices;
         const ChainLayerArg& W = extra ? a.LX[l] : L;
         const int w = extra ? wave - CHAIN_SEQ_WPS * L.n_slices : wave;
-        // this workgroup's rotation of the slice order (0 with rot_mul = 0; never with operator words that crossed the barrier: KN_CHAIN_PRE builds)
-        const int rot = (KN_CHAIN_PRE == 0 && a.rot_mul > 0 && W.n_slices > 1) ? (int)(((uint32_t)grp * (uint32_t)a.rot_mul) % (uint32_t)W.n_slices) : 0;
-        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(W, w, lane, pre, rot);
+        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(W, w, lane, pre);
         if (KN_CHAIN_PRE == 2) chain_pre<ST, 2>(W, w, lane, pre);               // (the lane records crossed the barrier; the ring is requested here)
         if (W.seq_len > 0) chain_rows_thin_seq<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
         else if (W.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
-        else if (W.cols_quads < 0 && W.rpl == 2) chain_rows_cl<ST, 2>(W, out_off, w, lane, pre, ws, rot);
-        else if (W.cols_quads < 0) chain_rows_cl<ST, 1>(W, out_off, w, lane, pre, ws, rot);
-        else chain_rows<ST>(W, out_off, w, lane, pre, ws, rot);
+        else if (W.cols_quads < 0 && W.rpl == 2) chain_rows_cl<ST, 2>(W, out_off, w, lane, pre, ws);
+        else if (W.cols_quads < 0) chain_rows_cl<ST, 1>(W, out_off, w, lane, pre, ws);
+        else chain_rows<ST>(W, out_off, w, lane, pre, ws);
         CHAIN_WSTAMP(6, false);
         if (stage_next) chain_stage_now<ST>(a.L[l + 1], tid);
         // the next layer's first operator words: on their way across the barrier.  (A fresh object per layer: what a wavefront without a slice, or a walk
@@ -1160,7 +1152,6 @@ int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, 
         if (rc) return rc;
     }
     c->args.n_layers = (int32_t)n_ops;
-    c->args.rot_mul = ops[0]->csr.tune.chain_rot;
     c->args.n_in = (int32_t)ops[0]->cols;
     c->args.n_out = (int32_t)ops[n_ops - 1]->rows;
     c->args.buf1_off = (int32_t)feat[0];

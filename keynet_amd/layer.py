@@ -127,8 +127,8 @@ def gate(y, ref):
     t = FLOAT_KEY_ATOL + FLOAT_KEY_RTOL * ref.abs()
     r = d / t
     r = torch.where(torch.isnan(r), torch.full_like(r, float('inf')), r)        # NaN (Inf - Inf, NaN on one side): never inside any tolerance
-    k = int(torch.argmax(r))
-    (rk, dk, tk, dmax) = (float(r.flatten()[k]), float(d.flatten()[k]), float(t.flatten()[k]), float(d.max()))
+    k = torch.argmax(r)
+    (rk, dk, tk, dmax) = torch.stack((r.flatten()[k], d.flatten()[k], t.flatten()[k], d.max())).tolist()      # the four scalars in ONE device-to-host read
     return (rk if np.isfinite(rk) else float('nan'), dk, tk, dmax)
 
 

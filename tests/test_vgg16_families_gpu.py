@@ -174,7 +174,7 @@ def test_filled_in_operators_take_the_filled_in_kernels(stochastic_direct):
             pe = W._device_op(dev).plan(256, _capi.KN_FLAG_EXACT)
             pm = W._device_op(dev).plan(256, 0)
         if dups or slots > 64:
-            assert 'convtaps_exact_fill_kernel<taps in registers>' in pe, (n, pe)
+            assert 'convtaps_exact_fill_kernel<taps in registers' in pe, (n, pe)      # (at 256 columns: the forms with two column tiles per wavefront where the layer has the work for them)
             n_fill += 1
         if slots > 64 and W._inshape[0] % 16 == 0:                        # (the wave-uniform-pointer loaders take whole 16-channel chunks: conv1_1 / conv1_2 / conv2_1 of this reduced net keep the generic loader)
             assert 'slot groups' in pm, (n, pm)
