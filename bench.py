@@ -49,7 +49,7 @@ from keynet_amd import io as kio               # noqa: E402
 from keynet_amd.layer import KeyedLayer        # noqa: E402
 from keynet_amd.models import VGG16, LeNet_AvgPool, AllConvNet   # noqa: E402
 
-from benchlegs.common import ROOT as _ROOT, log, PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, keyed_layers, host_nnz, kernel_sources_sha   # noqa: E402,F401
+from benchlegs.common import ROOT as _ROOT, log, PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, PEAK_L2_READ_GBS_MEASURED, keyed_layers, host_nnz, kernel_sources_sha   # noqa: E402,F401
 from benchlegs.workloads import build_workload                                                                          # noqa: E402,F401
 from benchlegs.shared import build_workload_shared                                                                      # noqa: E402
 from benchlegs.cpu import cpu_baseline, host_cores                                                                      # noqa: E402,F401
@@ -314,7 +314,14 @@ def main():
             nnz_net = float(sum(r['nnz'] for r in table))
             rounds = -(-((batch + 3) // 4) // 256)
             valu_floor_ms = rounds * (nnz_net / 64.0) * 4 * 4 / 4 / 2.4e9 * 1e3
+            # ... and what it really streams (round 6): every workgroup (4 batch columns) reads the key-net's operator words from L2 once -- n_workgroups x the bytes the plan
+            # names -- against the L2 read rate all 256 CUs reach together on an L2-resident array (tools/micro/l2_read_rate.hip, profiles/r06_micro_l2_read_rate.txt)
+            import re
+            m_l2 = re.search(r'(\d+) B of operator words per workgroup', chain.plan(batch))
+            l2_bytes = float(m_l2.group(1)) * ((batch + 3) // 4) if m_l2 else None
             roof = dict(bound='hbm', kernel=chain.plan(batch), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                        l2_stream_bytes_per_forward=l2_bytes, l2_read_peak_gbs_measured=PEAK_L2_READ_GBS_MEASURED,
+                        frac_of_l2_read_roof=(l2_bytes / ch_ms / 1e6 / PEAK_L2_READ_GBS_MEASURED) if l2_bytes else None,
                         valu_floor_ms=valu_floor_ms, frac_of_valu_floor=valu_floor_ms / ch_ms,
                         algorithmic_bytes=total_bytes, algorithmic_macs=float(sum(r['nnz'] for r in table)) * batch, ms_per_forward=ch_ms,
                         t_mac_per_s=float(sum(r['nnz'] for r in table)) * batch / ch_ms / 1e9,

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense f32-input MFMA = f32 vector peak)
 PEAK_VALU_NOFMA_TMACS = 39.3     # the same vector peak with separate multiply and add (bit-exact contract): 157.3 / 4 T MAC/s
+PEAK_L2_READ_GBS_MEASURED = 28300.0   # all 256 CUs reading one L2-resident array (2.7 MB, 16-byte loads): tools/micro/l2_read_rate.hip, profiles/r06_micro_l2_read_rate.txt (no guide figure)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md:36 (spec; 6.29 TB/s measured copy)
 
 

@@ -12,7 +12,7 @@ DETAIL_FILE = 'bench_detail.json'
 def _compact_roofline(r):
     if not isinstance(r, dict):
         return r
-    out = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_ratio', 'algorithmic_bytes', 'algorithmic_flops', 'algorithmic_macs', 'ms_per_forward'))
+    out = _pick(r, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'frac_of_l2_read_roof', 'traffic', 'traffic_ratio', 'algorithmic_bytes', 'algorithmic_flops', 'algorithmic_macs', 'ms_per_forward'))
     out['kernel'] = _clip(out.get('kernel'), 96)
     return out
 
@@ -37,7 +37,8 @@ def _compact_secondary(s):
     par = s.get('parity') or {}
     cpu = s.get('cpu_baseline') or {}
     return {'images_per_gpu': s.get('images_per_gpu'), 'images_per_s': s.get('images_per_s'), 'ms_per_step': s.get('ms_per_step'), 'bound': roof.get('bound'), 'achieved': roof.get('achieved'),
-            'peak': roof.get('peak'), 'unit': roof.get('unit'), 'frac': roof.get('frac'), 'kernel_ms': roof.get('ms_per_forward'), 'bit_equal': par.get('bit_equal'),
+            'peak': roof.get('peak'), 'unit': roof.get('unit'), 'frac': roof.get('frac'), 'frac_of_l2_read_roof': roof.get('frac_of_l2_read_roof'), 'kernel_ms': roof.get('ms_per_forward'),
+            'bit_equal': par.get('bit_equal'),
             'cpu_images_per_s': cpu.get('value'), 'cpu_cores': cpu.get('cores')}
 
 

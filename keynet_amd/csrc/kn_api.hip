@@ -36,7 +36,7 @@ Tuning tuning_from_env() {
         {"KN_OCC", &Tuning::occ}, {"KN_NO_TAIL_SPLIT", &Tuning::no_tail_split}, {"KN_NO_SMALLK", &Tuning::no_smallk}, {"KN_EXACT_PIPE", &Tuning::exact_pipe},
         {"KN_EXACT_COB_GROUPS", &Tuning::exact_cob_groups}, {"KN_EXACT_XD", &Tuning::exact_xd}, {"KN_EXACT_VEC", &Tuning::exact_vec}, {"KN_MF_PF", &Tuning::mf_pf},
         {"KN_TABLE_WINDOW", &Tuning::table_window}, {"KN_TABLE_STRIP", &Tuning::table_strip}, {"KN_NO_PATCH", &Tuning::no_patch}, {"KN_CONV_BALL", &Tuning::conv_ball},
-        {"KN_NO_ROW_ORDER", &Tuning::no_row_order}, {"KN_CHAIN_NO_CL", &Tuning::chain_no_cl}, {"KN_CHAIN_NO_RPL2", &Tuning::chain_no_rpl2}, {"KN_CHAIN_NO_EARLY", &Tuning::chain_no_early}, {"KN_CHAIN_NO_SEQ", &Tuning::chain_no_seq}, {"KN_FILL_FORM", &Tuning::fill_form}, {"KN_ABL", &Tuning::abl},
+        {"KN_NO_ROW_ORDER", &Tuning::no_row_order}, {"KN_CHAIN_NO_CL", &Tuning::chain_no_cl}, {"KN_CHAIN_NO_RPL2", &Tuning::chain_no_rpl2}, {"KN_CHAIN_NO_EARLY", &Tuning::chain_no_early}, {"KN_CHAIN_NO_SEQ", &Tuning::chain_no_seq}, {"KN_CHAIN_NO_SHARE", &Tuning::chain_no_share}, {"KN_FILL_FORM", &Tuning::fill_form}, {"KN_ABL", &Tuning::abl},
 #endif
     };
     for (const Knob& k : knobs)
@@ -59,7 +59,7 @@ std::string Tuning::describe() const {
     add("occ", occ, d.occ); add("no_tail_split", no_tail_split, d.no_tail_split); add("no_smallk", no_smallk, d.no_smallk); add("exact_pipe", exact_pipe, d.exact_pipe);
     add("exact_cob_groups", exact_cob_groups, d.exact_cob_groups); add("exact_xd", exact_xd, d.exact_xd); add("exact_vec", exact_vec, d.exact_vec); add("mf_pf", mf_pf, d.mf_pf);
     add("table_window", table_window, d.table_window); add("table_strip", table_strip, d.table_strip); add("no_patch", no_patch, d.no_patch); add("conv_ball", conv_ball, d.conv_ball);
-    add("no_row_order", no_row_order, d.no_row_order); add("chain_no_cl", chain_no_cl, d.chain_no_cl); add("chain_no_rpl2", chain_no_rpl2, d.chain_no_rpl2); add("chain_no_early", chain_no_early, d.chain_no_early); add("chain_no_seq", chain_no_seq, d.chain_no_seq); add("fill_form", fill_form, d.fill_form); add("abl", abl, d.abl);
+    add("no_row_order", no_row_order, d.no_row_order); add("chain_no_cl", chain_no_cl, d.chain_no_cl); add("chain_no_rpl2", chain_no_rpl2, d.chain_no_rpl2); add("chain_no_early", chain_no_early, d.chain_no_early); add("chain_no_seq", chain_no_seq, d.chain_no_seq); add("chain_no_share", chain_no_share, d.chain_no_share); add("fill_form", fill_form, d.fill_form); add("abl", abl, d.abl);
     return o.empty() ? o : " opts{" + o + "}";
 }
 

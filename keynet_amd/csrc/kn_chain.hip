@@ -60,6 +60,8 @@ struct ChainLayerArg {
     int32_t rpl;                // output rows per lane: 1, or 2 (chain_rows_cl: two rows of one column pattern share every activation read)
     int32_t stage_off;          // float4 index of the LDS area the pool is staged in
     int32_t early;              // 1 = the pool is staged while the PREVIOUS layer runs (layer 0: with the input), 0 = at the start of this layer
+    int32_t vstride;            // general / pattern walks: distance between a lane's consecutive value quads, in units of 16 * rpl bytes (64 = every lane its own copy; the number of
+                                // lanes per pixel when lanes that carry the SAME value sequence share one copy: see chain_build_layer)
     int32_t seq_len;            // > 0: a SEQUENTIAL thin layer (chain_rows_thin_seq) -- the stored entries of the one column pattern all of these rows share; the
     int32_t seq_base;           //      layer's input buffer (LDS byte offset seq_base) is laid out in that pattern's order by the layer before it
 };
@@ -174,7 +176,7 @@ __device__ __forceinline__ ChainMeta chain_load_meta(const ChainLayerArg& L, int
     if constexpr (R == 2) m.row1 = lm.z;      // (one row per lane: never read)
     m.nq = si[0];
     m.cstride_b = 16u * (uint32_t)si[1];
-    m.voff = 16u * (uint32_t)R * ((uint32_t)si[2] * RPS + (uint32_t)lane);
+    m.voff = 16u * (uint32_t)R * (uint32_t)lm.w;                  // (the lane's own value base: lanes whose rows carry one value sequence -- a conv channel at every interior pixel -- share a copy)
     m.coff = 16u * (uint32_t)(POOL ? (pool4 + lm.y) : lm.y);
     return m;
 }
@@ -203,14 +205,13 @@ __device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int
 #pragma unroll
     for (int i = 0; i < D; i++) {
         pre.c[i] = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)i * pre.m0.cstride_b) + pre.m0.coff);
-        pre.v[i] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * 64)) + pre.m0.voff);
+        pre.v[i] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * (uint32_t)L.vstride)) + pre.m0.voff);
     }
 }
 
 template <bool ST>
 __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
-    constexpr int RPS = 64;                    // rows per slice (wavefront)
-    constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS, NP = CHAIN_NP;
+    constexpr int NW = CHAIN_THREADS / 64, D = CHAIN_D_ROWS, NP = CHAIN_NP;      // (64 rows per slice = one wavefront)
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
@@ -219,9 +220,10 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     // clamp: a request past a slice's last quad reads the next slice's words (or the arrays' zero padding) and is never used.
     const char* const cols_b = reinterpret_cast<const char*>(L.cols);
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const uint32_t vstride_b = 16u * (uint32_t)L.vstride;          // bytes between a lane's consecutive value quads (wave-uniform)
     auto fetch = [&](const ChainMeta& m, const int q, i32x4& c, f32x4& v) {
         c = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)q * m.cstride_b) + m.coff);
-        v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + m.voff);
+        v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * vstride_b) + m.voff);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     CHAIN_WSTAMP(0, false);
@@ -340,18 +342,18 @@ __device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const 
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll
-        for (int r = 0; r < R; r++) pre.v[i * R + r] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * R * 64)) + pre.m0.voff + 16u * r);
+        for (int r = 0; r < R; r++) pre.v[i * R + r] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * R * (uint32_t)L.vstride)) + pre.m0.voff + 16u * r);
 }
 
 template <bool ST, int R>
 __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
-    constexpr int RPS = 64;
     constexpr int NW = CHAIN_THREADS / 64, D = (R == 2) ? 2 : CHAIN_D, NP = (R == 2) ? 1 : CHAIN_NP;
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
     const char* const vals_b = reinterpret_cast<const char*>(L.vals);
-    auto ldv = [&](const ChainMeta& m, const int q, const int r) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * R * RPS)) + m.voff + 16u * r); };
+    const uint32_t vstride_b = 16u * R * (uint32_t)L.vstride;      // bytes between a lane's consecutive value quads (wave-uniform)
+    auto ldv = [&](const ChainMeta& m, const int q, const int r) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * vstride_b) + m.voff + 16u * r); };
     auto ldc = [&](const ChainMeta& m, const int q) { return *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(chain_lds) + m.coff + 16u * (uint32_t)q); };     // (the pool is padded: quads past a row's end are readable)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     ChainMeta m0 = pre.m0, m1 = pre.m1;
@@ -781,6 +783,8 @@ struct ChainDev {
     std::vector<void*> allocs;
     ChainArgs args;
     size_t lds_bytes = 0;
+    size_t stream_bytes = 0;     // operator words ONE workgroup requests from L2 per forward (values, columns read from memory or staged, lane and slice records): the kernel's real
+                                 // traffic is n_workgroups x this -- for LeNet 256 x 2.3 MB against an L2 that delivers 28 TB/s (tools/micro/l2_read_rate.hip)
 };
 
 void chain_free(ChainDev* c) {
@@ -885,9 +889,18 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
         size_t pool_quads = 0;
         bool thin = false, all_shared = false;
         int longest = 0;
+        int vstride = 64;                 // see ChainLayerArg::vstride
+        size_t val_line_bytes = 0;        // 64-byte lines the wavefronts' value requests of one forward touch (what they ask the L2 for)
     };
     // R output rows per lane (R = 2: two rows of ONE column pattern; a pattern with an odd number of rows leaves one lane half empty)
-    auto build = [&](const int R, const std::vector<int32_t>* subset = nullptr) {
+    // `share` (general / pattern walks): lanes whose rows carry the SAME value sequence read ONE copy of it.  A keyed conv stores one weight sequence per (output channel, border
+    // class) -- LeNet conv2: 145 distinct sequences for 3 137 rows, its pooling layers 4 for 1 177 -- while the walk used to stream a private copy per lane: 1.0 of the 2.3 MB a
+    // workgroup asks the L2 for per forward, in a kernel whose 256 workgroups together run at 60-70 % of the L2's measured read rate (profiles/r06_lenet_chain_breakdown.txt).
+    // Layout: the lanes of one column pattern (the channels of a pixel, `U` lanes) keep their order; patterns whose lanes carry identical sequences share a block
+    // [quad][lane of the pattern][row of the lane][4] -- a quad's request of such a pattern is U * 16 * R contiguous bytes, the same for every pixel of the class.  A lane's base
+    // goes into its record (lane_meta.w), the quad stride U into the layer record.  Reads past a block's last quad (a shorter row in a slice of longer ones) hit the next block's
+    // finite values and multiply the always-zero feature: +-0.0 onto a sum that started at +0.0, as with the 0.0f padding before.
+    auto build = [&](const int R, const std::vector<int32_t>* subset = nullptr, const bool share = false) {
         Built B;
         std::vector<int32_t> rows_sorted((size_t)rows);
         std::iota(rows_sorted.begin(), rows_sorted.end(), 0);
@@ -957,19 +970,79 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
         B.colpool.assign(4, zero_byte);
         std::vector<int64_t> pat_cq(pat_rep.size(), -1);         // column quad offset of a pattern stored once
         int64_t vq = 0;                                          // running value-quad offset, in units of RPS * R quads
+        int U = 1;                                               // share: lanes per column pattern (the longest run of units of one pattern)
+        if (share) {
+            std::map<std::string, int64_t> blocks;               // value sequences of a pattern's lanes -> base of their block, in units of 16 * R bytes
+            for (size_t a = 0; a < units.size();) {
+                size_t b = a + 1;
+                while (b < units.size() && pat[(size_t)units[b][0]] == pat[(size_t)units[a][0]]) b++;
+                U = std::max(U, (int)(b - a));
+                a = b;
+            }
+            B.vstride = U;
+            int64_t next_base = 0;
+            for (size_t a = 0; a < units.size();) {
+                size_t b = a + 1;
+                while (b < units.size() && pat[(size_t)units[b][0]] == pat[(size_t)units[a][0]]) b++;
+                std::string key;
+                int len = 0;
+                for (size_t u = a; u < b; u++)
+                    for (int rr = 0; rr < R; rr++) {
+                        const int32_t r = units[u][(size_t)rr];
+                        const int l = r < 0 ? 0 : len_of(r);
+                        len = std::max(len, l);
+                        key.append(reinterpret_cast<const char*>(&l), sizeof(l));
+                        if (l > 0) key.append(reinterpret_cast<const char*>(dt.data() + ip[(size_t)r]), sizeof(float) * (size_t)l);
+                    }
+                auto it = blocks.find(key);
+                if (it == blocks.end()) {
+                    const int nqc = std::max((len + 3) / 4, 1);
+                    it = blocks.emplace(key, next_base).first;
+                    const size_t f0 = (size_t)next_base * 4 * (size_t)R;
+                    B.vals.resize(f0 + (size_t)nqc * (size_t)U * (size_t)R * 4, 0.0f);
+                    for (size_t u = a; u < b; u++)
+                        for (int rr = 0; rr < R; rr++) {
+                            const int32_t r = units[u][(size_t)rr];
+                            if (r < 0) continue;
+                            const int32_t rs = ip[(size_t)r];
+                            const int l = len_of(r);
+                            for (int k = 0; k < l; k++) B.vals[f0 + ((((size_t)(k >> 2) * (size_t)U + (u - a)) * (size_t)R + (size_t)rr) * 4) + (size_t)(k & 3)] = dt[(size_t)(rs + k)];
+                        }
+                    next_base += (int64_t)nqc * U;
+                }
+                for (size_t u = a; u < b; u++) B.lane_meta[4 * u + 3] = (int32_t)(it->second + (int64_t)(u - a));
+                a = b;
+            }
+        }
         for (int64_t s = 0; s < n_slices; s++) {
             const int nq = (s_max[(size_t)s] + 3) / 4;
             const int real = (int)std::min<int64_t>(RPS, n_units - s * RPS);
-            const size_t v0 = B.vals.size();
-            B.vals.resize(v0 + (size_t)nq * RPS * R * 4, 0.0f);
-            for (int i = 0; i < real; i++)
-                for (int rr = 0; rr < R; rr++) {
-                    const int32_t r = units[(size_t)(s * RPS + i)][(size_t)rr];
-                    if (r < 0) continue;
-                    const int32_t rs = ip[(size_t)r];
-                    const int len = len_of(r);
-                    for (int k = 0; k < len; k++) B.vals[v0 + ((((size_t)(k >> 2) * RPS + (size_t)i) * R + (size_t)rr) * 4) + (size_t)(k & 3)] = dt[(size_t)(rs + k)];
+            if (!share) {
+                const size_t v0 = B.vals.size();
+                B.vals.resize(v0 + (size_t)nq * RPS * R * 4, 0.0f);
+                for (int i = 0; i < real; i++)
+                    for (int rr = 0; rr < R; rr++) {
+                        const int32_t r = units[(size_t)(s * RPS + i)][(size_t)rr];
+                        if (r < 0) continue;
+                        const int32_t rs = ip[(size_t)r];
+                        const int len = len_of(r);
+                        for (int k = 0; k < len; k++) B.vals[v0 + ((((size_t)(k >> 2) * RPS + (size_t)i) * R + (size_t)rr) * 4) + (size_t)(k & 3)] = dt[(size_t)(rs + k)];
+                    }
+                for (int i = 0; i < RPS; i++) B.lane_meta[4 * (size_t)(s * RPS + i) + 3] = (int32_t)(vq * RPS + i);      // (every lane its own copy: base = slice's first quad * 64 + lane, stride 64)
+            }
+            {
+                // 64-byte lines one wavefront's requests of this slice touch, quad by quad (what it asks the L2 for; identical addresses and neighbours inside a line are one request)
+                std::vector<int64_t> lines;
+                for (int q = 0; q < nq; q++) {
+                    lines.clear();
+                    for (int i = 0; i < real; i++) {
+                        const int64_t byte0 = (int64_t)16 * R * ((int64_t)B.lane_meta[4 * (size_t)(s * RPS + i) + 3] + (int64_t)q * B.vstride);
+                        for (int64_t l = byte0 / 64; l <= (byte0 + 16 * R - 1) / 64; l++) lines.push_back(l);
+                    }
+                    std::sort(lines.begin(), lines.end());
+                    B.val_line_bytes += 64 * (size_t)(std::unique(lines.begin(), lines.end()) - lines.begin());
                 }
+            }
             int cstride = 1;
             if (s_shared[(size_t)s]) {
                 for (int i = 0; i < RPS; i++) {
@@ -1007,7 +1080,7 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
             B.info[(size_t)(4 * s + 2)] = (int32_t)vq;
             vq += nq;
         }
-        B.vals.resize(B.vals.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * R * 4, 0.0f);     // requests run past a slice's (and the array's) last quad: readable, never used
+        B.vals.resize(B.vals.size() + (size_t)CHAIN_OVERREAD_QUADS * (size_t)std::max(B.vstride, RPS) * R * 4, 0.0f);     // requests run past a slice's (and the array's) last quad: readable, never used
         B.pool_quads = B.colpool.size() / 4 + 3;                                           // what is staged: the patterns + the three quads a walk requests ahead
         B.colpool.resize(B.colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
         // thin layer: two wavefronts per slice fit the workgroup, every slice on shared patterns, a walk long enough to be bound by one wavefront's
@@ -1027,7 +1100,12 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
             for (int w : {0, 2})
                 if (X.lane_meta[o + (size_t)w] >= 0) X.lane_meta[o + (size_t)w] = (*out_pos)[(size_t)X.lane_meta[o + (size_t)w]];
     };
-    auto upload_built = [&](ChainLayerArg& T, const Built& X) -> int {
+    auto upload_built = [&](ChainLayerArg& T, const Built& X, const int value_readers = 1, const bool cols_read = true) -> int {
+        // what a workgroup's wavefronts ask the L2 for per forward: the 64-byte lines of their value requests (a thin layer: once per wavefront of the slice), the column pool
+        // (once: staged, or walked from memory), a 16-byte lane record per lane, the slice records.  The over-read padding behind the arrays is not counted.
+        const size_t pad_c = (size_t)CHAIN_OVERREAD_QUADS * 64 * 4;
+        c->stream_bytes += X.val_line_bytes * (size_t)value_readers + 4 * ((cols_read && X.colpool.size() > pad_c ? X.colpool.size() - pad_c : 0) + X.lane_meta.size() + X.info.size());
+        T.vstride = X.vstride;
         int rc;
         if ((rc = chain_upload(c, &T.vals, X.vals)) || (rc = chain_upload(c, &T.cols, X.colpool)) || (rc = chain_upload(c, &T.lane_meta, X.lane_meta)) ||
             (rc = chain_upload(c, &T.slice_info, X.info)))
@@ -1048,10 +1126,10 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
         L.early = 0;
         L.seq_len = plan.len;
         L.seq_base = in_base;
-        int rc = upload_built(L, Bm);
+        int rc = upload_built(L, Bm, CHAIN_SEQ_WPS, false);       // (columns implicit: nothing read)
         if (rc) return rc;
         if (!plan.other_rows.empty()) {
-            Built Bx = build(1, &plan.other_rows);
+            Built Bx = build(1, &plan.other_rows, true);
             place(Bx);
             LX.n_slices = (int32_t)Bx.n_slices;
             LX.n_rows = (int32_t)plan.other_rows.size();
@@ -1084,6 +1162,7 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
             }
         }
     }
+    if (cols_quads <= 0 && !tune.chain_no_share) B = build(rpl, nullptr, true);      // general / pattern walks: one copy per distinct value sequence (same rows, same lanes, same columns)
     place(B);
     L.n_slices = (int32_t)B.n_slices;
     L.n_rows = (int32_t)rows;
@@ -1094,7 +1173,7 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
     L.early = 0;
     L.seq_len = 0;
     L.seq_base = 0;
-    return upload_built(L, B);
+    return upload_built(L, B, cols_quads > 0 ? 2 : 1);
 }
 
 int chain_create(int64_t n_ops, kn_operator* const* ops, const uint32_t* flags, ChainDev** out, int64_t* rows_out, int64_t* cols_out, int64_t* nnz_out) {
@@ -1222,7 +1301,8 @@ int chain_forward(const ChainDev* c, const float* x, int64_t ldx, int64_t n_vecs
     }
     const std::string d = "chain_kernel<" + std::to_string(a.n_layers) + " operators (" + std::to_string(n_thin) + " on the thin walk -- " + std::to_string(n_seq) + " of them sequentially, " + std::to_string(n_cl) +
                           " with column patterns in LDS), " + std::to_string(n_rpl2) + " with two rows per lane, " + std::to_string(n_early) +
-                          " column pools staged a layer early, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS>";
+                          " column pools staged a layer early, 4 batch columns per workgroup, " + std::to_string(c->lds_bytes) + " B LDS, " + std::to_string(c->stream_bytes) +
+                          " B of operator words per workgroup from L2>";
     if (2 * c->lds_bytes > CHAIN_LDS_BYTES) KN_LAUNCH(d, chain_kernel<true>, dim3((unsigned)grid), dim3(CHAIN_THREADS), 0, s, a);       // one workgroup per CU either way
     else KN_LAUNCH(d, chain_kernel<false>, dim3((unsigned)grid), dim3(CHAIN_THREADS), c->lds_bytes, s, a);
     KN_HIP(hipGetLastError());

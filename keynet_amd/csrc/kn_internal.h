@@ -155,6 +155,7 @@ struct Tuning {
     int chain_no_cl = 0;      // KN_CHAIN_NO_CL
     int chain_no_rpl2 = 0;    // KN_CHAIN_NO_RPL2     whole-net kernel: one output row per lane in the pattern walk
     int chain_no_early = 0;   // KN_CHAIN_NO_EARLY    whole-net kernel: column pools staged at the start of their own layer
+    int chain_no_share = 0;   // KN_CHAIN_NO_SHARE    whole-net kernel: every lane streams its own copy of its row's values (no shared value blocks)
     int chain_no_seq = 0;     // KN_CHAIN_NO_SEQ      whole-net kernel: thin layers read their columns from the staged pool instead of walking a re-ordered input sequentially
     int fill_form = 0;        // KN_FILL_FORM         filled-in order-preserving kernel: 0 = the dispatch rule, 1 / 2 = 32 / 64 channels x one column tile, 3 / 4 = 32 / 64 channels x two tiles
     int abl = 0;              // KN_ABL               kernel ablation mask (kn_conv.hip, KN_ABLATION code paths)
