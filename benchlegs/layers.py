@@ -110,14 +110,14 @@ def committed_traffic(workload, mode):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_%s_*traffic.json' % workload)))
     if not files:
-        return (None, 'no committed PMC pass')
+        return (None, 'no committed PMC pass', None)
     t = json.load(open(files[-1]))
     rel = os.path.relpath(files[-1], ROOT)
     if t.get('mode', 'tolerance') != mode:
-        return (None, '%s is a %s-mode pass' % (rel, t.get('mode', 'tolerance')))
+        return (None, '%s is a %s-mode pass' % (rel, t.get('mode', 'tolerance')), None)
     if t.get('csrc_sha256') != kernel_sources_sha():
-        return (None, '%s was taken on other kernel sources' % rel)
-    return (t.get('convtaps_hbm_bytes_per_forward', t.get('dominant_hbm_bytes_per_forward')), rel)
+        return (None, '%s was taken on other kernel sources' % rel, None)
+    return (t.get('convtaps_hbm_bytes_per_forward', t.get('dominant_hbm_bytes_per_forward')), rel, t.get('traffic_ratio'))
 
 
 def roofline_of(table, workload, batch, mode):
@@ -144,10 +144,10 @@ def roofline_of(table, workload, batch, mode):
         dom = kinds.get('convtaps', []) or dom
         dom_ms = sum(r['ms'] for r in dom)
         ach = sum(r['flops'] for r in dom) / dom_ms / 1e9
-        (traffic, tsrc) = committed_traffic(workload, mode) if batch == 256 else (None, 'PMC pass is for 256 images')
+        (traffic, tsrc, tratio) = committed_traffic(workload, mode) if batch == 256 else (None, 'PMC pass is for 256 images', None)
         return dict(bound='mfma', kernel='convtaps_mfma_kernel (%d launches/forward)' % len(dom), achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=ach / PEAK_F32_MFMA_TFLOPS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass over ONE marked forward: tools/pmc_forward.py)', traffic_source=tsrc,
-                    traffic_ratio=(traffic / sum(r['bytes'] for r in dom)) if traffic else None,
+                    traffic_ratio=tratio,        # traffic / the algorithmic bytes of the launches the pass counted (the conv layers + the split-K launches of fc6-8)
                     algorithmic_bytes=sum(r['bytes'] for r in dom), algorithmic_flops=sum(r['flops'] for r in dom), ms_per_forward=dom_ms)
     macs = sum(r['nnz'] for r in dom) * float(batch)
     intensity = 2.0 * macs / sum(r['bytes'] for r in dom)
@@ -163,9 +163,9 @@ def roofline_of(table, workload, batch, mode):
         return dict(bound='hbm', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS,
                     traffic=None, algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms)
     ach = macs / dom_ms / 1e9
-    (traffic, tsrc) = committed_traffic(workload, mode)
+    (traffic, tsrc, tratio) = committed_traffic(workload, mode)
     return dict(bound='valu-nofma', kernel='%s (%d launches/forward)' % (names, len(dom)), achieved=ach, peak=PEAK_VALU_NOFMA_TMACS, unit='T MAC/s',
-                frac=ach / PEAK_VALU_NOFMA_TMACS, traffic=traffic, traffic_unit='bytes/forward (PMC, offline pass)', traffic_source=tsrc, algorithmic_macs=macs,
+                frac=ach / PEAK_VALU_NOFMA_TMACS, traffic=traffic, traffic_ratio=tratio, traffic_unit='bytes/forward (PMC, offline pass over ONE marked forward: tools/pmc_forward.py)', traffic_source=tsrc, algorithmic_macs=macs,
                 algorithmic_bytes=sum(r['bytes'] for r in dom), ms_per_forward=dom_ms,
                 note='bit-exact contract: a separately rounded f32 product and an f32 add per stored value, in the reference\'s order -- no fused multiply-add, no '
                      'accumulating matrix instruction; roof = one product + one add per lane per 2 cycles = 157.3 TFLOP/s / 4 (kernels that take their products '

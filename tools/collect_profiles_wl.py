@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the condensed artefacts of tools/run_profiles_wl.sh runs into profiles/:  python3 tools/collect_profiles_wl.py r03 gpurun_out/p_lenet:lenet_b1024 ...
 A third field names the dominant kernel (substring): `gpurun_out/p_allconv:allconv_b4096:csr_group_mfma_kernel` also writes <prefix>traffic.json = the
-HBM bytes per forward of those launches (FETCH_SIZE doubled per the guide's gfx950 note + WRITE_SIZE, first forward of the PMC passes) with the sha256
+HBM bytes of those launches of ONE marked forward (tools/pmc_forward.py: FETCH_SIZE doubled per the guide's gfx950 note + WRITE_SIZE) with the sha256
 of the kernel sources, which bench.py quotes as roofline.traffic when its own sources are byte-identical."""
 import csv
 import glob
@@ -29,28 +29,13 @@ for spec in sys.argv[2:]:
             if int(r[2]) < 3:
                 w.writerow(r)
     if dominant:
-        import hashlib
-        import json
-        h = hashlib.sha256()
-        cs = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'keynet_amd', 'csrc')
-        for f in sorted(os.listdir(cs)):
-            if f.endswith(('.hip', '.h')):
-                h.update(open(os.path.join(cs, f), 'rb').read())
-        (ik, io, ifx, iw) = (rows[0].index('kernel'), rows[0].index('occ'), rows[0].index('fetch_GB_x2'), rows[0].index('write_GB'))
-        first = [r for r in rows[1:] if dominant in r[ik]]
-        # occurrence numbers count per (kernel, grid): the first forward = the lowest occurrence of each grid, repeated grids (two layers of one shape) in launch order
-        n_first = {}
-        for r in first:
-            n_first.setdefault(r[1], []).append(int(r[io]))
-        bench = json.loads([l for l in open(d + '/bench.json') if l.startswith('{')][0])
-        mode = 'exact' if str(bench.get('config', {}).get('mode', '')).startswith('exact') else 'tolerance'
-        per_fwd = json.load(open(d + '/layers.json')) if os.path.exists(d + '/layers.json') else {}
-        n_launch = sum(1 for l in per_fwd.get('layers', []) if dominant in str(l.get('plan', '')))
-        use = first[:n_launch] if n_launch else first
-        json.dump({'workload': name, 'mode': mode, 'csrc_sha256': h.hexdigest(), 'dominant_kernel': dominant, 'launches_per_forward': len(use),
-                   'dominant_hbm_bytes_per_forward': sum((float(r[ifx]) + float(r[iw])) * 1e9 for r in use),
-                   'fetch_bytes_x2': sum(float(r[ifx]) * 1e9 for r in use), 'write_bytes': sum(float(r[iw]) * 1e9 for r in use),
-                   'source': 'separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/run_profiles_wl.sh), rows of %spmc.csv' % pre}, open(pre + 'traffic.json', 'w'), indent=1)
+        # roofline.traffic: the launches of ONE marked forward (bench.py --pmc-forward in passes 1 / 2 of tools/run_profiles_wl.sh), condensed by tools/pmc_forward.py; a fourth
+        # field names the layer kinds (bench's per-layer table) whose algorithmic bytes the dominant kernel is priced against
+        import subprocess
+        kinds = spec.split(':')[3] if spec.count(':') >= 3 else 'convexact,csr'
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = subprocess.check_output([sys.executable, os.path.join(root, 'tools', 'pmc_forward.py'), d + '/p1', d + '/p2', d + '/forward1.json', dominant, kinds])
+        open(pre + 'traffic.json', 'wb').write(out)
     st = sorted(glob.glob(d + '/stats/**/*kernel_stats.csv', recursive=True), key=os.path.getmtime, reverse=True)      # newest first: gpurun merges runs into one directory
     if st:
         with open(pre + 'kernel_stats.csv', 'w') as f:

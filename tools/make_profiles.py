@@ -60,28 +60,10 @@ def main(R, tag, out='profiles', forwards=None):
         shutil.copy(R + '/bench_detail.json', pre + 'bench_detail.json')
     shutil.copy(R + '/stats_bench.json', pre + 'bench_under_rocprof.json')
     open(pre + 'layers.log', 'w').write(''.join(l for l in open(R + '/bench.log') if 'bench' in l))
-    (fe, wr) = (per_kernel(R + '/pmc_fetch', 'FETCH_SIZE'), per_kernel(R + '/pmc_write', 'WRITE_SIZE'))
-    if forwards is None:      # conv1_1 runs the small-K kernel exactly once per forward
-        forwards = max([len(v) for (k, v) in fe.items() if 'convtaps_smallk' in k] + [1])
-    tr = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES '
-                     'SQ_LDS_BANK_CONFLICT / TCC_HIT_sum TCC_MISS_sum) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline',
-          'units': 'FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of wide coalesced reads: MI355X_MICROARCH.md HBM section; calibrated in the '
-                   'same kind of run on kn::transpose_kernel: 147.0 MiB read -> FETCH_SIZE 73.5 MiB, WRITE_SIZE 147.0 MiB exact)',
-          'forwards_in_run': forwards, 'mode': 'tolerance', 'csrc_sha256': kernel_sources_sha(), 'kernels': {}}
-    (tot_f, tot_w) = (0.0, 0.0)
-    for k in fe:
-        if 'convtaps' not in k and 'csr_' not in k and 'dense_reduce' not in k:
-            continue
-        f_raw = sum(fe[k]) * 1024 / forwards
-        w_b = sum(wr.get(k, [0])) * 1024 / forwards
-        tr['kernels'][k[:80]] = {'launches_per_forward': len(fe[k]) // forwards, 'fetch_bytes_raw_per_forward': f_raw,
-                                 'fetch_bytes_corrected_per_forward': 2 * f_raw, 'write_bytes_per_forward': w_b}
-        if 'convtaps_mfma' in k:
-            tot_f += 2 * f_raw
-            tot_w += w_b
-    tr['convtaps_hbm_bytes_per_forward'] = tot_f + tot_w
-    tr['convtaps_fetch_corrected_per_forward'] = tot_f
-    tr['convtaps_write_per_forward'] = tot_w
+    # roofline.traffic: the launches of ONE marked forward (tools/pmc_forward.py; bench.py --pmc-forward), nothing estimated
+    tr = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, 'tools', 'pmc_forward.py'), R + '/pmc_fetch', R + '/pmc_write', R + '/forward.json']))
+    assert tr['csrc_sha256'] == kernel_sources_sha(), 'the PMC passes were taken on other kernel sources than this tree'
+    (tot_f, tot_w) = (tr['fetch_x2'], tr['write'])
     pm = {}
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(newest(R + '/pmc_mfma/runc/*counter_collection.csv'))):

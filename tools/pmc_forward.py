@@ -3,7 +3,8 @@
 `bench.py --pmc-forward FILE` (--kernel-trace --pmc FETCH_SIZE, and --pmc WRITE_SIZE; never combined with other trace domains).  The forward is cut out of the
 dispatch stream by the two torch elementwise marker kernels bench.py launches around it -- no "forwards in the run" estimate, no dispatch-order heuristics.
 
-    python3 tools/pmc_forward.py <fetch dir> <write dir> <FILE written by bench.py> [kernel substring = convtaps_mfma_kernel] > profiles/rNN_<workload>_traffic.json
+    python3 tools/pmc_forward.py <fetch dir> <write dir> <FILE written by bench.py> [kernel substring = convtaps_mfma_kernel] [layer kinds whose algorithmic bytes it is priced
+                                 against, comma-separated = convtaps,dense] > profiles/rNN_<workload>_traffic.json
 
 Units: FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads: MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
 import collections
@@ -32,7 +33,7 @@ def short(name):
     return (m.group(1) + (m.group(2) or '')) if m else name[:60]
 
 
-def main(fetch_dir, write_dir, meta_file, dominant='convtaps_mfma_kernel'):
+def main(fetch_dir, write_dir, meta_file, dominant='convtaps_mfma_kernel', kinds='convtaps,dense'):
     meta = json.load(open(meta_file))
     fetch = between_markers(fetch_dir, 'FETCH_SIZE')
     write = between_markers(write_dir, 'WRITE_SIZE')
@@ -49,7 +50,7 @@ def main(fetch_dir, write_dir, meta_file, dominant='convtaps_mfma_kernel'):
         e['write'] += wb
     dom = [l for l in launches if dominant in l['kernel']]
     alg = meta.get('algorithmic_bytes_per_forward', {})
-    alg_dom = float(alg.get('convtaps', 0.0) + alg.get('dense', 0.0)) if dominant == 'convtaps_mfma_kernel' else None
+    alg_dom = float(sum(alg.get(k, 0.0) for k in kinds.split(','))) or None
     out = {'definition': 'HBM bytes of the launches of ONE forward_linear between two marker kernels (bench.py --pmc-forward), separate --pmc FETCH_SIZE / WRITE_SIZE passes; '
                          'FETCH_SIZE x 2 (gfx950), KiB -> bytes', 'forwards_counted': 1, 'mode': meta.get('mode'), 'batch': meta.get('batch'), 'workload': meta.get('workload'),
            'csrc_sha256': meta.get('csrc_sha256'), 'dominant_kernel': dominant, 'dominant_launches': len(dom),
@@ -65,4 +66,4 @@ def main(fetch_dir, write_dir, meta_file, dominant='convtaps_mfma_kernel'):
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

@@ -14,8 +14,9 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > "$R/stats_bench.json" 2> "$R/stats_bench.log"
 rocprofv3 --kernel-trace --output-format csv -d "$R/trace" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-secondary --trace-layers "$R/layers.json" > /dev/null 2> "$R/trace.log"
 PMC_BENCH="--steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline --no-exact-leg --no-secondary"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/pmc_fetch" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_fetch.json" 2> "$R/pmc_fetch.log"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/pmc_write" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_write.json" 2> "$R/pmc_write.log"
+# roofline.traffic, ONE definition (round 6): the launches of exactly one forward between two marker kernels (bench.py --pmc-forward), FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/pmc_fetch" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-secondary --pmc-forward "$R/forward.json" > /dev/null 2> "$R/pmc_fetch.log"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$R/pmc_write" -- python3 "$REPO/bench.py" --no-cpu-baseline --no-secondary --pmc-forward "$R/forward_w.json" > /dev/null 2> "$R/pmc_write.log"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_LDS_BANK_CONFLICT --output-format csv -d "$R/pmc_mfma" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_mfma.json" 2> "$R/pmc_mfma.log"
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$R/pmc_l2" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/pmc_l2.json" 2> "$R/pmc_l2.log"
 cd "$REPO"

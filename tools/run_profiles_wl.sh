@@ -19,10 +19,12 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/stats" -- python3 "$REPO/bench.py" --workload $WL --steps $SSTEPS --warmup $SWARM --no-cpu-baseline --no-secondary --no-exact-leg $EXTRA > "$R/stats_bench.json" 2> "$R/stats_bench.log"
 rocprofv3 --kernel-trace --output-format csv -d "$R/trace" -- python3 "$REPO/bench.py" --workload $WL --no-cpu-baseline --no-secondary --trace-layers "$R/layers.json" $EXTRA > /dev/null 2> "$R/trace.log"
 PMC_BENCH="--workload $WL --steps 1 --warmup 0 --layer-iters 1 --no-cpu-baseline --no-exact-leg --no-secondary $EXTRA"
+# (passes 1 and 2 -- FETCH_SIZE, WRITE_SIZE -- run ONE marked forward: bench.py --pmc-forward, condensed by tools/pmc_forward.py into roofline.traffic)
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$R/p$i" -- python3 "$REPO/bench.py" $PMC_BENCH > "$R/p$i.json" 2> "$R/p$i.log"
+  MARK=""; if [ $i -le 2 ]; then MARK="--pmc-forward $R/forward$i.json"; fi
+  timeout 600 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$R/p$i" -- python3 "$REPO/bench.py" $PMC_BENCH $MARK > "$R/p$i.json" 2> "$R/p$i.log"
 done
 cd "$REPO"
 python3 tools/trace_layers.py "$R/trace" "$R/layers.json" > "$R/per_layer_trace.csv"
