@@ -27,7 +27,6 @@ Rank 0 prints ONE JSON line.
                 (the reference's criterion, atol 1e-3); a run that fails it raises instead of printing a number.
 """
 import argparse
-import hashlib
 import json
 import os
 import subprocess
@@ -42,14 +41,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from keynet_amd import system as ksys          # noqa: E402
 from keynet_amd import sparse as ksp           # noqa: E402
 from keynet_amd import dist as kdist           # noqa: E402
-from keynet_amd import io as kio               # noqa: E402
-from keynet_amd.layer import KeyedLayer        # noqa: E402
-from keynet_amd.models import VGG16, LeNet_AvgPool, AllConvNet   # noqa: E402
 
-from benchlegs.common import ROOT as _ROOT, log, PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, PEAK_L2_READ_GBS_MEASURED, keyed_layers, host_nnz, kernel_sources_sha   # noqa: E402,F401
+# what the timed path below calls; everything else lives in benchlegs/ (re-exported here for the tools and tests that use `bench.<name>`)
+from benchlegs.common import log, PEAK_HBM_GBS, PEAK_L2_READ_GBS_MEASURED, kernel_sources_sha                          # noqa: E402
+from benchlegs.common import PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, keyed_layers, host_nnz                        # noqa: E402,F401
 from benchlegs.workloads import build_workload                                                                          # noqa: E402,F401
 from benchlegs.shared import build_workload_shared                                                                      # noqa: E402
 from benchlegs.cpu import cpu_baseline, host_cores                                                                      # noqa: E402,F401
@@ -141,7 +138,9 @@ def main():
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=timedelta(minutes=30))   # "nccl" is RCCL on ROCm
 
-    if world > 1:
+    # (KN_BENCH_TEST_FORCE_SHARED=1 with --dist: test-only -- the hand-over protocol of benchlegs/shared.py with ONE rank, so that its collectives run on the RCCL backend of a
+    # single-GPU box: tests/test_rccl_gpu.py; never set by the driver)
+    if world > 1 or (args.dist and os.environ.get('KN_BENCH_TEST_FORCE_SHARED') == '1'):
         # N ranks: the process group first -- the ranks of a node key ONCE and hand the net on through it (benchlegs/shared.py); nothing forks at N > 1
         # (the scipy baseline is an N = 1 leg), so the GPU may be initialised before the host phase here
         assert torch.cuda.is_available(), 'bench.py needs an MI355X'

@@ -52,7 +52,8 @@ def _barrier(what):
 def build_workload_shared(name, rank, world, exact=None):
     """build_workload for the ranks of ONE node (bench contract: --nnodes=1, so rank 0 is the node's first rank).  Ranks other than 0 get net = None (only rank 0
     evaluates the plain network for the parity gate).  Returns the tuple of build_workload."""
-    if world <= 1 or not dist.is_available() or not dist.is_initialized():
+    forced = os.environ.get('KN_BENCH_TEST_FORCE_SHARED') == '1'            # test-only: run the protocol with one rank (its collectives on the RCCL backend of a single-GPU box)
+    if (world <= 1 and not forced) or not dist.is_available() or not dist.is_initialized():
         return build_workload(name, rank, exact=exact)
     out = None
     fd = -1

@@ -44,3 +44,20 @@ def test_bench_dist_flag_runs_the_rccl_path_on_one_gpu():
     assert c['ranks'] == [[0, 0]] and len(lines[0]) < 4096                 # the compact line: [rank, device_index] pairs, details in bench_detail.json
     full = json.load(open(os.path.join(ROOT, r['detail'])))
     assert full['collective']['rank0_shard_bit_equal'] is True and full['collective']['ranks'][0]['device_name']
+
+
+def test_keyed_net_handover_protocol_runs_on_the_rccl_backend():
+    """benchlegs/shared.py's hand-over (broadcast_object_list of the archive's (pid, descriptor), the polled asynchronous barrier) has only ever run on gloo with more than one
+    rank: there is no multi-GPU box in the builder's pool.  Forced with ONE rank on the real RCCL backend (KN_BENCH_TEST_FORCE_SHARED: test-only), the same calls must work --
+    rank 0 keys, writes the anonymous archive, broadcasts to itself, passes the barrier -- and the bench line must come out as usual."""
+    env = dict(os.environ, KN_BENCH_TEST_FORCE_SHARED='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'KN_BENCH_SHARE_GPU'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dist', '--workload', 'lenet', '--steps', '3', '--warmup', '1',
+                        '--layer-iters', '1', '--no-cpu-baseline', '--no-secondary'], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert 'keyed net handed to the other 0 ranks through an anonymous file' in p.stderr, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['collective']['backend'] == 'nccl' and r['parity']['ok'] and r['parity']['oracle_bit_equal'] is True
