@@ -117,7 +117,11 @@ def committed_traffic(workload, mode):
         return (None, '%s is a %s-mode pass' % (rel, t.get('mode', 'tolerance')), None)
     if t.get('csrc_sha256') != kernel_sources_sha():
         return (None, '%s was taken on other kernel sources' % rel, None)
-    return (t.get('convtaps_hbm_bytes_per_forward', t.get('dominant_hbm_bytes_per_forward')), rel, t.get('traffic_ratio'))
+    # (the pass counts EVERY launch of the dominant kernel in one forward -- for the conv-taps kernel also the split-K launches of fc6-8 and both half-batch windows of a layer: the
+    #  ratio is priced against the algorithmic bytes of exactly those launches, which the source file names)
+    return (t.get('convtaps_hbm_bytes_per_forward', t.get('dominant_hbm_bytes_per_forward')),
+            '%s (%s launches of one marked forward, %.4g algorithmic bytes)' % (rel, t.get('dominant_launches', t.get('launches_per_forward', '?')), t.get('algorithmic_bytes_dominant') or float('nan')),
+            t.get('traffic_ratio'))
 
 
 def roofline_of(table, workload, batch, mode):

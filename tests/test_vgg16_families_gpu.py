@@ -256,3 +256,47 @@ def test_directly_keyed_stochastic_net_meets_the_references_tolerance_fused_and_
     finally:
         ksp.Conv2dTiledMatrix.split_capable = offered
         knet.exact_mode(None)
+
+
+def test_one_full_size_filled_in_layer_against_the_oracle():
+    """The driver's tier sees the doubly-stochastic family on reduced nets; the full-size key-net (minutes of keying) is builder-run (profiles/r06_vgg16_stochastic_*).  This is ONE
+    layer of it at FULL size, keyed the way `Keynet(...)` keys conv5_1 of VGG-16 under test/test_keynet.py:116-129 -- input key: hierarchical permutation + doubly-stochastic
+    14 x 14 blocks + affine photometric (its inverse is dense inside the block: the fill-in), output key: the following ReLU's permutation + gain -- 512 -> 512 channels on 14 x 14
+    pixels: ~780 slots per output pixel, 4.4 terms per stored entry, 9.1e9 stored values (no CSR of it can exist).  The order-preserving kernel AS THE BENCH RUNS IT (256 columns:
+    two column tiles per wavefront; 64 columns: one) against the CPU oracle on the canonical rows of one output pixel (all 512 channels, 49.8 M stored entries), bit for bit."""
+    import time
+    from torch import nn
+    from keynet_amd import _capi
+    dev = torch.device('cuda:0')
+    common = dict(memoryorder='channel', blocksize=14, tileshape=(14, 14), alpha=2.0, beta=1.0, gamma=1.0, hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1, 2))
+    np.random.seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        (_, a_in_inv) = ksys.keygen((512, 14, 14), global_photometric='identity', local_photometric='uniform_random_affine', global_geometric='hierarchical_permutation',
+                                    local_geometric='doubly_stochastic', **common)
+        (a_out, _) = ksys.keygen((512, 14, 14), global_photometric='identity', local_photometric='uniform_random_gain', global_geometric='identity', local_geometric='permutation', **common)
+    torch.manual_seed(0)
+    layer = KeyedLayer(nn.Conv2d(512, 512, 3, padding=1), (512, 14, 14), (512, 14, 14), a_out, a_in_inv, tileshape=(14, 14), direct=True)
+    W = layer.W
+    t = W._taps
+    assert isinstance(W, ksp.Conv2dTiledMatrix) and t is not None and t['ent_coef'] is not None
+    pairs = len(np.unique(t['ent_out'].astype(np.int64) * 196 + t['ent_in']))
+    assert len(t['ent_out']) / 196.0 > 500 and len(t['ent_out']) / pairs > 3 and pairs * 512 * 512 > 8e9
+    with torch.cuda.device(dev):
+        (p256, p64) = (W._device_op(dev).plan(256, _capi.KN_FLAG_EXACT), W._device_op(dev).plan(64, _capi.KN_FLAG_EXACT))
+    assert 'convtaps_exact_fill_kernel' in p256 and 'two column tiles per wavefront' in p256 and 'convtaps_exact_fill_kernel' in p64 and 'two column tiles' not in p64, (p256, p64)
+    x = torch.randn(W.shape[1], 256, generator=torch.Generator().manual_seed(3))
+    x[-1] = 1.0
+    xd = x.to(dev)
+    y256 = W.torchdot(xd, relu=True, exact=True)
+    y64 = W.torchdot(xd[:, :64].contiguous(), relu=True, exact=True)
+    assert torch.equal(y256[:, :64], y64)                                   # the two forms agree bit for bit on the columns both computed
+    pix = np.array([int(np.argmax(np.bincount(t['ent_out'], minlength=196)))])                          # the pixel with the most slots
+    t0 = time.time()
+    M = W.rows_csr(pix)
+    cols = [0, 1, 63, 64, 129, 190, 254, 255]                               # columns of both tiles of both 128-column items
+    ref = np.maximum(oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), np.ascontiguousarray(x.numpy()[:, cols])), 0)
+    rows = np.arange(512) * 196 + int(pix[0])
+    got = y256[torch.as_tensor(rows, device=dev)][:, torch.as_tensor(cols, device=dev)].cpu().numpy()
+    assert np.array_equal(got, ref), np.abs(got - ref).max()
+    print('full-size conv5_1-like layer: %d slots per pixel at pixel %d, %d stored entries in its 512 rows, bit-equal; host expansion + oracle %.1f s' % (int(np.bincount(t['ent_out']).max()), int(pix[0]), M.nnz, time.time() - t0))
