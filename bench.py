@@ -28,12 +28,12 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
+from types import SimpleNamespace
 import os
 import subprocess
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -41,19 +41,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from keynet_amd import sparse as ksp           # noqa: E402
 from keynet_amd import dist as kdist           # noqa: E402
 
-# what the timed path below calls; everything else lives in benchlegs/ (re-exported here for the tools and tests that use `bench.<name>`)
-from benchlegs.common import log, PEAK_HBM_GBS, PEAK_L2_READ_GBS_MEASURED, kernel_sources_sha                          # noqa: E402
-from benchlegs.common import PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, keyed_layers, host_nnz                        # noqa: E402,F401
-from benchlegs.workloads import build_workload                                                                          # noqa: E402,F401
+# what the timed path below calls; everything else lives in benchlegs/
+from benchlegs.common import log, kernel_sources_sha                                                                    # noqa: E402
 from benchlegs.shared import build_workload_shared                                                                      # noqa: E402
-from benchlegs.cpu import cpu_baseline, host_cores                                                                      # noqa: E402,F401
-from benchlegs.layers import layer_table, time_layers, roofline_of, committed_traffic                                   # noqa: E402,F401
-from benchlegs.parity import exact_parity, float_key_parity, oracle_parity_csr                                          # noqa: E402
-from benchlegs.legs import run_secondary, end_to_end, collective_record                                                 # noqa: E402
-from benchlegs.line import compact_record, write_detail, DETAIL_FILE, LINE_LIMIT                                        # noqa: E402,F401
+from benchlegs.cpu import cpu_baseline                                                                                  # noqa: E402
+from benchlegs.layers import layer_table, time_layers, roofline_of, chain_roofline                                      # noqa: E402
+from benchlegs.parity import oracle_parity_csr                                                                          # noqa: E402
+from benchlegs.legs import run_secondary, collective_record                                                             # noqa: E402
+from benchlegs.sidelegs import run_side_legs                                                                            # noqa: E402
+from benchlegs.line import compact_record, write_detail, DETAIL_FILE                                                    # noqa: E402
+# re-exported for the tools and tests that use `bench.<name>`
+from benchlegs.common import PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, keyed_layers, host_nnz          # noqa: E402,F401
+from benchlegs.workloads import build_workload                                                                          # noqa: E402,F401
+from benchlegs.cpu import host_cores                                                                                    # noqa: E402,F401
+from benchlegs.layers import committed_traffic                                                                          # noqa: E402,F401
+from benchlegs.line import LINE_LIMIT                                                                                   # noqa: E402,F401
 
 
 def spawn_ranks(args):
@@ -293,39 +297,8 @@ def main():
         roof = roofline_of(table, args.workload, batch, mode)
         total_bytes = sum(r['bytes'] for r in table)
         chain = knet._chain_op(dev) if hasattr(knet, '_chain_op') else None
-        if chain is not None:
-            # the forward of this key-net is ONE launch of the whole-net kernel (csrc/kn_chain.hip): that launch is the dominant kernel.
-            # Algorithmic bytes: every operator once (8 B per stored non-zero) + activations in and out of every layer.
-            # (a launch is 37 us: 2 000 untimed launches = 75 ms bring the GPU off its idle clock, as in the timed loop; 5 + 50 launches -- 2 ms -- read 41 us)
-            for _ in range(2000):
-                knet.forward_linear(x_cipher)
-            (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(500):
-                knet.forward_linear(x_cipher)
-            e1.record()
-            torch.cuda.synchronize()
-            ch_ms = e0.elapsed_time(e1) / 500
-            ach = total_bytes / ch_ms / 1e6
-            # What really bounds it: bit-exactness with scipy forbids the FMA, so a stored non-zero costs one packed multiply and one
-            # packed add per two batch columns, 4 cycles each on one of the CU's four SIMDs; a workgroup owns 4 columns, 256 CUs run a round.
-            nnz_net = float(sum(r['nnz'] for r in table))
-            rounds = -(-((batch + 3) // 4) // 256)
-            valu_floor_ms = rounds * (nnz_net / 64.0) * 4 * 4 / 4 / 2.4e9 * 1e3
-            # ... and what it really streams (round 6): every workgroup (4 batch columns) reads the key-net's operator words from L2 once -- n_workgroups x the bytes the plan
-            # names -- against the L2 read rate all 256 CUs reach together on an L2-resident array (tools/micro/l2_read_rate.hip, profiles/r06_micro_l2_read_rate.txt)
-            import re
-            m_l2 = re.search(r'(\d+) B of operator words per workgroup', chain.plan(batch))
-            l2_bytes = float(m_l2.group(1)) * ((batch + 3) // 4) if m_l2 else None
-            roof = dict(bound='hbm', kernel=chain.plan(batch), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
-                        l2_stream_bytes_per_forward=l2_bytes, l2_read_peak_gbs_measured=PEAK_L2_READ_GBS_MEASURED,
-                        frac_of_l2_read_roof=(l2_bytes / ch_ms / 1e6 / PEAK_L2_READ_GBS_MEASURED) if l2_bytes else None,
-                        valu_floor_ms=valu_floor_ms, frac_of_valu_floor=valu_floor_ms / ch_ms,
-                        algorithmic_bytes=total_bytes, algorithmic_macs=float(sum(r['nnz'] for r in table)) * batch, ms_per_forward=ch_ms,
-                        t_mac_per_s=float(sum(r['nnz'] for r in table)) * batch / ch_ms / 1e9,
-                        launch_per_layer_ms={r['name']: round(r['ms'], 4) for r in table},
-                        note='one launch for the whole key-net, activations in LDS; launch_per_layer_ms = the seven separate kernels it replaces (KN_NO_CHAIN=1)')
+        if chain is not None:                # the forward of this key-net is ONE launch of the whole-net kernel: that launch is the dominant kernel
+            roof = chain_roofline(knet, chain, x_cipher, table, batch)
         ms_per_step = 1e3 * elapsed / args.steps
         res = {
             'metric': 'encrypted images/sec (whole node), keyed %s' % {'vgg16': 'VGG-16 224x224', 'vgg16-gain': 'VGG-16 224x224 (float keys: permutation + photometric gain)', 'vgg16-givens': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, the reference\'s test_vgg16_orthogonal)', 'vgg16-givens28': 'VGG-16 224x224 (float keys: Givens rotations + affine photometric, tile 28: the reference\'s test_vgg16_orthogonal_8)', 'vgg16-stochastic': 'VGG-16 224x224 (float keys: hierarchical permutation + doubly-stochastic blocks + affine photometric: the reference\'s test_vgg16_stochastic)', 'vgg16-slice': 'VGG-16 slice 32x32 width 8 (rehearsal workload)', 'lenet': 'LeNet_AvgPool 28x28', 'allconv': 'AllConvNet 32x32'}[args.workload],
@@ -353,129 +326,9 @@ def main():
         # an entry of res['errors'], and the line is printed from the `finally` -- a late failure (an out-of-memory in a side leg, say)
         # can no longer lose the headline.
         res['errors'] = {}
-        built_mode = None          # exact_mode(None) = back to the contract this key-net was built with (the headline's)
-
-        def leg(name, fn):
-            t0 = time.time()
-            try:
-                fn()
-            except Exception as e:
-                res['errors'][name] = '%s: %s' % (type(e).__name__, e)
-                log('[bench] leg "%s" failed: %s: %s' % (name, type(e).__name__, e))
-            log('[bench] leg "%s" took %.1f s' % (name, time.time() - t0))
-
-        def leg_contract():
-            rep = knet.contract_report()
-            if any(r['calibration'] is not None for r in rep['layers']):
-                # float-key contract (KeyedLayer._calibrate): which layers the first forward left on the matrix cores, which it moved to the
-                # order-preserving kernels so that |y - y_reference| <= 1e-5 max(1, |y|) holds, and the evidence per layer
-                res['contract'] = {'tolerance': 1e-5, 'layers_switched_to_exact': rep['switched'], 'rescreened_every_forward': bool(rep.get('rescreen', False)),
-                                   'layers': {r['name']: ({k: r['calibration'].get(k) for k in ('decided', 'bound', 'measured_mfma_vs_exact', 'tol', 'max_abs_rowsum', 'max_abs_x', 'max_abs_y')}
-                                                          if r['calibration'] is not None else {'decided': 'exact' if r['exact'] else 'mfma', 'declared': True}) for r in rep['layers']}}
-
-        def leg_slots():
-            convs = [(r['name'], r['layer'].W) for r in table if isinstance(r['layer'].W, ksp.Conv2dTiledMatrix) and r['layer'].W._taps is not None]
-            res['config']['slots_per_output_pixel'] = {n: {'mean': round(float(len(W._taps['ent_out'])) / (W._outshape[1] * W._outshape[2]), 3),
-                                                           'max': int(np.bincount(W._taps['ent_out']).max())} for (n, W) in convs}
-            res['config']['entries_carry_coefficients'] = bool(any(W._taps['ent_coef'] is not None for (n, W) in convs))
-
-        def leg_end_to_end():
-            res['end_to_end'] = end_to_end(sensor, knet, x_plain, args.steps, 1)
-
-        def leg_graph():
-            rp = knet.capture(x_cipher)
-            for _ in range(3):
-                rp(x_cipher)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                og = rp(x_cipher)
-            torch.cuda.synchronize()
-            el_g = time.perf_counter() - t0
-            res['graph'] = {'images_per_s': batch * args.steps / el_g, 'ms_per_step': 1e3 * el_g / args.steps,
-                            'bit_equal_to_eager': bool(torch.equal(og, knet.forward_linear(x_cipher))), 'what': 'the same forward replayed from ONE captured HIP graph (KeyedModel.capture)'}
-
-        def leg_bf16x3():
-            # EXPERIMENTAL (--experimental only; never the headline): the same key-net with the bf16x3 kernel as the first candidate of the
-            # float-key contract.  Each conv layer keeps it only if its result, measured against the order-preserving kernel on the
-            # calibration batch, has 4x headroom under 1e-5 * max(1, |y|).
-            try:
-                knet.exact_mode('auto-bf16x3')
-                knet.forward_linear(x_cipher)
-                torch.cuda.synchronize()
-                (el_b, out_b) = timed(1, args.steps)
-                err_b = float((out_b[:n_gate].contiguous().cpu() - y_plain).abs().max())
-                del out_b
-                table_b = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
-                rep_b = knet.contract_report()
-                res['experimental'] = {'bf16x3': {
-                    'what': 'KeyedModel.exact_mode(\'auto-bf16x3\'): f32 products emulated on the bf16 matrix pipe (three-way split of both operands, six of the nine '
-                            'cross products, f32 accumulate: KN_FLAG_BF16X3) in every conv layer whose calibration measured 4x headroom under the 1e-5 tolerance',
-                    'dtype': 'f32 emulated (3 x bf16 split, 6 of 9 cross products, f32 accumulate)',
-                    'images_per_s': batch * args.steps / el_b, 'ms_per_step': 1e3 * el_b / args.steps, 'steps': args.steps,
-                    'parity': {'vs_source_network_max_abs_err': err_b, 'ok': bool(err_b <= 1e-3),
-                               'per_layer_vs_order_preserving_kernel': {r['name']: {k: r['calibration'].get(k) for k in ('decided', 'measured_bf16x3_vs_exact', 'measured_mfma_vs_exact', 'tol')}
-                                                                        for r in rep_b['layers'] if r['calibration'] is not None and 'tol' in r['calibration']}},
-                    'layers_on_bf16x3': [r['name'] for r in rep_b['layers'] if r['exact'] == 'bf16x3'],
-                    'roofline': roofline_of(table_b, args.workload, batch, 'tolerance'),
-                    'layers_ms': {r['name']: round(r['ms'], 4) for r in table_b}}}
-            finally:
-                knet.exact_mode(built_mode)
-
-        def leg_exact():
-            # the same key-net under the bit-exact contract (north_star: "bit-exact for the permutation-only key"; the DEFAULT of a
-            # permutation-only tiled key-net -- the headline above opted into the matrix cores explicitly, config.mode says so)
-            try:
-                knet.exact_mode(True)
-                t0 = time.time()
-                knet.forward_linear(x_cipher)                    # uploads the CSR twins of fc6-8
-                torch.cuda.synchronize()
-                log('[bench exact] exact-mode operators resident + first forward in %.1f s' % (time.time() - t0))
-                (el_x, out_x) = timed(1, args.steps)
-                err_x = float((out_x[:n_gate].contiguous().cpu() - y_plain).abs().max())
-                del out_x
-                table_x = time_layers(x_cipher, layer_table(knet, batch), max(1, min(args.layer_iters, 3)))
-                for r in table_x:
-                    log('[bench exact] %-8s %-9s %8.3f ms  %7.2f T MAC/s' % (r['name'], r['kind'], r['ms'], r['nnz'] * batch / r['ms'] / 1e9))
-                par_x = exact_parity(knet, x_cipher)
-                par_x['vs_source_network_max_abs_err'] = err_x
-                par_x['ok'] = bool(par_x['ok'] and err_x <= 1e-3)
-                par_x['note'] = 'this leg samples conv1_2 and conv4_2; all 21 layers are checked the same way by tests/test_vgg16_full_gpu.py'
-                res['exact'] = {'images_per_s': batch * args.steps / el_x, 'ms_per_step': 1e3 * el_x / args.steps, 'steps': args.steps,
-                                'mode': 'KeyedModel.exact_mode(True): every layer in the reference\'s accumulation order and rounding (no FMA, no MFMA)',
-                                'roofline': roofline_of(table_x, args.workload, batch, 'exact'), 'parity': par_x,
-                                'layers_ms': {r['name']: round(r['ms'], 4) for r in table_x}}
-                if not par_x['ok']:
-                    raise AssertionError('exact-mode parity failed: %s' % json.dumps(par_x))
-            finally:
-                knet.exact_mode(built_mode)
-
-        def leg_float_key_parity():
-            res['float_key_parity'] = float_key_parity(dev)
-
-        def leg_exact_layers():
-            # float-key workloads: the layers the contract keeps in the reference's order, AS TIMED (whole batch, the key-net's own activations as input), against the CPU oracle
-            # on the canonical CSR of sampled output pixels (Conv2dTiledMatrix.rows_csr: a pixel pair hit by several taps is one stored entry, its terms summed in entry order)
-            names = tuple(r['name'] for r in knet.contract_report()['layers'] if r['exact'] is True and r['calibration'] is not None and r['calibration'].get('decided') == 'exact')
-            if names:
-                res['exact_layers_parity'] = exact_parity(knet, x_cipher, n_img=8, n_pix=1, layers=names)
-
         try:
-            single = world == 1 and replay is None
-            leg('contract', leg_contract)
-            if args.workload.startswith('vgg16'):
-                leg('slots', leg_slots)
-            if single and x_plain is not None:
-                leg('end_to_end', leg_end_to_end)
-            if args.graph_leg and single:
-                leg('graph', leg_graph)
-            if args.workload == 'vgg16' and single and not args.exact and not args.no_exact_leg:
-                leg('exact', leg_exact)
-                leg('float_key_parity', leg_float_key_parity)
-            if args.exact_layers_parity and args.workload.startswith('vgg16-') and single and not args.exact:
-                leg('exact_layers_parity', leg_exact_layers)
-            if args.experimental and args.workload.startswith('vgg16') and single and not args.exact:
-                leg('experimental_bf16x3', leg_bf16x3)
+            run_side_legs(SimpleNamespace(args=args, res=res, knet=knet, sensor=sensor, x_cipher=x_cipher, x_plain=x_plain, y_plain=y_plain, n_gate=n_gate, batch=batch, world=world,
+                                          dev=dev, table=table, timed=timed, replay=replay))
         finally:
             if not res['errors']:
                 del res['errors']

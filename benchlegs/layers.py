@@ -7,7 +7,7 @@ import torch
 
 from keynet_amd import sparse as ksp
 from keynet_amd.layer import KeyedLayer
-from .common import ROOT, PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, kernel_sources_sha
+from .common import ROOT, PEAK_F32_MFMA_TFLOPS, PEAK_VALU_NOFMA_TMACS, PEAK_HBM_GBS, PEAK_L2_READ_GBS_MEASURED, kernel_sources_sha
 
 
 def _takes_small_k_kernel(W, batch):
@@ -174,3 +174,42 @@ def roofline_of(table, workload, batch, mode):
                 note='bit-exact contract: a separately rounded f32 product and an f32 add per stored value, in the reference\'s order -- no fused multiply-add, no '
                      'accumulating matrix instruction; roof = one product + one add per lane per 2 cycles = 157.3 TFLOP/s / 4 (kernels that take their products '
                      'from K = 1 matrix instructions with a zero accumulator still pay the adds on the same lanes: DESIGN.md section 8)')
+
+
+def chain_roofline(knet, chain, x_cipher, table, batch):
+    """Roofline record of a key-net whose forward is ONE launch of the whole-net kernel (csrc/kn_chain.hip).  Algorithmic bytes: every operator once (8 B per stored
+    non-zero) + activations in and out of every layer; next to it what the kernel really streams -- the operator words once PER WORKGROUP, from L2."""
+    import re
+    total_bytes = sum(r['bytes'] for r in table)
+    # the forward of this key-net is ONE launch of the whole-net kernel (csrc/kn_chain.hip): that launch is the dominant kernel.
+    # Algorithmic bytes (SURVEY 8d): every operator once (8 B per stored non-zero) + activations in and out of every layer.
+    # (a launch is 37 us: 2 000 untimed launches = 75 ms bring the GPU off its idle clock, as in the timed loop; 5 + 50 launches -- 2 ms -- read 41 us)
+    for _ in range(2000):
+        knet.forward_linear(x_cipher)
+    (e0, e1) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(500):
+        knet.forward_linear(x_cipher)
+    e1.record()
+    torch.cuda.synchronize()
+    ch_ms = e0.elapsed_time(e1) / 500
+    ach = total_bytes / ch_ms / 1e6
+    # What really bounds it (DESIGN.md 5): bit-exactness with scipy forbids the FMA, so a stored non-zero costs one packed multiply and one
+    # packed add per two batch columns, 4 cycles each on one of the CU's four SIMDs; a workgroup owns 4 columns, 256 CUs run a round.
+    nnz_net = float(sum(r['nnz'] for r in table))
+    rounds = -(-((batch + 3) // 4) // 256)
+    valu_floor_ms = rounds * (nnz_net / 64.0) * 4 * 4 / 4 / 2.4e9 * 1e3
+    # ... and what it really streams (round 6): every workgroup (4 batch columns) reads the key-net's operator words from L2 once -- n_workgroups x the bytes the plan
+    # names -- against the L2 read rate all 256 CUs reach together on an L2-resident array (tools/micro/l2_read_rate.hip, profiles/r06_micro_l2_read_rate.txt)
+    m_l2 = re.search(r'(\d+) B of operator words per workgroup', chain.plan(batch))
+    l2_bytes = float(m_l2.group(1)) * ((batch + 3) // 4) if m_l2 else None
+    roof = dict(bound='hbm', kernel=chain.plan(batch), achieved=ach, peak=PEAK_HBM_GBS, unit='GB/s', frac=ach / PEAK_HBM_GBS, traffic=None,
+                l2_stream_bytes_per_forward=l2_bytes, l2_read_peak_gbs_measured=PEAK_L2_READ_GBS_MEASURED,
+                frac_of_l2_read_roof=(l2_bytes / ch_ms / 1e6 / PEAK_L2_READ_GBS_MEASURED) if l2_bytes else None,
+                valu_floor_ms=valu_floor_ms, frac_of_valu_floor=valu_floor_ms / ch_ms,
+                algorithmic_bytes=total_bytes, algorithmic_macs=float(sum(r['nnz'] for r in table)) * batch, ms_per_forward=ch_ms,
+                t_mac_per_s=float(sum(r['nnz'] for r in table)) * batch / ch_ms / 1e9,
+                launch_per_layer_ms={r['name']: round(r['ms'], 4) for r in table},
+                note='one launch for the whole key-net, activations in LDS; launch_per_layer_ms = the seven separate kernels it replaces (KN_NO_CHAIN=1)')
+    return roof

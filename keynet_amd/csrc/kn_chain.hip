@@ -908,7 +908,10 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
         std::stable_sort(rows_sorted.begin(), rows_sorted.end(), [&](int32_t x, int32_t y) {
             const int32_t lx = ip[(size_t)x + 1] - ip[(size_t)x], ly = ip[(size_t)y + 1] - ip[(size_t)y];
             if (lx != ly) return lx > ly;
-            return pat[(size_t)x] < pat[(size_t)y];
+            if (pat[(size_t)x] != pat[(size_t)y]) return pat[(size_t)x] < pat[(size_t)y];
+            // share: the rows of one pattern (the channels of a pixel) in a canonical order -- by their value sequences -- so that two pixels whose channels carry the same
+            // sequences form the same block whatever order the output key gave their rows (which lane of a pattern takes which of its rows changes no result)
+            return share && lx > 0 && std::memcmp(dt.data() + ip[(size_t)x], dt.data() + ip[(size_t)y], sizeof(float) * (size_t)lx) < 0;
         });
         // units = what a lane owns: R consecutive rows of the sorted order when they share a pattern (equal pattern => equal length), else one row
         std::vector<std::array<int32_t, 2>> units;

@@ -1179,6 +1179,47 @@ def test_whole_net_kernel_layout_choices_vs_oracle():
         '2 operators (1 on the thin walk -- 1 of them sequentially, 1 with column patterns in LDS), 1 with two rows per lane, 1 column pools staged a layer early')
 
 
+def test_whole_net_kernel_shares_value_sequences_between_pixels():
+    """Round 6: lanes whose rows carry the SAME value sequence read one copy (a keyed conv stores one weight sequence per output channel and border class).  Two conv-like
+    layers of identical structure -- 600 "pixels" of 8 "channels" sharing a column sequence each --: in the first every pixel carries the same 8 value sequences, its rows in a
+    DIFFERENT order per pixel (what an output permutation key does); in the second all values are distinct.  Both bit-equal to the oracle; the first asks the L2 for a fraction
+    of the second's operator words (kn_spmm_plan prints the figure)."""
+    import re
+    rng = np.random.RandomState(21)
+    (pixels, ch, nnz, cols) = (600, 8, 22, 500)
+    base_vals = rng.randn(ch, nnz).astype(np.float32)
+
+    def layer(shared_values):
+        order = rng.permutation(pixels * ch)                               # row r = (pixel, channel) in a random order: the output key
+        (ip, ix, dt) = ([0], [], [])
+        pat = [rng.randint(0, cols, size=nnz) for _ in range(pixels)]
+        perm_ch = [rng.permutation(ch) for _ in range(pixels)]
+        rows = [None] * (pixels * ch)
+        for p in range(pixels):
+            for c in range(ch):
+                rows[order[p * ch + c]] = (pat[p], base_vals[perm_ch[p][c]] if shared_values else rng.randn(nnz).astype(np.float32))
+        for (c_, v_) in rows:
+            ix.extend(int(v) for v in c_)
+            dt.extend(v_)
+            ip.append(len(ix))
+        return (np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32))
+
+    words = []
+    for shared_values in (True, False):
+        (ip, ix, dt) = layer(shared_values)
+        op = _capi.Operator.csr((pixels * ch, cols), ip, ix, dt)
+        chain = _capi.Operator.chain([op], [1])
+        plan = chain.plan(12)
+        words.append(int(re.search(r'(\d+) B of operator words per workgroup', plan).group(1)))
+        X = rng.randn(cols, 12).astype(np.float32)
+        xd = torch.as_tensor(X).to(dev())
+        yd = torch.empty((pixels * ch, 12), device=dev())
+        chain.spmm(xd.data_ptr(), 12, 12, yd.data_ptr(), 12, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+        ref = np.maximum(oracle.csr_matvecs((pixels * ch, cols), ip, ix, dt, X), 0)
+        assert np.array_equal(yd.cpu().numpy(), ref), shared_values
+    assert words[0] < 0.6 * words[1], words
+
+
 def test_whole_net_kernel_is_what_small_keynets_run(golden, monkeypatch):
     """LeNet_AvgPool (BASELINE configs[0]-[1]) takes the whole-net kernel by default; KN_NO_CHAIN=1 selects the launch-per-layer forward;
     both equal the reference's vectors bit for bit, for the golden batch, a ragged one and 1024 images."""
