@@ -203,6 +203,11 @@ int kn_spmm_screen(kn_handle_t h, const float* x_dev, int64_t ldx, int64_t n_vec
  * kn_spmm_screen does. */
 int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, float* absmax_dev, void* stream);
 
+/* Drops the side tables a conv-taps operator builds at first use (the slot records of the filled-in order-preserving kernel: 16 bytes per slot, 0.4 - 4 GB per layer of the
+ * reference's doubly-stochastic VGG-16; the bf16 planes of KN_FLAG_BF16X3).  They are rebuilt by the next kn_spmm that needs them.  No reference counterpart (memory management
+ * of this library): the host calls it for a layer whose calibration settled on a contract that does not use them.  Waits for the device; not for the hot path. */
+int kn_release_side_tables(kn_handle_t h);
+
 /* Pre-size the per-stream state kn_spmm would otherwise allocate at first use on `stream` for `n_vecs` batch columns (only a
  * kn_dense_create handle has any: its split-K partial sums), so that the first kn_spmm on that stream can be captured into a HIP graph.
  * A no-op for every other operator kind. */

@@ -20,7 +20,7 @@ KN_ABI_VERSION = 4
 
 # every symbol include/keynet_hip.h declares (tests/test_capi.py checks the header against this list)
 SYMBOLS = ['kn_abi_version', 'kn_last_error', 'kn_device_info', 'kn_csr_create', 'kn_csr_create_f64', 'kn_dtype_bits', 'kn_export_csr_f64', 'kn_spmm_f64', 'kn_tiled_create', 'kn_conv2dtiled_create',
-           'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_planes', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_spmm_plan', 'kn_relu',
+           'kn_convtaps_create', 'kn_convtaps_drop_zero_entries', 'kn_dense_create', 'kn_chain_create', 'kn_destroy', 'kn_nnz', 'kn_nnz_expanded', 'kn_shape', 'kn_export_csr', 'kn_spmm', 'kn_spmm_planes', 'kn_spmm_screen', 'kn_absmax', 'kn_reserve_workspace', 'kn_release_side_tables', 'kn_spmm_plan', 'kn_relu',
            'kn_affine_to_linear', 'kn_linear_to_affine']
 
 
@@ -72,6 +72,7 @@ def lib():
         L.kn_spmm_plan.argtypes = [p, i64, i64, i64, u32, p, i64]
         L.kn_spmm_screen.argtypes = [p, p, i64, i64, p, i64, u32, p, p]
         L.kn_spmm_planes.argtypes = [p, p, i64, i64, i64, i64, p, i64, i64, u32, p]
+        L.kn_release_side_tables.argtypes = [p]
         L.kn_absmax.argtypes = [p, i64, i64, i64, p, p]
         L.kn_reserve_workspace.argtypes = [p, i64, p]
         L.kn_relu.argtypes = [p, i64, i64, i64, p]
@@ -255,6 +256,10 @@ class Operator(object):
             return False
         check(rc)
         return True
+
+    def release_side_tables(self):
+        """kn_release_side_tables: free what the operator built lazily (filled-in slot records, bf16 planes); rebuilt at next use."""
+        check(lib().kn_release_side_tables(self._h))
 
     def plan(self, n_vecs, flags=0, ldx=None, ldy=None):
         """The kernels kn_spmm would launch for this batch width / flags (kn_spmm_plan): '; '-separated descriptions."""

@@ -1004,6 +1004,26 @@ int kn_absmax(const float* x_dev, int64_t rows, int64_t ld, int64_t n_vecs, floa
     });
 }
 
+int kn_release_side_tables(kn_handle_t h) {
+    return guarded([&]() -> int {
+    KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");
+    if (h->kind != KIND_CONVTAPS) return KN_OK;
+    std::lock_guard<std::mutex> g(h->lazy_mu);
+    int32_t* rec = __atomic_load_n(&h->ct.fill_rec, __ATOMIC_ACQUIRE);
+    uint16_t* tb = __atomic_load_n(&h->ct.tapsB, __ATOMIC_ACQUIRE);
+    if (!rec && !tb) return KN_OK;
+    int cur = -1;
+    KN_HIP(hipGetDevice(&cur));
+    KN_REQUIRE(cur == h->device, KN_ERR_INVALID, "operator was created on another HIP device than the current one");
+    KN_HIP(hipDeviceSynchronize());                               // a launch on ANY stream may still be reading the tables (rare call: a layer changed its contract)
+    __atomic_store_n(&h->ct.fill_rec, (int32_t*)nullptr, __ATOMIC_RELEASE);
+    __atomic_store_n(&h->ct.tapsB, (uint16_t*)nullptr, __ATOMIC_RELEASE);
+    if (rec) (void)hipFree(rec);
+    if (tb) (void)hipFree(tb);
+    return KN_OK;
+    });
+}
+
 int kn_reserve_workspace(kn_handle_t h, int64_t n_vecs, void* stream) {
     return guarded([&]() -> int {
     KN_REQUIRE(h != nullptr, KN_ERR_INVALID, "NULL handle");

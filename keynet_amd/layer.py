@@ -329,6 +329,10 @@ class KeyedLayer(nn.Module):
                 self._contract_record = dict(layer=self._repr, decided='split', max_abs_rowsum=asum, max_abs_x=xmax, max_abs_y=float(ys.abs().max()), tol=tol_s, bound=bound,
                                              measured_split_vs_exact=meas_s, gate_ratio=ratio_s, max_abs_diff=dmax_s, measured_on_columns=cols, measured_from_column=c0,
                                              fill_factor=W.fill_factor())
+                # the order-preserving measurement above built the operator's slot records (16 bytes per slot: 0.4 - 4 GB per layer of the doubly-stochastic VGG-16); a layer that
+                # runs split does not use them again until it is re-calibrated (round-5 advisor finding)
+                with torch.cuda.device(xt.device):
+                    W._device_op(dev).release_side_tables()
                 return ys.t()
             del ys
         y = W.torchdot(xt, relu=relu, exact=False)
