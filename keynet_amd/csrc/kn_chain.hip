@@ -98,6 +98,14 @@ struct ChainArgs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// Operator words are requested through BUFFER resources: (array base in four scalar registers) + (the lane's own 32-bit byte offset) + (a wave-uniform scalar offset: slice /
+// running quad) + immediate.  The plain pointer form `base + uniform + lane offset` is compiled to a 64-bit vector add per request (v_lshl_add_u64 + global_load ... off) --
+// two of the ~36 vector-ALU instructions of a conv quad, one of 12 of a thin quad.  A request past an array's end is inside its over-read padding, as before.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t chain_res(const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000); }
+template <typename T>
+__device__ __forceinline__ T chain_ldq(const __amdgpu_buffer_rsrc_t res, const uint32_t lane_off, const uint32_t uniform_off) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(res, lane_off, uniform_off, 0));
+}
 // Slice records are read with SCALAR loads (the address is wave-uniform): a vector load + readfirstlane makes the wavefront wait for the load where
 // the readfirstlane stands -- at the START of every slice, for records it needs two slices later (44.3 against 45.5 us per LeNet launch).
 typedef const int32_t __attribute__((address_space(4))) * chain_const_i32;
@@ -146,6 +154,13 @@ __device__ __forceinline__ float* chain_lds_base() {
 // columns -- the slice's value stream loaded once instead of twice, but 21 instead of 11 vector instructions per quad on a wavefront that is alone on its SIMD: fc1 13.3 against
 // 10.4 us, the LeNet forward 41.8 against 38.4 us (profiles/r06_lenet_chain_breakdown.txt).  The walk below is written for either.
 static constexpr int CHAIN_SEQ_WPS = 2;
+#ifndef KN_CHAIN_SEQ_DV
+#define KN_CHAIN_SEQ_DV 6        // value quads in flight per wavefront of the sequential thin walk (a multiple of 3; 9 and 12 measured: no faster -- the walk does not wait for its values)
+#endif
+#ifndef KN_CHAIN_SEQ_PRE
+#define KN_CHAIN_SEQ_PRE 4       // the wavefronts that will walk a sequential thin layer request its first KN_CHAIN_SEQ_PRE value quads BEFORE the barrier that ends the layer in front of
+                                 // it (0 = none; all six do not fit the 128 registers of 16 wavefronts per CU: two of them spill, with a wait for the data in front of the barrier)
+#endif
 static constexpr int CHAIN_D = 4, CHAIN_NP = 2;       // ring depth / next-slice quads requested early (pattern walk, one row per lane)
 static constexpr int CHAIN_D_ROWS = 2;                // ... of the general walk (what takes it are short rows of unrelated patterns -- keyed pooling: 9 entries = 3 quads -- and it
                                                       // holds a column quad per value quad: the register budget of 16 wavefronts per CU is 128)
@@ -200,12 +215,11 @@ __device__ __forceinline__ void chain_rows_pre(const ChainLayerArg& L, const int
         pre.m1 = chain_load_meta<1, false>(L, wave + NW, lane, 0);
     }
     if (!(PART & 2)) return;
-    const char* const cols_b = reinterpret_cast<const char*>(L.cols);
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const __amdgpu_buffer_rsrc_t cres = chain_res(L.cols), vres = chain_res(L.vals);
 #pragma unroll
     for (int i = 0; i < D; i++) {
-        pre.c[i] = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)i * pre.m0.cstride_b) + pre.m0.coff);
-        pre.v[i] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * (uint32_t)L.vstride)) + pre.m0.voff);
+        pre.c[i] = chain_ldq<i32x4>(cres, pre.m0.coff, (uint32_t)i * pre.m0.cstride_b);
+        pre.v[i] = chain_ldq<f32x4>(vres, pre.m0.voff, (uint32_t)i * (16u * (uint32_t)L.vstride));
     }
 }
 
@@ -215,15 +229,13 @@ __device__ __forceinline__ void chain_rows(const ChainLayerArg& L, const int out
     static_assert(NP <= D, "the next slice's early quads become the head of its ring");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
-    // Operator words are addressed as (array base, wave-uniform) + (32-bit byte offset): the slice's offset and the running quad offset are scalar,
-    // the lane's own offset is a constant of the slice -- the loads take the saddr form and the walk has no 64-bit vector address arithmetic and no
-    // clamp: a request past a slice's last quad reads the next slice's words (or the arrays' zero padding) and is never used.
-    const char* const cols_b = reinterpret_cast<const char*>(L.cols);
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    // Operator words: the slice's offset and the running quad offset are scalar, the lane's own offset is a constant of the slice (chain_ldq) -- no 64-bit vector
+    // address arithmetic and no clamp: a request past a slice's last quad reads the next slice's words (or the arrays' zero padding) and is never used.
+    const __amdgpu_buffer_rsrc_t cres = chain_res(L.cols), vres = chain_res(L.vals);
     const uint32_t vstride_b = 16u * (uint32_t)L.vstride;          // bytes between a lane's consecutive value quads (wave-uniform)
     auto fetch = [&](const ChainMeta& m, const int q, i32x4& c, f32x4& v) {
-        c = *reinterpret_cast<const i32x4*>(cols_b + (size_t)((uint32_t)q * m.cstride_b) + m.coff);
-        v = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * vstride_b) + m.voff);
+        c = chain_ldq<i32x4>(cres, m.coff, (uint32_t)q * m.cstride_b);
+        v = chain_ldq<f32x4>(vres, m.voff, (uint32_t)q * vstride_b);
     };
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     CHAIN_WSTAMP(0, false);
@@ -338,11 +350,11 @@ __device__ __forceinline__ void chain_rows_cl_pre(const ChainLayerArg& L, const 
         pre.m1 = chain_load_meta<R, true>(L, wave + NW, lane, L.stage_off);
     }
     if (!(PART & 2)) return;
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const __amdgpu_buffer_rsrc_t vres = chain_res(L.vals);
 #pragma unroll
     for (int i = 0; i < D; i++)
 #pragma unroll
-        for (int r = 0; r < R; r++) pre.v[i * R + r] = *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)i * (16u * R * (uint32_t)L.vstride)) + pre.m0.voff + 16u * r);
+        for (int r = 0; r < R; r++) pre.v[i * R + r] = chain_ldq<f32x4>(vres, pre.m0.voff + 16u * r, (uint32_t)i * (16u * R * (uint32_t)L.vstride));
 }
 
 template <bool ST, int R>
@@ -351,9 +363,9 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
     static_assert(NP <= D && D % 2 == 0, "ring handover / x double buffer");
     const int n_slices = L.n_slices;
     if (wave >= n_slices) return;
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const __amdgpu_buffer_rsrc_t vres = chain_res(L.vals);
     const uint32_t vstride_b = 16u * R * (uint32_t)L.vstride;      // bytes between a lane's consecutive value quads (wave-uniform)
-    auto ldv = [&](const ChainMeta& m, const int q, const int r) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * vstride_b) + m.voff + 16u * r); };
+    auto ldv = [&](const ChainMeta& m, const int q, const int r) { return chain_ldq<f32x4>(vres, m.voff + 16u * r, (uint32_t)q * vstride_b); };
     auto ldc = [&](const ChainMeta& m, const int q) { return *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(chain_lds) + m.coff + 16u * (uint32_t)q); };     // (the pool is padded: quads past a row's end are readable)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     ChainMeta m0 = pre.m0, m1 = pre.m1;
@@ -478,15 +490,33 @@ __device__ __forceinline__ void chain_rows_cl(const ChainLayerArg& L, const int 
 // entry, so that a wavefront's activation address is the staged entry itself (no per-read address add) and only the VALUE quads are loaded from
 // memory (the two wavefronts of a slice load the same values: with the columns also from memory that would double the texture addresser's
 // work, which is shared by the CU -- the reason an earlier two-/four-lanes-per-row variant was slower).
+// (the sequential thin walk's value requests: chain_rows_thin_seq below)
+static_assert(CHAIN_SEQ_WPS == 2, "the sequential walk is written for one pair of batch columns per wavefront");
+// value quad (trip base + i) of the lane: scalar offset = the trip's byte offset (+ 4096 for i >= 4), immediate = 1024 * (i & 3)
+__device__ __forceinline__ f32x4 chain_seq_ldq(const __amdgpu_buffer_rsrc_t vres, const uint32_t voff, const uint32_t trip_b, const int i) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vres, voff + 1024u * (uint32_t)(i & 3), trip_b + 4096u * (uint32_t)(i >> 2), 0));
+}
+
 template <int DV, bool ST, int PART>
 __device__ __forceinline__ void chain_rows_thin_pre(const ChainLayerArg& L, const int wave, const int lane, ChainPre& pre) {
     constexpr int RPS = 64;
     const int wps = L.seq_len > 0 ? CHAIN_SEQ_WPS : 2;                            // wavefronts per slice
     if (wave >= wps * L.n_slices || !(PART & 1)) return;
     const int half = wave >= L.n_slices ? 1 : 0, sl = wave - half * L.n_slices;
-    const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
     const i32x4 lm = *reinterpret_cast<const i32x4*>(reinterpret_cast<const char*>(L.lane_meta) + 16u * (uint32_t)(sl * RPS + lane));
     pre.m0.row = lm.x;
+    if (L.seq_len > 0) {
+        // every slice of a sequential layer holds ceil(seq_len / 4) quads (chain_build_layer checks it): the lane's value base needs no slice record, so the walk's first value
+        // requests do not wait for a memory round trip (the lane record is first used when the row is stored)
+        pre.m0.voff = 16u * ((uint32_t)(sl * ((L.seq_len + 3) >> 2)) * RPS + (uint32_t)lane);
+        if (KN_CHAIN_SEQ_PRE && (PART & 2)) {
+            const __amdgpu_buffer_rsrc_t vres = chain_res(L.vals);
+#pragma unroll
+            for (int i = 0; i < KN_CHAIN_SEQ_PRE; i++) pre.v[i] = chain_seq_ldq(vres, pre.m0.voff, 0u, i);
+        }
+        return;
+    }
+    const i32x4 info = *reinterpret_cast<const i32x4*>(L.slice_info + 4 * sl);
     pre.m0.nq = __builtin_amdgcn_readfirstlane(info.x);
     pre.m0.voff = 16u * ((uint32_t)__builtin_amdgcn_readfirstlane(info.z) * RPS + (uint32_t)lane);
     pre.m0.coff = (uint32_t)lm.y;
@@ -503,11 +533,11 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
     if (wave >= 2 * L.n_slices) return;
     const int half = wave >= L.n_slices ? 1 : 0;
     const int nq = pre.m0.nq;
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
+    const __amdgpu_buffer_rsrc_t vres = chain_res(L.vals);
     const uint32_t voff = pre.m0.voff;
     const int cbase = 4 * cols_off4 + half * pool + 4 * (int)pre.m0.coff;         // int index of the row's column quad 0 in the wavefront's copy (+ 4 q)
     auto ldc = [&](const int q) { return *reinterpret_cast<const i32x4*>(&reinterpret_cast<const int*>(chain_lds)[cbase + 4 * q]); };      // (the pool is padded: requests past the row's end are readable)
-    auto ldv = [&](const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + voff); };
+    auto ldv = [&](const int q) { return chain_ldq<f32x4>(vres, voff, (uint32_t)q * (16u * RPS)); };
     auto xread = [&](const i32x4& cq, f32x2 (&x)[4]) {
         x[0] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.x);
         x[1] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + cq.y);
@@ -573,72 +603,81 @@ __device__ __forceinline__ void chain_rows_thin(const ChainLayerArg& L, const in
 
 // A thin layer walked SEQUENTIALLY (round 6).  All rows of a keyed nn.Linear (but the homogeneous one) share ONE stored column sequence P.  When the layer BEFORE it writes its
 // output row f to LDS position pos(f) with pos(P_k) = k -- its lane records carry positions instead of rows, nothing else changes -- this layer's k-th activation sits at
-// seq_base + 16 k: no column quads, no staged pool, and a quad's four activations are two ds_read2_b64 at constant offsets (the compiler merges the constant-offset reads):
-// 11 vector instructions per quad instead of 15 in a walk that is bound by one wavefront's instruction issue.  Same values, same order, same separate multiply / add per
-// row: bit-identical.  The row's last 1-3 entries (len % 4) are a tail of their own: a padded quad would multiply whatever lies behind the pattern by 0.0f (NaN if it is not
-// finite).  Rows that do not share P run on other wavefronts through the general walk (ChainArgs::LX).
+// seq_base + 16 k: no column quads, no staged pool, and a quad's four activations are two ds_read2_b64 at constant offsets (the compiler merges the constant-offset reads).
+// Two wavefronts per slice, one per pair of batch columns.  Same values, same order, same separate multiply / add per row: bit-identical.  The row's last 1-3 entries
+// (len % 4) are a tail of their own: a padded quad would multiply whatever lies behind the pattern by 0.0f (NaN if it is not finite).  Rows that do not share P run on other
+// wavefronts through the general walk (ChainArgs::LX).
+//
+// What the walk costs is the serial chain of adds: a packed add issues ~15 clocks after the add it depends on, ONE other instruction between them is free, every further one
+// adds its ~4 clocks of issue, and every 64-lane dword a memory instruction returns into registers another ~4 (tools/micro/seq_walk_sched.hip).  So the arithmetic of quad k
+// is ONE block of eight instructions in which the four adds of quad k - 1's products alternate with the four multiplies of quad k,
+//     acc += p0;  p0 = v0 * x0;   acc += p1;  p1 = v1 * x1;   acc += p2;  p2 = v2 * x2;   acc += p3;  p3 = v3 * x3
+// (the same multiplies and adds in the same order per row -- products rounded, then added one by one -- but no add directly behind the add it depends on, where gfx950 wants a
+// wait state: the compiler's `s_nop 0`), and the value quads come through a buffer resource (per-lane 32-bit offset + scalar offset + immediate: no 64-bit vector add per
+// quad).  12 issued vector / memory instructions per quad instead of 18; fc1 of the LeNet 10.6 -> 8.5 us.  Dealing the two LDS reads into the gaps between the adds was
+// measured too: slower (9.8 us), as the micro-benchmark says.
 template <int DV, bool ST>
 __device__ __forceinline__ void chain_rows_thin_seq(const ChainLayerArg& L, const int out_off, const int wave, const int lane, const ChainPre& pre, unsigned long long* const ws) {
-    constexpr int RPS = 64, WPS = CHAIN_SEQ_WPS, NC = 4 / WPS;                   // NC batch columns per wavefront
+    constexpr int RPS = 64;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef float xw_t __attribute__((ext_vector_type(NC)));                     // a wavefront's share of an activation word
-    if (wave >= WPS * L.n_slices) return;
-    const int half = (WPS == 2 && wave >= L.n_slices) ? 1 : 0;
+    static_assert(16u * RPS == 1024u, "a slice's quads are 1 KiB apart");
+    static_assert(DV % 3 == 0 && KN_CHAIN_SEQ_PRE <= DV && KN_CHAIN_SEQ_PRE <= 2 * CHAIN_D, "the activation buffers rotate with period 3; part of the ring arrives in ChainPre::v");
+    if (wave >= 2 * L.n_slices) return;
+    const int half = wave >= L.n_slices ? 1 : 0;
     const int nq = L.seq_len >> 2, rem = L.seq_len & 3;                           // full quads, tail entries (wave-uniform)
-    const char* const vals_b = reinterpret_cast<const char*>(L.vals);
     const uint32_t voff = pre.m0.voff;
-    auto ldv = [&](const int q) { return *reinterpret_cast<const f32x4*>(vals_b + (size_t)((uint32_t)q * (16u * RPS)) + voff); };
+    const __amdgpu_buffer_rsrc_t vres = chain_res(L.vals);
     uint32_t xtrip = (uint32_t)L.seq_base + 8u * (uint32_t)half;                  // LDS byte address of the trip's first activation word (+ 64 per quad, + 16 per entry)
-    auto xread = [&](const uint32_t a, xw_t (&x)[4]) {
+    auto xread = [&](const uint32_t a, f32x2 (&x)[4]) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) x[e] = *reinterpret_cast<const xw_t*>(reinterpret_cast<const char*>(chain_lds) + a + 16u * (uint32_t)e);
-    };
-    f32x2 acc[NC / 2];
-#pragma unroll
-    for (int j = 0; j < NC / 2; j++) acc[j] = f32x2{0.f, 0.f};
-    auto mac1 = [&](const xw_t& xe, const f32x2 vp, const int e) {              // one stored entry: the NC columns' products, then their adds (separate rounding)
-#pragma unroll
-        for (int j = 0; j < NC / 2; j++) {
-            const f32x2 xj = {xe[2 * j], xe[2 * j + 1]};
-            const f32x2 p = (e & 1) ? chain_mul_hi(xj, vp) : chain_mul_lo(xj, vp);
-            acc[j] = acc[j] + p;
-        }
-    };
-    auto macs = [&](const xw_t (&x)[4], const f32x4& vq) {
-        const f32x2 vp[2] = {f32x2{vq.x, vq.y}, f32x2{vq.z, vq.w}};
-#pragma unroll
-        for (int e = 0; e < 4; e++) mac1(x[e], vp[e >> 1], e);
+        for (int e = 0; e < 4; e++) x[e] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(chain_lds) + a + 16u * (uint32_t)e);
     };
     f32x4 v[DV];
 #pragma unroll
-    for (int i = 0; i < DV; i++) v[i] = ldv(i);
+    for (int i = 0; i < DV; i++) v[i] = i < KN_CHAIN_SEQ_PRE ? pre.v[i] : chain_seq_ldq(vres, voff, 0u, i);   // (the first KN_CHAIN_SEQ_PRE: requested before the barrier that ended the previous layer)
     __builtin_amdgcn_sched_barrier(0);
     CHAIN_WSTAMP(2, true);
-    xw_t x[3][4];                                                                 // activations two quads ahead of the arithmetic, values DV quads ahead (as in chain_rows_thin)
+    f32x2 x[3][4];                                                                // activations two quads ahead of the arithmetic, values DV quads ahead
     xread(xtrip, x[0]);
     xread(xtrip + 64u, x[1]);
-    static_assert(DV % 3 == 0, "the activation buffers rotate with period 3");
-    auto quad = [&](const int i, const int k, const bool refill) {
+    f32x2 acc = {0.f, 0.f}, p0 = {0.f, 0.f}, p1 = {0.f, 0.f}, p2 = {0.f, 0.f}, p3 = {0.f, 0.f};      // (the first block adds +0 four times to +0: still +0)
+    uint32_t trip_b = 0;                                                          // byte offset of the trip's first value quad
+    auto quad = [&](const int i, const bool refill) {
         xread(xtrip + 64u * (uint32_t)(i + 2), x[(i + 2) % 3]);                   // quad k + 2 (reads past the pattern's end land inside LDS and are never used)
         __builtin_amdgcn_sched_barrier(0);
-        macs(x[i % 3], v[i]);
-        if (refill) v[i] = ldv(k + DV);
+        const f32x2 vlo = {v[i].x, v[i].y}, vhi = {v[i].z, v[i].w};
+        asm volatile("v_pk_add_f32 %0, %0, %1\n\t"
+                     "v_pk_mul_f32 %1, %9, %5 op_sel_hi:[0,1]\n\t"
+                     "v_pk_add_f32 %0, %0, %2\n\t"
+                     "v_pk_mul_f32 %2, %9, %6 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+                     "v_pk_add_f32 %0, %0, %3\n\t"
+                     "v_pk_mul_f32 %3, %10, %7 op_sel_hi:[0,1]\n\t"
+                     "v_pk_add_f32 %0, %0, %4\n\t"
+                     "v_pk_mul_f32 %4, %10, %8 op_sel:[1,0] op_sel_hi:[1,1]"
+                     : "+v"(acc), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+                     : "v"(x[i % 3][0]), "v"(x[i % 3][1]), "v"(x[i % 3][2]), "v"(x[i % 3][3]), "v"(vlo), "v"(vhi));
+        if (refill) v[i] = chain_seq_ldq(vres, voff, trip_b + 1024u * DV, i);
         __builtin_amdgcn_sched_barrier(0);
     };
     int q = 0;
     for (; q + DV <= nq; q += DV) {
 #pragma unroll
-        for (int i = 0; i < DV; i++) quad(i, q + i, true);
+        for (int i = 0; i < DV; i++) quad(i, true);
         xtrip += 64u * DV;
+        trip_b += 1024u * DV;
     }
     int done = 0;                                                                 // quads of the last, partial trip
 #pragma unroll
     for (int i = 0; i < DV - 1; i++) {
         if (q + i < nq) {
-            quad(i, q + i, false);
+            quad(i, false);
             done = i + 1;
         }
     }
+    acc = acc + p0;                                                               // the last full quad's products
+    acc = acc + p1;
+    acc = acc + p2;
+    acc = acc + p3;
     if (rem) {                                                                    // the pattern's last 1-3 entries: quad nq, entries e < rem only
         // (slot `done` of the ring holds quad nq's values: requested DV quads ago, or by the prologue; its activations were read two quads ago into x[done % 3] -- all three
         // buffers are indexed statically below)
@@ -648,20 +687,17 @@ __device__ __forceinline__ void chain_rows_thin_seq(const ChainLayerArg& L, cons
                 const f32x2 vp[2] = {f32x2{v[i].x, v[i].y}, f32x2{v[i].z, v[i].w}};
 #pragma unroll
                 for (int e = 0; e < 3; e++)
-                    if (e < rem) mac1(x[i % 3][e], vp[e >> 1], e);
+                    if (e < rem) acc = acc + ((e & 1) ? chain_mul_hi(x[i % 3][e], vp[e >> 1]) : chain_mul_lo(x[i % 3][e], vp[e >> 1]));      // the products, then their adds (separate rounding)
             }
         }
     }
     if (pre.m0.row >= 0) {
-#pragma unroll
-        for (int j = 0; j < NC / 2; j++) {
-            f32x2 t = acc[j];
-            if (L.relu) {                                      // torch relu: NaN stays NaN
-                t.x = (t.x < 0.0f) ? 0.0f : t.x;
-                t.y = (t.y < 0.0f) ? 0.0f : t.y;
-            }
-            *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * pre.m0.row + 2 * (half + j)]) = t;
+        f32x2 t = acc;
+        if (L.relu) {                                          // torch relu: NaN stays NaN
+            t.x = (t.x < 0.0f) ? 0.0f : t.x;
+            t.y = (t.y < 0.0f) ? 0.0f : t.y;
         }
+        *reinterpret_cast<f32x2*>(&chain_lds[out_off + 4 * pre.m0.row + 2 * half]) = t;
     }
 }
 
@@ -748,9 +784,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         const bool extra = L.seq_len > 0 && wave >= CHAIN_SEQ_WPS * L.n_slices;
         const ChainLayerArg& W = extra ? a.LX[l] : L;
         const int w = extra ? wave - CHAIN_SEQ_WPS * L.n_slices : wave;
-        if (KN_CHAIN_PRE == 0) chain_pre<ST, 3>(W, w, lane, pre);
+        const bool seq_main = KN_CHAIN_SEQ_PRE && L.seq_len > 0 && !extra && l > 0;      // (its lane record and first value quads were requested before the barrier: below)
+        if (KN_CHAIN_PRE == 0 && !seq_main) chain_pre<ST, 3>(W, w, lane, pre);
         if (KN_CHAIN_PRE == 2) chain_pre<ST, 2>(W, w, lane, pre);               // (the lane records crossed the barrier; the ring is requested here)
-        if (W.seq_len > 0) chain_rows_thin_seq<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
+        if (W.seq_len > 0) chain_rows_thin_seq<KN_CHAIN_SEQ_DV, ST>(W, out_off, w, lane, pre, ws);
         else if (W.cols_quads > 0) chain_rows_thin<KN_CHAIN_DV, ST>(W, out_off, w, lane, pre, ws);
         else if (W.cols_quads < 0 && W.rpl == 2) chain_rows_cl<ST, 2>(W, out_off, w, lane, pre, ws);
         else if (W.cols_quads < 0) chain_rows_cl<ST, 1>(W, out_off, w, lane, pre, ws);
@@ -761,6 +798,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_kernel(ChainArgs a) {
         // kind that needs fewer words, leaves unwritten is then undefined rather than the previous layer's values kept alive through the walk.)
         ChainPre nxt;
         if (KN_CHAIN_PRE && l + 1 < a.n_layers) chain_pre<ST, (KN_CHAIN_PRE == 2 ? 1 : 3)>(a.L[l + 1], wave, lane, nxt);
+        // a sequential thin layer next: its value quads depend on nothing this layer computes, and the few wavefronts that will walk it hold nothing else now
+        if (KN_CHAIN_SEQ_PRE && KN_CHAIN_PRE == 0 && l + 1 < a.n_layers && a.L[l + 1].seq_len > 0) chain_rows_thin_pre<KN_CHAIN_DV, ST, 3>(a.L[l + 1], wave, lane, pre);
         __syncthreads();
         if (KN_CHAIN_PRE) pre = nxt;
         CHAIN_WSTAMP(7, false);
@@ -1129,6 +1168,8 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
         L.early = 0;
         L.seq_len = plan.len;
         L.seq_base = in_base;
+        for (int64_t sl = 0; sl < Bm.n_slices; sl++)               // (chain_rows_thin_pre computes a slice's value base instead of loading its record)
+            if (Bm.info[(size_t)(4 * sl + 2)] != (int32_t)(sl * ((plan.len + 3) / 4)) || Bm.vstride != RPS) return KN_ERR_UNSUPPORTED;      // (cannot happen: equal rows, private copies)
         int rc = upload_built(L, Bm, CHAIN_SEQ_WPS, false);       // (columns implicit: nothing read)
         if (rc) return rc;
         if (!plan.other_rows.empty()) {

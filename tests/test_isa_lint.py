@@ -285,3 +285,30 @@ def test_matrix_instruction_results_are_read_after_the_required_wait_states(src,
         assert checked >= 100 and worst == MFMA_WAIT, (checked, worst)      # (the closest reader anywhere is a compiler-spaced one, at exactly the compiler's figure)
     else:                                                                   # the filled-in conv kernel: 8 column ends per loop body x (1 or 2) matrix instructions x 3 instantiations
         assert checked >= 30 and set(worst) == {'v_mfma_f32_32x32x1'} and worst['v_mfma_f32_32x32x1'] >= MFMA_WAIT['v_mfma_f32_32x32x1'], (checked, worst)
+
+
+# gfx950 wants a wait state between a packed f32 instruction and a vector instruction that reads its result in the very next slot (the compiler's own `s_nop 0` between two
+# dependent v_pk_add_f32).  The compiler inserts it for its own instructions, NOT inside inline asm -- and the sequential thin walk of the whole-net kernel
+# (kn_chain.hip: chain_rows_thin_seq) is one asm block of four adds with a multiply between each two.  Held by construction there; measured here for every packed instruction
+# of the kernel (straight-line neighbours; a label or branch between two instructions is a slot of its own).
+@pytest.mark.skipif(shutil.which('hipcc') is None, reason='needs hipcc')
+def test_no_packed_result_is_read_in_the_next_issue_slot_of_the_whole_net_kernel(tmp_path):
+    s = _isa('kn_chain.hip', tmp_path)
+    kernels = _kernel_bodies(s, [r'_ZN2kn12chain_kernel'])
+    assert len(kernels) == 2
+    (n_pk, n_block) = (0, 0)
+    for (name, lines) in kernels:
+        for (a, b) in zip(lines, lines[1:]):
+            if not a.startswith('v_pk_') or not b.startswith('v_'):
+                continue
+            n_pk += 1
+            dst = _regs(a.split(None, 1)[1].split(',')[0], 'v')
+            src_b = _regs(b.split(None, 1)[1].split(',', 1)[1], 'v')
+            assert not (dst & src_b), 'result of a packed instruction read in the next slot: %s: %s -> %s' % (name, a, b)
+        # the block itself is there: add, multiply, add, multiply ... on one accumulator
+        for i in range(len(lines) - 7):
+            w = lines[i:i + 8]
+            if all(x.startswith('v_pk_add_f32') for x in w[0::2]) and all(x.startswith('v_pk_mul_f32') for x in w[1::2]):
+                acc = {x.split(None, 1)[1].split(',')[0] for x in w[0::2]}
+                n_block += len(acc) == 1
+    assert n_pk > 100 and n_block >= 12, (n_pk, n_block)          # (six ring slots per kernel instance at least)
