@@ -89,6 +89,15 @@ def compact_record(res, detail_path=DETAIL_FILE):
         line['end_to_end'] = _pick(res['end_to_end'], ('images_per_s', 'ms_per_step', 'encrypt_ms', 'error'))
     if isinstance(res.get('exact_layers_parity'), dict):
         line['exact_layers_parity'] = {'bit_equal': res['exact_layers_parity'].get('ok'), 'oracle_checked_layers': [r.get('layer') for r in (res['exact_layers_parity'].get('layers') or [])]}
+    if isinstance((res.get('experimental') or {}).get('bf16x3'), dict):
+        # --experimental only, never the headline (`value` and `dtype` above are the f32 path's): f32 products emulated on the bf16 matrix pipe, per layer inside the same gate
+        e = res['experimental']['bf16x3']
+        roof = e.get('roofline') or {}
+        per = (e.get('parity') or {}).get('per_layer_vs_order_preserving_kernel') or {}
+        ratios = [v['measured_bf16x3_vs_exact'] / v['tol'] for v in per.values() if v.get('decided') == 'bf16x3' and v.get('measured_bf16x3_vs_exact') is not None and v.get('tol')]
+        line['experimental'] = {'bf16x3': {'images_per_s': e.get('images_per_s'), 'tf_equiv': roof.get('achieved'), 'frac_of_bf16_roof': roof.get('frac'),
+                                           'worst_gate_ratio': max(ratios) if ratios else None, 'layers_on': len(e.get('layers_on_bf16x3') or []),
+                                           'vs_source_network_max_abs_err': (e.get('parity') or {}).get('vs_source_network_max_abs_err')}}
     if res.get('collective') is not None:
         line['collective'] = _compact_collective(res['collective'])
     if res.get('errors'):
@@ -97,7 +106,7 @@ def compact_record(res, detail_path=DETAIL_FILE):
     line = _num(line)
     s = json.dumps(line, separators=(',', ':'))
     # belt and braces: if a pathological string still pushes the line over the limit, drop optional sections until it fits
-    for k in ('end_to_end', 'exact_layers_parity', 'contract', 'secondary', 'exact', 'errors'):
+    for k in ('experimental', 'end_to_end', 'exact_layers_parity', 'contract', 'secondary', 'exact', 'errors'):
         if len(s) < LINE_LIMIT:
             break
         line.pop(k, None)

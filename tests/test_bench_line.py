@@ -81,3 +81,16 @@ def test_non_finite_numbers_do_not_break_json():
     res['roofline']['traffic'] = float('nan')
     r = check(bench.compact_record(res))
     assert r['roofline']['traffic'] is None
+
+
+def test_experimental_leg_is_reported_beside_the_headline_never_as_it():
+    """`bench.py --experimental` (round-5 review, Next #7): the bf16x3 leg appears as experimental.bf16x3{images_per_s, tf_equiv, frac_of_bf16_roof, worst_gate_ratio,
+    layers_on}; `value` and `dtype` stay the f32 path's.  The record is a real run's (profiles/r06_vgg16_experimental_bf16x3_detail.json)."""
+    res = canned()
+    real = json.load(open(os.path.join(ROOT, 'profiles', 'r06_vgg16_experimental_bf16x3_detail.json')))
+    res['experimental'] = real['experimental']
+    r = check(bench.compact_record(res))
+    e = r['experimental']['bf16x3']
+    assert set(e) >= {'images_per_s', 'tf_equiv', 'frac_of_bf16_roof', 'worst_gate_ratio', 'layers_on'}
+    assert e['layers_on'] == 12 and 0 < e['worst_gate_ratio'] < 0.25 and 0.3 < e['frac_of_bf16_roof'] < 1
+    assert r['dtype'] == 'f32' and abs(r['value'] - res['value']) / res['value'] < 1e-5 and e['images_per_s'] != r['value']
