@@ -1123,6 +1123,18 @@ static int chain_build_layer(ChainDev* c, ChainLayerArg& L, ChainLayerArg& LX, i
             vq += nq;
         }
         B.vals.resize(B.vals.size() + (size_t)CHAIN_OVERREAD_QUADS * (size_t)std::max(B.vstride, RPS) * R * 4, 0.0f);     // requests run past a slice's (and the array's) last quad: readable, never used
+        if (share) {
+            // ... and past a BLOCK's last quad: every lane of a slice walks the slice's longest row, a short row's lane (a keyed Linear's homogeneous row in a slice of
+            // 2 000-entry rows) from its own small block on through whatever follows it, `vstride` lanes per quad.  The array must reach as far as the furthest such request
+            // (found by the fuzzer's keyed-Linear layers: a first layer of 336 rows x 2 179 entries read 2.8 MB past the end).
+            size_t reach = 0;                                                                     // in units of 16 * R bytes
+            for (int64_t s = 0; s < n_slices; s++) {
+                const size_t nq = (size_t)((s_max[(size_t)s] + 3) / 4) + (size_t)CHAIN_OVERREAD_QUADS;
+                const int real = (int)std::min<int64_t>(RPS, n_units - s * RPS);
+                for (int i = 0; i < real; i++) reach = std::max(reach, (size_t)B.lane_meta[4 * (size_t)(s * RPS + i) + 3] + nq * (size_t)B.vstride + 1);
+            }
+            if (B.vals.size() < reach * R * 4) B.vals.resize(reach * R * 4, 0.0f);
+        }
         B.pool_quads = B.colpool.size() / 4 + 3;                                           // what is staged: the patterns + the three quads a walk requests ahead
         B.colpool.resize(B.colpool.size() + (size_t)CHAIN_OVERREAD_QUADS * RPS * 4, zero_byte);
         // thin layer: two wavefronts per slice fit the workgroup, every slice on shared patterns, a walk long enough to be bound by one wavefront's

@@ -17,11 +17,12 @@ pytestmark = pytest.mark.gpu
 
 
 def fuzz_chain(n_cases, seed=12345, verbose=False):
-    """Random chains of 1 - 6 CSR operators (four row-pattern kinds, >= 1024-row layouts, ReLU flags, Inf activations, batch widths 1 .. 257) through
+    """Random chains of 1 - 6 CSR operators (five row-pattern kinds incl. keyed-Linear layers on the sequential thin walk, >= 1024-row layouts, ReLU flags, Inf activations, batch widths 1 .. 257) through
     kn_chain_create / kn_spmm against the oracle layer by layer: bit-equal incl. NaN positions.  Returns (cases run, refused, mismatches)."""
     dev = torch.device('cuda:0')
     S = torch.cuda.current_stream().cuda_stream
     (bad, refused) = (0, 0)
+    fuzz_chain.sequential_layers = 0              # (how many layers of the run took the sequential thin walk: the test asserts the fuzzer reaches it)
     rng = np.random.RandomState(seed)
     for case in range(n_cases):
         n_ops = rng.randint(1, 7)
@@ -29,11 +30,15 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
         mats = []
         for l in range(n_ops):
             (rows, cols) = (dims[l + 1], dims[l])
-            kind = rng.randint(0, 4)
+            kind = rng.randint(0, 5)
             (ip, ix, dt) = ([0], [], [])
             shared = rng.randint(0, cols, size=rng.randint(0, min(cols, 60) + 1))
+            if kind == 4:                       # a keyed nn.Linear: (nearly) all rows carry ONE sequence of distinct columns, any length (behind another layer and >= 64 long: the
+                shared = rng.permutation(cols)[:rng.randint(max(cols - 7, 1), cols + 1)]      # sequential thin walk, its tail of 1-3 entries, its odd rows on a wavefront of their own)
             for r in range(rows):
-                if kind == 0:
+                if kind == 4:
+                    c = shared if rng.rand() < 0.97 else rng.randint(0, cols, size=rng.randint(0, 4))
+                elif kind == 0:
                     c = rng.randint(0, cols, size=rng.randint(0, 12))
                 elif kind == 1:
                     if r % int(rng.randint(2, 20)) == 0:
@@ -47,6 +52,8 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
                 dt.extend(rng.randn(len(c)).astype(np.float32))
                 ip.append(len(ix))
             mats.append(((rows, cols), np.array(ip, np.int32), np.array(ix, np.int32), np.array(dt, np.float32), int(rng.randint(0, 2))))
+        if verbose:
+            print('case', case, 'dims', dims, 'relu', [m[4] for m in mats], flush=True)
         ops = [_capi.Operator.csr(m[0], m[1], m[2], m[3]) for m in mats]
         try:
             chain = _capi.Operator.chain(ops, [m[4] for m in mats])
@@ -56,6 +63,9 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
                 print('case', case, 'refused:', str(e)[:80])
             continue
         n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 33, 64, 130, 257]))
+        import re
+        m_seq = re.search(r'-- (\d+) of them sequentially', chain.plan(n))
+        fuzz_chain.sequential_layers += int(m_seq.group(1)) if m_seq else 0
         X = rng.randn(dims[0], n).astype(np.float32)
         if rng.rand() < 0.2:
             X[rng.randint(0, dims[0]), rng.randint(0, n)] = np.inf          # non-finite activations must reach exactly the reference's outputs
@@ -151,6 +161,7 @@ def fuzz_factored(n_cases, seed=777, verbose=False):
 def test_fuzz_whole_net_kernel():
     (n, refused, bad) = fuzz_chain(40)
     assert bad == 0 and refused < n // 2, (n, refused, bad)
+    assert fuzz_chain.sequential_layers >= 3, fuzz_chain.sequential_layers
 
 
 def test_fuzz_factored_untiled_route():
@@ -162,5 +173,5 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     r = fuzz_chain(cases, verbose=True) if which == 'chain' else fuzz_factored(cases, verbose=True)
-    print('%s fuzz: cases / (refused) / mismatches = %s' % (which, r))
+    print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
     sys.exit(1 if r[-1] else 0)

@@ -1177,6 +1177,11 @@ def test_whole_net_kernel_layout_choices_vs_oracle():
         '5 operators (2 on the thin walk -- 2 of them sequentially, 2 with column patterns in LDS), 2 with two rows per lane, 2 column pools staged a layer early')
     run([((1500, 257), grouped(1500, 257, 11, 13, 1), 0), ((33, 1500), dense(33, 1500), 0)],
         '2 operators (1 on the thin walk -- 1 of them sequentially, 1 with column patterns in LDS), 1 with two rows per lane, 1 column pools staged a layer early')
+    # a keyed Linear of long rows as the FIRST operator whose column pool is too large for the thin walk (two patterns of 545 quads): pattern walk with shared value blocks, and the
+    # short odd rows of its last slice walk the slice's 2 179 entries from their own one-quad blocks on through everything behind them -- the value array has to reach that far
+    # (found by the fuzzer's keyed-Linear layers in round 6: a memory access fault 2.8 MB behind the array)
+    run([((336, 2184), dense_plus(336, 2184, 9), 0), ((50, 336), dense_plus(50, 336, 1), 1)],
+        '2 operators (1 on the thin walk -- 1 of them sequentially, 1 with column patterns in LDS)')
 
 
 def test_whole_net_kernel_shares_value_sequences_between_pixels():
