@@ -1,5 +1,5 @@
 """Seeded fuzzers of the whole-net kernel and of the factored untiled conv route against the CPU oracle, as collected `-m gpu` tests with a case budget
-(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60"""
+(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200"""
 import os
 import sys
 import numpy as np
@@ -85,6 +85,182 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
     return (n_cases, refused, bad)
 
 
+def fuzz_csr(n_cases, seed=4242, verbose=False):
+    """Random structured CSR operators through SparseMatrix.torchdot (kn_spmm: loose rows, pattern groups of 2 .. 600 members incl. the pipelined / matrix-pipe grouped
+    kernels' thresholds, rows that are their group's pattern minus a few entries, a Linear-like big group, one very long row, empty rows, duplicate and unsorted columns,
+    explicit zeros) against the oracle: bit-equal incl. NaN positions, with and without ReLU, contiguous and transposed activations, batch widths 1 .. 1024.
+    Returns (cases run, mismatches)."""
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    fuzz_csr.kernels = set()
+    for case in range(n_cases):
+        n = int(rng.choice([1, 5, 33, 157, 900, 2100, 3000]))
+        n_vecs = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 31, 64, 65, 128, 130, 255, 256, 300, 512, 640, 1024]))
+        budget = int(1.5e9 // n_vecs)                                  # stored entries the oracle gets through in well under a second (~7 G multiply-adds per second)
+        rows = []
+        nnz = 0
+        while nnz < budget and len(rows) < 60000 and (len(rows) == 0 or rng.rand() < 0.93):
+            kind = rng.randint(0, 8)
+            if kind == 6 and n >= 33:                                  # very many small groups: the software-pipelined grouped kernel's regime on wide batches
+                members = int(rng.choice([4, 8, 16, 24]))
+                for _ in range(int(rng.randint(200, 3000))):
+                    pattern = rng.randint(0, n, rng.randint(1, 71)).astype(np.int32)
+                    rows.extend([pattern] * members)
+                    if rng.rand() < 0.2:
+                        rows.append(rng.randint(0, n, rng.randint(0, 12)).astype(np.int32))
+                    if sum(len(r) for r in rows[-members:]) * len(rows) // members > budget:
+                        break
+                nnz = sum(len(r) for r in rows)
+                continue
+            if kind == 7 and n >= 900 and n_vecs >= 128:               # groups of >= 96 members with long stored sequences: products on the matrix pipe
+                for _ in range(int(rng.randint(20, 140))):
+                    pattern = rng.randint(0, n, rng.randint(256, 600)).astype(np.int32)
+                    rows.extend([pattern] * int(rng.choice([96, 100, 128, 200])))
+                    if sum(len(r) for r in rows) > budget:
+                        break
+                nnz = sum(len(r) for r in rows)
+                continue
+            if kind == 0:                                              # loose rows
+                for _ in range(rng.randint(1, 80)):
+                    rows.append(rng.randint(0, n, rng.randint(0, 41)).astype(np.int32))
+            elif kind in (1, 2):                                       # a pattern group (kind 2: some members lost a few entries)
+                pattern = rng.randint(0, n, rng.randint(0, 121)).astype(np.int32)
+                for _ in range(int(rng.choice([2, 3, 7, 8, 15, 16, 17, 31, 32, 33, 64, 100, 257, 600]))):
+                    if kind == 2 and len(pattern) > 3 and rng.rand() < 0.1:
+                        rows.append(np.delete(pattern, rng.choice(len(pattern), size=rng.randint(1, 4), replace=False)))
+                    else:
+                        rows.append(pattern)
+            elif kind == 3 and n >= 2048 and nnz + 300 * n < budget:   # a keyed Linear: one big group over (nearly) all columns
+                pattern = rng.permutation(n)[:rng.randint(n - 3, n + 1)].astype(np.int32)
+                for _ in range(int(rng.choice([256, 300]))):
+                    rows.append(pattern)
+            elif kind == 4:                                            # one long row with duplicates
+                rows.append(rng.randint(0, n, rng.randint(500, 4000)).astype(np.int32))
+            else:                                                      # empty rows
+                for _ in range(rng.randint(1, 5)):
+                    rows.append(np.zeros(0, np.int32))
+            nnz = sum(len(r) for r in rows)
+        if rng.rand() < 0.5:
+            order = rng.permutation(len(rows))                         # groups scattered over the operator
+            rows = [rows[i] for i in order]
+        m = len(rows)
+        indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
+        indices = np.concatenate(rows).astype(np.int32) if nnz else np.zeros(0, np.int32)
+        data = rng.randn(len(indices)).astype(np.float32)
+        if len(data) and rng.rand() < 0.3:
+            data[rng.randint(0, len(data), size=min(len(data), 5))] = 0.0          # explicit zeros are stored entries
+        X = rng.randn(n, n_vecs).astype(np.float32)
+        if rng.rand() < 0.3:
+            for _ in range(3):
+                X[rng.randint(n), rng.randint(n_vecs)] = rng.choice([np.inf, -np.inf, np.nan])
+        relu = bool(rng.rand() < 0.5)
+        if verbose:
+            print('case', case, 'shape', (m, n), 'nnz', len(indices), 'n_vecs', n_vecs, 'relu', relu, flush=True)
+        W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
+        with np.errstate(all='ignore'):
+            ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
+            if relu:
+                ref = np.where(ref < 0, np.float32(0), ref)            # torch relu: NaN stays NaN
+        if rng.rand() < 0.5:
+            xd = torch.as_tensor(np.ascontiguousarray(X.T)).to(dev).t()           # what x_affine.t() is for a row-major batch
+        else:
+            xd = torch.as_tensor(X).to(dev)
+        got = W.torchdot(xd, relu=relu).cpu().numpy()
+        with torch.cuda.device(dev):
+            import re
+            fuzz_csr.kernels |= set(re.findall(r'(csr_\w+_kernel)', W._device_op(dev).plan(n_vecs, _capi.KN_FLAG_EXACT)))
+        if not np.array_equal(got, ref, equal_nan=True):
+            bad += 1
+            print('case', case, 'MISMATCH shape', (m, n), 'n_vecs', n_vecs, 'relu', relu, 'max', np.nanmax(np.abs(got - ref)))
+    return (n_cases, bad)
+
+
+def fuzz_convtaps(n_cases, seed=2024, verbose=False, only=None, hook=None):
+    """Random FACTORED conv operators (Conv2dTiledMatrix.fromtaps: 1 .. 25 taps, 0 .. 40 input pixels per output pixel, one or several taps per pixel pair -- the
+    filled-in key families --, unit or float coefficients, channel counts that are and are not multiples of the kernels' bundles, with and without the homogeneous
+    column) under KN_FLAG_EXACT against the oracle on the operator's canonical CSR (a pair's terms summed in entry order): bit-equal incl. NaN positions, ReLU on
+    and off, batch widths 1 .. 640; the matrix-core path of the same operator inside the float-key bound.  Returns (cases run, mismatches)."""
+    import re
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    fuzz_convtaps.kernels = set()
+    for case in range(n_cases):
+        Cin = int(rng.choice([1, 2, 3, 4, 8, 16, 17, 32, 48, 64]))
+        Cout = int(rng.choice([1, 5, 8, 16, 24, 32, 33, 64, 96, 128, 160]))
+        side = int(rng.choice([10, 10, 17, 29]))                    # (mostly small; sometimes hundreds of pixels: the wide forms of the kernels want thousands of work items)
+        (hi, wi, ho, wo) = (int(rng.randint(1, side)), int(rng.randint(1, side)), int(rng.randint(1, side)), int(rng.randint(1, side)))
+        (Pin, Pout) = (hi * wi, ho * wo)
+        ntaps = int(rng.choice([1, 2, 4, 9, 16, 17, 25]))
+        n_vecs = int(rng.choice([1, 7, 64, 65, 96, 128, 130, 200, 256, 300, 384, 512, 640]))
+        taps = (rng.randn(ntaps, Cout, Cin) / np.sqrt(max(Cin, 1))).astype(np.float32)
+        filled = rng.rand() < 0.5                                   # several taps per (output, input) pixel pair
+        max_in = int(rng.choice([1, 3, 9, 40]))
+        coef = rng.rand() < 0.5
+        (eo, ei, et, ec) = ([], [], [], [])
+        for o in range(Pout):
+            for i in rng.choice(Pin, size=rng.randint(0 if rng.rand() < 0.1 else 1, min(Pin, max_in) + 1), replace=False):
+                k = int(rng.randint(1, min(ntaps, 6) + 1)) if filled else 1
+                for t in rng.choice(ntaps, size=k, replace=False):  # entry order, not tap order
+                    eo.append(o); ei.append(int(i)); et.append(int(t)); ec.append(np.float32(1.0) if rng.rand() < 0.2 else np.float32(rng.randn()))
+        if not eo:
+            (eo, ei, et, ec) = ([0], [0], [0], [np.float32(1.0)])
+        if Cout * Cin * len(eo) * max(n_vecs, 64) > 2e9:            # keep the oracle's work and the host expansion small
+            n_vecs = 64
+        if Cout * Cin * len(eo) > 6e7:
+            continue
+        has_last = bool(rng.rand() < 0.7)
+        lastcol = None
+        if has_last:
+            lastcol = np.concatenate((rng.randn(Cout * Pout), [1.0])).astype(np.float32)
+            lastcol[rng.randint(0, Cout * Pout, size=3)] = 0.0
+        W = ksp.Conv2dTiledMatrix.fromtaps((Cin, hi, wi), (Cout, ho, wo), taps, np.array(eo, np.int32), np.array(ei, np.int32), np.array(et, np.int32),
+                                           np.array(ec, np.float32) if coef else None, lastcol)
+        X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+        if rng.rand() < 0.2:
+            X[rng.randint(0, Cin * Pin), rng.randint(n_vecs)] = rng.choice([np.inf, -np.inf, np.nan])
+        if has_last:
+            X[-1] = 1.0
+        relu = bool(rng.rand() < 0.5)
+        if only is not None and case != only:                       # (re-running ONE case of a longer run: the generator has consumed what it would have)
+            continue
+        if hook is not None:
+            hook(W, X, relu)
+        with torch.cuda.device(dev):
+            plan = W._device_op(dev).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        fuzz_convtaps.kernels |= set(re.findall(r'(convtaps_\w+_kernel(?:<[^>]*>)?)', plan))
+        if verbose:
+            print('case', case, 'Cin', Cin, 'Cout', Cout, 'pixels', (Pin, Pout), 'taps', ntaps, 'entries', len(eo), 'filled', filled, 'coef', coef, 'last', has_last, 'n_vecs', n_vecs,
+                  'relu', relu, '|', plan[:110], flush=True)
+        M = W.tosparse('csr')
+        M.sort_indices()
+        with np.errstate(all='ignore'):
+            ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+            if relu:
+                ref = np.where(ref < 0, np.float32(0), ref)
+        got = W.torchdot(torch.as_tensor(X).to(dev), relu=relu, exact=True).cpu().numpy()
+        if np.all(np.isfinite(X)):
+            # the matrix-core path of the same operator: another order of the same f32 sum -- inside 1e-5 max(1, |ref|) + 8 eps sum |w x|, element-wise
+            ym = W.torchdot(torch.as_tensor(X).to(dev), relu=relu, exact=False).cpu().numpy()
+            # (sum over the TERMS: the matrix cores add a pair's terms c_t w_t x one by one, the stored order adds the pair's rounded sum once -- with cancelling terms the
+            # merged |entry| understates what either evaluation rounds)
+            Wabs = ksp.Conv2dTiledMatrix.fromtaps((Cin, hi, wi), (Cout, ho, wo), np.abs(taps), np.array(eo, np.int32), np.array(ei, np.int32), np.array(et, np.int32),
+                                                  np.abs(np.array(ec, np.float32)) if coef else None, None if lastcol is None else np.abs(lastcol))
+            S = Wabs.tosparse('csr').astype(np.float64).dot(np.abs(X.astype(np.float64)))
+            # (8 eps: rows of this generator hold up to ~10 000 terms; the stored-order f32 sum itself sits ~5 eps sum |w x| from the f64 value on such rows, the matrix cores' as far
+            # on the other side at worst -- measured on case 194 of seed 2024, where 2 eps was exceeded by 1.7 % at one element of 369 k)
+            if not np.all(np.abs(ym.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)) + 8 * 2.0 ** -24 * S):
+                bad += 1
+                with torch.cuda.device(dev):
+                    print('case', case, 'MATRIX-CORE PATH off by', float(np.abs(ym - ref).max()), '|', W._device_op(dev).plan(n_vecs, 0)[:160])
+        if not np.array_equal(got, ref, equal_nan=True):
+            bad += 1
+            print('case', case, 'MISMATCH', 'Cin', Cin, 'Cout', Cout, 'pixels', (Pin, Pout), 'taps', ntaps, 'entries', len(eo), 'filled', filled, 'coef', coef, 'last', has_last,
+                  'n_vecs', n_vecs, 'relu', relu, 'max', np.nanmax(np.abs(got - ref)), '|', plan[:160])
+    return (n_cases, bad)
+
+
 def fuzz_factored(n_cases, seed=777, verbose=False):
     """Random untiled convs (channel counts, image sides, strides, exact-zero weights, Inf / NaN activations, batch widths) through the factored route and the
     forced 16-row big-group kernel against the oracle on the STORED CSR: bit-equal incl. NaN positions.  Returns (cases run, mismatches)."""
@@ -164,6 +340,18 @@ def test_fuzz_whole_net_kernel():
     assert fuzz_chain.sequential_layers >= 3, fuzz_chain.sequential_layers
 
 
+def test_fuzz_csr_operators():
+    (n, bad) = fuzz_csr(80)
+    assert bad == 0, (n, bad)
+    assert len(fuzz_csr.kernels) >= 3, fuzz_csr.kernels          # (the run reached several of the order-preserving CSR kernels)
+
+
+def test_fuzz_factored_conv_operators():
+    (n, bad) = fuzz_convtaps(60)
+    assert bad == 0, (n, bad)
+    assert len(fuzz_convtaps.kernels) >= 4, fuzz_convtaps.kernels
+
+
 def test_fuzz_factored_untiled_route():
     (n, bad) = fuzz_factored(24)
     assert bad == 0 and n >= 28, (n, bad)
@@ -172,6 +360,8 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = fuzz_chain(cases, verbose=True) if which == 'chain' else fuzz_factored(cases, verbose=True)
+    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'factored': fuzz_factored}[which](cases, verbose=True)
+    if which in ('csr', 'convtaps'):
+        print('kernels reached:', sorted(fuzz_csr.kernels if which == 'csr' else fuzz_convtaps.kernels))
     print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
     sys.exit(1 if r[-1] else 0)
