@@ -1,5 +1,5 @@
 """Seeded fuzzers of the whole-net kernel and of the factored untiled conv route against the CPU oracle, as collected `-m gpu` tests with a case budget
-(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200"""
+(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200"""
 import os
 import sys
 import numpy as np
@@ -148,6 +148,9 @@ def fuzz_csr(n_cases, seed=4242, verbose=False):
         indptr = np.concatenate(([0], np.cumsum([len(r) for r in rows]))).astype(np.int32)
         indices = np.concatenate(rows).astype(np.int32) if nnz else np.zeros(0, np.int32)
         data = rng.randn(len(indices)).astype(np.float32)
+        f64 = bool(rng.rand() < 0.15)                                              # a float64 operator (the challenge notebook's): float64 sums of float32 activations
+        if f64:
+            data = rng.randn(len(indices)) * np.exp(rng.uniform(-20, 20, len(indices)))
         if len(data) and rng.rand() < 0.3:
             data[rng.randint(0, len(data), size=min(len(data), 5))] = 0.0          # explicit zeros are stored entries
         X = rng.randn(n, n_vecs).astype(np.float32)
@@ -156,12 +159,12 @@ def fuzz_csr(n_cases, seed=4242, verbose=False):
                 X[rng.randint(n), rng.randint(n_vecs)] = rng.choice([np.inf, -np.inf, np.nan])
         relu = bool(rng.rand() < 0.5)
         if verbose:
-            print('case', case, 'shape', (m, n), 'nnz', len(indices), 'n_vecs', n_vecs, 'relu', relu, flush=True)
+            print('case', case, 'shape', (m, n), 'nnz', len(indices), 'n_vecs', n_vecs, 'relu', relu, 'f64' if f64 else '', flush=True)
         W = ksp.SparseMatrix(scipy.sparse.csr_matrix((data, indices, indptr), shape=(m, n)))
         with np.errstate(all='ignore'):
             ref = oracle.csr_matvecs((m, n), indptr, indices, data, X)
             if relu:
-                ref = np.where(ref < 0, np.float32(0), ref)            # torch relu: NaN stays NaN
+                ref = np.where(ref < 0, ref.dtype.type(0), ref)        # torch relu: NaN stays NaN
         if rng.rand() < 0.5:
             xd = torch.as_tensor(np.ascontiguousarray(X.T)).to(dev).t()           # what x_affine.t() is for a row-major batch
         else:
@@ -254,10 +257,67 @@ def fuzz_convtaps(n_cases, seed=2024, verbose=False, only=None, hook=None):
                 bad += 1
                 with torch.cuda.device(dev):
                     print('case', case, 'MATRIX-CORE PATH off by', float(np.abs(ym - ref).max()), '|', W._device_op(dev).plan(n_vecs, 0)[:160])
+            if filled and case % 3 == 0:
+                # the split application (spatial CSR on every input-channel plane, then a 9-slot conv on the result): a third association of the same sum
+                ys = W.torchdot(torch.as_tensor(X).to(dev), relu=relu, exact='split').cpu().numpy()
+                if not np.all(np.abs(ys.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)) + 8 * 2.0 ** -24 * S):
+                    bad += 1
+                    print('case', case, 'SPLIT APPLICATION off by', float(np.abs(ys - ref).max()))
         if not np.array_equal(got, ref, equal_nan=True):
             bad += 1
             print('case', case, 'MISMATCH', 'Cin', Cin, 'Cout', Cout, 'pixels', (Pin, Pout), 'taps', ntaps, 'entries', len(eo), 'filled', filled, 'coef', coef, 'last', has_last,
                   'n_vecs', n_vecs, 'relu', relu, 'max', np.nanmax(np.abs(got - ref)), '|', plan[:160])
+    return (n_cases, bad)
+
+
+def fuzz_tiled(n_cases, seed=99, verbose=False):
+    """Random TiledMatrix / DiagonalTiledMatrix operators (tile shapes that do and do not divide the matrix, repeated tiles, empty blocks, explicit tile structure) through
+    kn_tiled_create (expanded once on the device) against the oracle on the canonical CSR of the same matrix: bit-equal, ReLU on and off.  Returns (cases run, mismatches)."""
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    for case in range(n_cases):
+        (m, n) = (int(rng.randint(1, 700)), int(rng.randint(1, 700)))
+        (h, w) = (int(rng.randint(1, 90)), int(rng.randint(1, 90)))
+        n_vecs = int(rng.choice([1, 3, 8, 64, 65, 130, 256, 300]))
+        kind = rng.randint(0, 3)
+        if kind == 0:                                               # unstructured
+            T = scipy.sparse.random(m, n, density=float(rng.choice([0.0, 0.002, 0.02, 0.2])), format='coo', dtype=np.float32, random_state=rng)
+            W = ksp.TiledMatrix(T, (h, w))
+        elif kind == 1:                                             # a few distinct tiles repeated on a random block pattern, cropped to a shape the tile does not divide
+            tiles = [scipy.sparse.random(h, w, density=float(rng.choice([0.05, 0.3, 1.0])), format='csr', dtype=np.float32, random_state=rng) for _ in range(rng.randint(1, 4))]
+            (gb, gw) = ((m + h - 1) // h, (n + w - 1) // w)
+            rows = []
+            for _ in range(gb):
+                rows.append([tiles[rng.randint(len(tiles))] if rng.rand() < 0.4 else None for _ in range(gw)])
+            if all(t is None for r in rows for t in r):
+                rows[0][0] = tiles[0]
+            T = scipy.sparse.bmat([[t if t is not None else scipy.sparse.csr_matrix((h, w), dtype=np.float32) for t in r] for r in rows], format='csr')[:m, :n].tocoo()
+            W = ksp.TiledMatrix(T, (h, w))
+        else:                                                       # one block down the diagonal (a block key), the last position an identity corner
+            b = int(rng.randint(1, 40))
+            B = scipy.sparse.random(b, b, density=float(rng.choice([0.1, 0.5, 1.0])), format='csr', dtype=np.float32, random_state=rng)
+            if rng.rand() < 0.5:
+                B = B.toarray()                                     # dense block: every entry stored, zeros included
+            sq = int(rng.randint(1, 500))
+            W = ksp.DiagonalTiledMatrix(B, (sq, sq))
+            T = W.tosparse('coo')
+            (m, n) = W.shape
+        M = scipy.sparse.csr_matrix(T)
+        M.sum_duplicates()
+        M.sort_indices()
+        X = rng.randn(n, n_vecs).astype(np.float32)
+        relu = bool(rng.rand() < 0.5)
+        if verbose:
+            print('case', case, 'kind', kind, 'shape', (m, n), 'tile', W.tileshape(), 'nnz', M.nnz, 'n_vecs', n_vecs, flush=True)
+        with np.errstate(all='ignore'):
+            ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data.astype(np.float32), X)
+            if relu:
+                ref = np.where(ref < 0, np.float32(0), ref)
+        got = W.torchdot(torch.as_tensor(X).to(dev), relu=relu).cpu().numpy()
+        if not np.array_equal(got, ref, equal_nan=True):
+            bad += 1
+            print('case', case, 'MISMATCH kind', kind, 'shape', (m, n), 'tile', W.tileshape(), 'n_vecs', n_vecs, 'max', np.nanmax(np.abs(got - ref)))
     return (n_cases, bad)
 
 
@@ -352,6 +412,11 @@ def test_fuzz_factored_conv_operators():
     assert len(fuzz_convtaps.kernels) >= 4, fuzz_convtaps.kernels
 
 
+def test_fuzz_tiled_operators():
+    (n, bad) = fuzz_tiled(60)
+    assert bad == 0, (n, bad)
+
+
 def test_fuzz_factored_untiled_route():
     (n, bad) = fuzz_factored(24)
     assert bad == 0 and n >= 28, (n, bad)
@@ -360,7 +425,7 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'factored': fuzz_factored}[which](cases, verbose=True)
+    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'factored': fuzz_factored}[which](cases, verbose=True)
     if which in ('csr', 'convtaps'):
         print('kernels reached:', sorted(fuzz_csr.kernels if which == 'csr' else fuzz_convtaps.kernels))
     print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
