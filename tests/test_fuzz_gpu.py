@@ -1,5 +1,5 @@
 """Seeded fuzzers of the whole-net kernel and of the factored untiled conv route against the CPU oracle, as collected `-m gpu` tests with a case budget
-(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200"""
+(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200 | models 100"""
 import os
 import sys
 import numpy as np
@@ -321,6 +321,83 @@ def fuzz_tiled(n_cases, seed=99, verbose=False):
     return (n_cases, bad)
 
 
+def _random_net(rng):
+    """A random small source network in the reference's naming convention (convN / reluN / poolN, fcN behind a flatten), its input shape."""
+    from keynet_amd.models import _Chain
+    (C, side) = (int(rng.choice([1, 2, 3])), int(rng.choice([6, 8, 12, 16, 20])))
+    spec = []
+    (c, hw, k) = (C, side, 0)
+    for _ in range(rng.randint(0, 4)):
+        k += 1
+        (ks, stride, co) = (int(rng.choice([1, 3, 3, 5])), int(rng.choice([1, 1, 2])), int(rng.randint(2, 9)))
+        if hw < 3:
+            break
+        if hw % 2:
+            stride = 1                                              # (strided layers on even sides only: what the reference's Toeplitz builder supports, keynet/sparse.py:900-960)
+        spec.append(('conv%d' % k, nn.Conv2d(c, co, ks, stride=stride, padding=ks // 2)))
+        (c, hw) = (co, (hw + 2 * (ks // 2) - ks) // stride + 1)
+        if rng.rand() < 0.8:
+            spec.append(('relu%d' % k, nn.ReLU()))
+        if rng.rand() < 0.5 and hw >= 4 and hw % 2 == 0:            # (odd pooling windows only, as the reference's Toeplitz builder: keynet/sparse.py:920)
+            spec.append(('pool%d' % k, nn.AvgPool2d(3, stride=2, padding=1)))
+            hw = (hw + 2 - 3) // 2 + 1
+    feat = c * hw * hw
+    n_fc = int(rng.randint(1, 4))
+    for j in range(n_fc):
+        out = int(rng.randint(2, 150)) if j + 1 < n_fc else int(rng.randint(2, 20))
+        spec.append(('fc%d' % (j + 1), nn.Linear(feat, out)))
+        feat = out
+        if j + 1 < n_fc:
+            k += 1
+            spec.append(('relu%d' % (k + 10), nn.ReLU()))
+
+    class Net(_Chain):
+        flatten_before = 'fc1'
+
+        def __init__(self):
+            super(Net, self).__init__()
+            for (name, m) in spec:
+                setattr(self, name, m)
+    return (Net().eval(), (C, side, side), [name for (name, _) in spec])
+
+
+def fuzz_models(n_cases, seed=31337, verbose=False):
+    """Random small source networks keyed by permutations -- untiled (the whole-net kernel when it applies) or tiled (the per-layer operators, bit-exact default of
+    permutation-only keys) -- through sensor.encrypt + KeyedModel.forward on the device: the logits bit-equal to the oracle run over the key-net's exported operators
+    (keynet_amd.io -> oracle.keynet_forward), and equal to the plaintext network's within 1e-4.  Returns (cases run, mismatches)."""
+    import tempfile
+    from keynet_amd import system as ksys, io as kio
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    for case in range(n_cases):
+        torch.manual_seed(int(rng.randint(1 << 30)))
+        np.random.seed(int(rng.randint(1 << 30)))
+        (net, inshape, names) = _random_net(rng)
+        tile = int(rng.choice([0, 0, 2, 3, 4, 8]))
+        n = int(rng.choice([1, 2, 5, 8, 33, 64, 130]))
+        if verbose:
+            print('case', case, 'inshape', inshape, 'tile', tile, 'n', n, names, flush=True)
+        (sensor, knet) = ksys.PermutationKeynet(inshape, net) if tile == 0 else ksys.TiledPermutationKeynet(inshape, net, tile)
+        x = torch.randn((n,) + inshape)
+        with torch.no_grad():
+            plain = net(x).numpy()
+        xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+        y = knet.forward_linear(xc).cpu().numpy()
+        with tempfile.TemporaryDirectory() as d:
+            kio.save_keynet(knet, os.path.join(d, 'k.npz'))
+            z = np.load(os.path.join(d, 'k.npz'), allow_pickle=False)
+            with np.errstate(all='ignore'):
+                ref = oracle.keynet_forward(oracle.load_golden_layers(z), xc.cpu().numpy())
+        ok_bits = np.array_equal(y, ref)
+        ok_plain = bool(np.allclose(y[:, :plain.shape[1]], plain, atol=1e-4, rtol=1e-4))
+        if not (ok_bits and ok_plain):
+            bad += 1
+            print('case', case, 'MISMATCH bits', ok_bits, 'plain', ok_plain, 'inshape', inshape, 'tile', tile, 'n', n, names, 'max vs oracle', float(np.abs(y - ref).max()),
+                  'max vs plain', float(np.abs(y[:, :plain.shape[1]] - plain).max()))
+    return (n_cases, bad)
+
+
 def fuzz_factored(n_cases, seed=777, verbose=False):
     """Random untiled convs (channel counts, image sides, strides, exact-zero weights, Inf / NaN activations, batch widths) through the factored route and the
     forced 16-row big-group kernel against the oracle on the STORED CSR: bit-equal incl. NaN positions.  Returns (cases run, mismatches)."""
@@ -395,9 +472,9 @@ def fuzz_factored(n_cases, seed=777, verbose=False):
 
 
 def test_fuzz_whole_net_kernel():
-    (n, refused, bad) = fuzz_chain(40)
+    (n, refused, bad) = fuzz_chain(100)
     assert bad == 0 and refused < n // 2, (n, refused, bad)
-    assert fuzz_chain.sequential_layers >= 3, fuzz_chain.sequential_layers
+    assert fuzz_chain.sequential_layers >= 10, fuzz_chain.sequential_layers
 
 
 def test_fuzz_csr_operators():
@@ -407,13 +484,18 @@ def test_fuzz_csr_operators():
 
 
 def test_fuzz_factored_conv_operators():
-    (n, bad) = fuzz_convtaps(60)
+    (n, bad) = fuzz_convtaps(150)
     assert bad == 0, (n, bad)
-    assert len(fuzz_convtaps.kernels) >= 4, fuzz_convtaps.kernels
+    assert len(fuzz_convtaps.kernels) >= 6, fuzz_convtaps.kernels
 
 
 def test_fuzz_tiled_operators():
-    (n, bad) = fuzz_tiled(60)
+    (n, bad) = fuzz_tiled(150)
+    assert bad == 0, (n, bad)
+
+
+def test_fuzz_keyed_models():
+    (n, bad) = fuzz_models(60)
     assert bad == 0, (n, bad)
 
 
@@ -425,7 +507,7 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'factored': fuzz_factored}[which](cases, verbose=True)
+    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'factored': fuzz_factored}[which](cases, verbose=True)
     if which in ('csr', 'convtaps'):
         print('kernels reached:', sorted(fuzz_csr.kernels if which == 'csr' else fuzz_convtaps.kernels))
     print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
