@@ -170,6 +170,22 @@ def fuzz_csr(n_cases, seed=4242, verbose=False):
         else:
             xd = torch.as_tensor(X).to(dev)
         got = W.torchdot(xd, relu=relu).cpu().numpy()
+        if not f64 and rng.rand() < 0.4:
+            # the same product on a column WINDOW of a wider block through the C ABI (leading dimensions > n_vecs, a start column of any alignment): same bits inside the
+            # window, nothing written outside it
+            (w0, pad) = (int(rng.choice([0, 1, 2, 3, 4, 5, 8, 64])), int(rng.choice([0, 1, 3, 4, 37, 128])))
+            wide = w0 + n_vecs + pad
+            Xw = rng.randn(n, wide).astype(np.float32)
+            Xw[:, w0:w0 + n_vecs] = X
+            xw = torch.as_tensor(Xw).to(dev)
+            yw = torch.full((m, wide), -7.0, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                W._device_op(dev).spmm(xw.data_ptr() + 4 * w0, wide, n_vecs, yw.data_ptr() + 4 * w0, wide, _capi.KN_FLAG_EXACT | (_capi.KN_FLAG_RELU if relu else 0),
+                                       torch.cuda.current_stream().cuda_stream)
+            yw = yw.cpu().numpy()
+            if not (np.array_equal(yw[:, w0:w0 + n_vecs], ref, equal_nan=True) and np.all(yw[:, :w0] == -7.0) and np.all(yw[:, w0 + n_vecs:] == -7.0)):
+                bad += 1
+                print('case', case, 'WINDOW MISMATCH shape', (m, n), 'n_vecs', n_vecs, 'w0', w0, 'wide', wide)
         with torch.cuda.device(dev):
             import re
             fuzz_csr.kernels |= set(re.findall(r'(csr_\w+_kernel)', W._device_op(dev).plan(n_vecs, _capi.KN_FLAG_EXACT)))
@@ -263,6 +279,20 @@ def fuzz_convtaps(n_cases, seed=2024, verbose=False, only=None, hook=None):
                 if not np.all(np.abs(ys.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)) + 8 * 2.0 ** -24 * S):
                     bad += 1
                     print('case', case, 'SPLIT APPLICATION off by', float(np.abs(ys - ref).max()))
+        if rng.rand() < 0.4:
+            (w0, pad) = (int(rng.choice([0, 1, 2, 3, 4, 5, 8, 64])), int(rng.choice([0, 1, 3, 4, 37, 128])))
+            wide = w0 + n_vecs + pad
+            Xw = rng.randn(W.shape[1], wide).astype(np.float32)
+            Xw[:, w0:w0 + n_vecs] = X
+            xw = torch.as_tensor(Xw).to(dev)
+            yw = torch.full((W.shape[0], wide), -7.0, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                W._device_op(dev).spmm(xw.data_ptr() + 4 * w0, wide, n_vecs, yw.data_ptr() + 4 * w0, wide, _capi.KN_FLAG_EXACT | (_capi.KN_FLAG_RELU if relu else 0),
+                                       torch.cuda.current_stream().cuda_stream)
+            yw = yw.cpu().numpy()
+            if not (np.array_equal(yw[:, w0:w0 + n_vecs], ref, equal_nan=True) and np.all(yw[:, :w0] == -7.0) and np.all(yw[:, w0 + n_vecs:] == -7.0)):
+                bad += 1
+                print('case', case, 'WINDOW MISMATCH n_vecs', n_vecs, 'w0', w0, 'wide', wide, '|', plan[:120])
         if not np.array_equal(got, ref, equal_nan=True):
             bad += 1
             print('case', case, 'MISMATCH', 'Cin', Cin, 'Cout', Cout, 'pixels', (Pin, Pout), 'taps', ntaps, 'entries', len(eo), 'filled', filled, 'coef', coef, 'last', has_last,
