@@ -1,5 +1,5 @@
 """Seeded fuzzers of the whole-net kernel and of the factored untiled conv route against the CPU oracle, as collected `-m gpu` tests with a case budget
-(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200 | models 100"""
+(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200 | models 100 | dense 100"""
 import os
 import sys
 import numpy as np
@@ -428,6 +428,44 @@ def fuzz_models(n_cases, seed=31337, verbose=False):
     return (n_cases, bad)
 
 
+def fuzz_dense(n_cases, seed=555, verbose=False):
+    """Random keyed nn.Linear operators (dense block + bias column + homogeneous row, columns in a permuted stored order): the order-preserving kernels bit-equal to the
+    oracle, the split-K matrix-core GEMM of the tolerance contract (kn_dense_create, where the operator qualifies) inside the float-key bound.  Returns (cases run, mismatches)."""
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    fuzz_dense.dense_ops = 0
+    for case in range(n_cases):
+        (outs, ins) = (int(rng.randint(1, 1500)), int(rng.randint(1, 3000)))
+        n_vecs = int(rng.choice([1, 2, 4, 7, 64, 100, 128, 130, 200, 256, 512]))
+        D = np.zeros((outs + 1, ins + 1), dtype=np.float32)
+        D[:-1, :-1] = (rng.randn(outs, ins) / np.sqrt(ins)).astype(np.float32)
+        D[:-1, -1] = rng.randn(outs).astype(np.float32)
+        D[-1, -1] = 1.0
+        perm = rng.permutation(ins)
+        M = scipy.sparse.csr_matrix(D)
+        M = scipy.sparse.csr_matrix((M.data, np.where(M.indices < ins, perm[np.minimum(M.indices, ins - 1)], M.indices).astype(np.int32), M.indptr), shape=M.shape)
+        W = ksp.SparseMatrix(M)
+        X = np.vstack((rng.randn(ins, n_vecs).astype(np.float32), np.ones((1, n_vecs), np.float32)))
+        relu = bool(rng.rand() < 0.5)
+        if verbose:
+            print('case', case, 'outs', outs, 'ins', ins, 'n_vecs', n_vecs, 'relu', relu, flush=True)
+        ref = oracle.csr_matvecs(M.shape, M.indptr, M.indices, M.data, X)
+        if relu:
+            ref = np.where(ref < 0, np.float32(0), ref)
+        xd = torch.as_tensor(X).to(dev)
+        if not np.array_equal(W.torchdot(xd, relu=relu).cpu().numpy(), ref):
+            bad += 1
+            print('case', case, 'MISMATCH (stored order) outs', outs, 'ins', ins, 'n_vecs', n_vecs)
+        ym = W.torchdot(xd, relu=relu, exact=False).cpu().numpy()
+        fuzz_dense.dense_ops += W._dense_device_op() is not None
+        S = abs(M).astype(np.float64).dot(np.abs(X.astype(np.float64)))
+        if not np.all(np.abs(ym.astype(np.float64) - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref)) + 8 * 2.0 ** -24 * S):
+            bad += 1
+            print('case', case, 'MATRIX-CORE PATH off by', float(np.abs(ym - ref).max()), 'outs', outs, 'ins', ins, 'n_vecs', n_vecs)
+    return (n_cases, bad)
+
+
 def fuzz_factored(n_cases, seed=777, verbose=False):
     """Random untiled convs (channel counts, image sides, strides, exact-zero weights, Inf / NaN activations, batch widths) through the factored route and the
     forced 16-row big-group kernel against the oracle on the STORED CSR: bit-equal incl. NaN positions.  Returns (cases run, mismatches)."""
@@ -529,6 +567,11 @@ def test_fuzz_keyed_models():
     assert bad == 0, (n, bad)
 
 
+def test_fuzz_keyed_linear_operators():
+    (n, bad) = fuzz_dense(40)
+    assert bad == 0 and fuzz_dense.dense_ops >= 10, (n, bad, fuzz_dense.dense_ops)
+
+
 def test_fuzz_factored_untiled_route():
     (n, bad) = fuzz_factored(24)
     assert bad == 0 and n >= 28, (n, bad)
@@ -537,7 +580,7 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'factored': fuzz_factored}[which](cases, verbose=True)
+    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'dense': fuzz_dense, 'factored': fuzz_factored}[which](cases, verbose=True)
     if which in ('csr', 'convtaps'):
         print('kernels reached:', sorted(fuzz_csr.kernels if which == 'csr' else fuzz_convtaps.kernels))
     print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
