@@ -437,6 +437,8 @@ def fuzz_dense(n_cases, seed=555, verbose=False):
     fuzz_dense.dense_ops = 0
     for case in range(n_cases):
         (outs, ins) = (int(rng.randint(1, 1500)), int(rng.randint(1, 3000)))
+        if rng.rand() < 0.6:                                        # what the matrix-core GEMM takes: whole 256-column K chunks, enough elements
+            (outs, ins) = (int(rng.randint(66, 1500)), 256 * int(rng.randint(1, 13)))
         n_vecs = int(rng.choice([1, 2, 4, 7, 64, 100, 128, 130, 200, 256, 512]))
         D = np.zeros((outs + 1, ins + 1), dtype=np.float32)
         D[:-1, :-1] = (rng.randn(outs, ins) / np.sqrt(ins)).astype(np.float32)
