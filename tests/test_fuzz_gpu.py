@@ -186,6 +186,33 @@ def fuzz_csr(n_cases, seed=4242, verbose=False):
             if not (np.array_equal(yw[:, w0:w0 + n_vecs], ref, equal_nan=True) and np.all(yw[:, :w0] == -7.0) and np.all(yw[:, w0 + n_vecs:] == -7.0)):
                 bad += 1
                 print('case', case, 'WINDOW MISMATCH shape', (m, n), 'n_vecs', n_vecs, 'w0', w0, 'wide', wide)
+        if not f64 and m * n_vecs < 4e6 and rng.rand() < 0.3:
+            # kn_spmm_planes: the operator on several activation blocks in one launch == one kn_spmm per block (or refused: the caller loops), surroundings untouched
+            n_pl = int(rng.randint(2, 6))
+            ld = n_vecs + int(rng.choice([0, 3, 32]))
+            (xs, ys) = (n * ld + int(rng.choice([0, 4, 4 * ld])), m * ld + int(rng.choice([0, 8, 8 * ld])))
+            Xp = rng.randn(n_pl * xs + 8).astype(np.float32)
+            xp = torch.as_tensor(Xp).to(dev)
+            st = torch.cuda.current_stream().cuda_stream
+            fl = _capi.KN_FLAG_EXACT | (_capi.KN_FLAG_RELU if relu else 0)
+            (ya, yb) = (torch.full((n_pl * ys + 8,), -7.0, dtype=torch.float32, device=dev), torch.full((n_pl * ys + 8,), -7.0, dtype=torch.float32, device=dev))
+            with torch.cuda.device(dev):
+                op = W._device_op(dev)
+                took = op.spmm_planes(xp.data_ptr(), ld, xs, n_pl, n_vecs, ya.data_ptr(), ld, ys, fl, st)
+                for q in range(n_pl):
+                    op.spmm(xp.data_ptr() + 4 * q * xs, ld, n_vecs, yb.data_ptr() + 4 * q * ys, ld, fl, st)
+            if took and not bool(torch.equal(ya, yb)):
+                bad += 1
+                print('case', case, 'PLANES MISMATCH shape', (m, n), 'n_vecs', n_vecs, 'planes', n_pl, 'ld', ld)
+            if not took and not bool((ya == -7.0).all()):
+                bad += 1
+                print('case', case, 'PLANES refused but wrote', (m, n))
+            with np.errstate(all='ignore'):
+                r0 = oracle.csr_matvecs((m, n), indptr, indices, data, np.ascontiguousarray(Xp[:n * ld].reshape(n, ld)[:, :n_vecs]))
+                r0 = np.where(r0 < 0, np.float32(0), r0) if relu else r0
+            if not np.array_equal(yb.cpu().numpy()[:m * ld].reshape(m, ld)[:, :n_vecs], r0, equal_nan=True):
+                bad += 1
+                print('case', case, 'PLANE 0 differs from the oracle', (m, n), n_vecs)
         with torch.cuda.device(dev):
             import re
             fuzz_csr.kernels |= set(re.findall(r'(csr_\w+_kernel)', W._device_op(dev).plan(n_vecs, _capi.KN_FLAG_EXACT)))
