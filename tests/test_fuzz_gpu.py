@@ -1,5 +1,5 @@
 """Seeded fuzzers of the whole-net kernel and of the factored untiled conv route against the CPU oracle, as collected `-m gpu` tests with a case budget
-(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200 | models 100 | dense 100"""
+(round-5 review: they used to be scripts outside pytest).  Larger runs:  python3 tests/test_fuzz_gpu.py chain 150 | factored 60 | csr 200 | convtaps 200 | tiled 200 | models 100 | floatmodels 60 | dense 100"""
 import os
 import sys
 import numpy as np
@@ -458,6 +458,61 @@ def fuzz_dense(n_cases, seed=555, verbose=False):
     return (n_cases, bad)
 
 
+def fuzz_float_models(n_cases, seed=161803, verbose=False):
+    """Random small source networks under FLOAT key families (the reference's orthogonal family: Givens rotations + affine photometric keys; its doubly-stochastic family:
+    filled-in operators) with the library's default contract for them ('auto': every layer decides on its first batch between the matrix cores, the split application and
+    the stored order): logits against the oracle over the exported operators and against the plaintext network, a second forward bit-equal to the first, every layer's
+    decision recorded.  Returns (cases run, mismatches)."""
+    import tempfile
+    import warnings
+    from keynet_amd import system as ksys, io as kio
+    dev = torch.device('cuda:0')
+    bad = 0
+    rng = np.random.RandomState(seed)
+    fuzz_float_models.decisions = {}
+    fuzz_float_models.skipped = 0
+    stochastic = dict(tileshape=(4, 4), global_geometric='hierarchical_permutation', hierarchical_blockshape=(2, 2), hierarchical_permute_at_level=(0, 1),
+                      local_geometric='doubly_stochastic', alpha=2.0, blocksize=4, local_photometric='uniform_random_affine', beta=1.0, gamma=1.0)
+    for case in range(n_cases):
+        torch.manual_seed(int(rng.randint(1 << 30)))
+        np.random.seed(int(rng.randint(1 << 30)))
+        (net, inshape, names) = _random_net(rng, sides=(8, 16))
+        family = 'stochastic' if rng.rand() < 0.4 else 'orthogonal'
+        n = int(rng.choice([1, 4, 33, 64, 130]))
+        if verbose:
+            print('case', case, family, 'inshape', inshape, 'n', n, names, flush=True)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                (sensor, knet) = ksys.Keynet(inshape, net, **stochastic) if family == 'stochastic' else ksys.TiledOrthogonalKeynet(inshape, net, 4)
+        except (AssertionError, ValueError) as e:                  # a shape this key family does not admit (the reference asserts the same way)
+            fuzz_float_models.skipped += 1
+            if verbose:
+                print('   skipped:', type(e).__name__, str(e)[:80])
+            continue
+        x = torch.randn((n,) + inshape)
+        with torch.no_grad():
+            plain = net(x).numpy()
+        xc = sensor.fromtensor(x.to(dev)).encrypt().astensor()
+        y = knet.forward_linear(xc).cpu().numpy()
+        y2 = knet.forward_linear(xc).cpu().numpy()
+        for r in knet.contract_report()['layers']:
+            d = (r['calibration'] or {}).get('decided', 'declared exact' if r['exact'] else 'declared mfma')
+            fuzz_float_models.decisions[d] = fuzz_float_models.decisions.get(d, 0) + 1
+        with tempfile.TemporaryDirectory() as d:
+            kio.save_keynet(knet, os.path.join(d, 'k.npz'))
+            z = np.load(os.path.join(d, 'k.npz'), allow_pickle=False)
+            with np.errstate(all='ignore'):
+                ref = oracle.keynet_forward(oracle.load_golden_layers(z), xc.cpu().numpy())
+        scale = max(1.0, float(np.abs(ref).max()))
+        (e_ref, e_plain) = (float(np.abs(y - ref).max()), float(np.abs(y[:, :plain.shape[1]] - plain).max()))
+        ok = e_ref <= 1e-4 * scale and e_plain <= 1e-3 * scale and np.array_equal(y, y2)
+        if not ok:
+            bad += 1
+            print('case', case, 'MISMATCH', family, 'inshape', inshape, 'n', n, names, 'vs oracle', e_ref, 'vs plain', e_plain, 'scale', scale, 'repeatable', bool(np.array_equal(y, y2)))
+    return (n_cases, bad)
+
+
 def fuzz_factored(n_cases, seed=777, verbose=False):
     """Random untiled convs (channel counts, image sides, strides, exact-zero weights, Inf / NaN activations, batch widths) through the factored route and the
     forced 16-row big-group kernel against the oracle on the STORED CSR: bit-equal incl. NaN positions.  Returns (cases run, mismatches)."""
@@ -559,6 +614,12 @@ def test_fuzz_keyed_models():
     assert bad == 0, (n, bad)
 
 
+def test_fuzz_float_keyed_models():
+    (n, bad) = fuzz_float_models(30)
+    assert bad == 0 and fuzz_float_models.skipped < n // 2, (n, bad, fuzz_float_models.skipped)
+    assert len(fuzz_float_models.decisions) >= 2, fuzz_float_models.decisions
+
+
 def test_fuzz_keyed_linear_operators():
     (n, bad) = fuzz_dense(40)
     assert bad == 0 and fuzz_dense.dense_ops >= 10, (n, bad, fuzz_dense.dense_ops)
@@ -572,7 +633,9 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'dense': fuzz_dense, 'factored': fuzz_factored}[which](cases, verbose=True)
+    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'floatmodels': fuzz_float_models, 'dense': fuzz_dense, 'factored': fuzz_factored}[which](cases, verbose=True)
+    if which == 'floatmodels':
+        print('decisions:', fuzz_float_models.decisions, 'skipped:', fuzz_float_models.skipped)
     if which in ('csr', 'convtaps'):
         print('kernels reached:', sorted(fuzz_csr.kernels if which == 'csr' else fuzz_convtaps.kernels))
     print('%s fuzz: cases / (refused) / mismatches = %s%s' % (which, r, '; layers on the sequential thin walk: %d' % fuzz_chain.sequential_layers if which == 'chain' else ''))
