@@ -354,9 +354,9 @@ def fuzz_tiled(n_cases, seed=99, verbose=False):
         else:                                                       # one block down the diagonal (a block key), the last position an identity corner
             b = int(rng.randint(1, 40))
             B = scipy.sparse.random(b, b, density=float(rng.choice([0.1, 0.5, 1.0])), format='csr', dtype=np.float32, random_state=rng)
-            if rng.rand() < 0.5:
-                B = B.toarray()                                     # dense block: every entry stored, zeros included
             sq = int(rng.randint(1, 500))
+            if rng.rand() < 0.5 and b <= sq:                        # (an oversized DENSE block is an AttributeError in the reference too -- keynet/sparse.py:660 calls .tocsr() on it)
+                B = B.toarray()                                     # dense block: every entry stored, zeros included
             W = ksp.DiagonalTiledMatrix(B, (sq, sq))
             T = W.tosparse('coo')
             (m, n) = W.shape
@@ -633,7 +633,8 @@ def test_fuzz_factored_untiled_route():
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'chain'
     cases = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-    r = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'floatmodels': fuzz_float_models, 'dense': fuzz_dense, 'factored': fuzz_factored}[which](cases, verbose=True)
+    fn = {'chain': fuzz_chain, 'csr': fuzz_csr, 'convtaps': fuzz_convtaps, 'tiled': fuzz_tiled, 'models': fuzz_models, 'floatmodels': fuzz_float_models, 'dense': fuzz_dense, 'factored': fuzz_factored}[which]
+    r = fn(cases, verbose=True, seed=int(sys.argv[3])) if len(sys.argv) > 3 else fn(cases, verbose=True)       # (a third argument: another seed than the tier's)
     if which == 'floatmodels':
         print('decisions:', fuzz_float_models.decisions, 'skipped:', fuzz_float_models.skipped)
     if which in ('csr', 'convtaps'):
