@@ -25,7 +25,7 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
     fuzz_chain.sequential_layers = 0              # (how many layers of the run took the sequential thin walk: the test asserts the fuzzer reaches it)
     rng = np.random.RandomState(seed)
     for case in range(n_cases):
-        n_ops = rng.randint(1, 7)
+        n_ops = rng.randint(1, 7) if rng.rand() < 0.9 else rng.randint(7, 13)                    # (up to the twelve operators a chain holds)
         dims = [int(rng.randint(1, 400)) if rng.rand() < 0.8 else int(rng.randint(1024, 2600)) for _ in range(n_ops + 1)]      # (>= 1024 rows: the two-rows-per-lane layout)
         mats = []
         for l in range(n_ops):
@@ -82,6 +82,19 @@ def fuzz_chain(n_cases, seed=12345, verbose=False):
         if not np.array_equal(got, ref, equal_nan=True):
             bad += 1
             print('case', case, 'MISMATCH dims', dims, 'n', n, 'max', np.nanmax(np.abs(got - ref)))
+        if rng.rand() < 0.3:
+            # the same forward on a column window of wider arrays (leading dimensions > n, a start column of any alignment): same bits inside, nothing written outside
+            (w0, pad) = (int(rng.choice([0, 1, 2, 3, 4, 5])), int(rng.choice([0, 1, 3, 4, 9])))
+            wide = w0 + n + pad
+            Xw = rng.randn(dims[0], wide).astype(np.float32)
+            Xw[:, w0:w0 + n] = X
+            xw = torch.as_tensor(Xw).to(dev)
+            yw = torch.full((dims[-1], wide), -7.0, dtype=torch.float32, device=dev)
+            chain.spmm(xw.data_ptr() + 4 * w0, wide, n, yw.data_ptr() + 4 * w0, wide, 2, S)
+            yw = yw.cpu().numpy()
+            if not (np.array_equal(yw[:, w0:w0 + n], ref, equal_nan=True) and np.all(yw[:, :w0] == -7.0) and np.all(yw[:, w0 + n:] == -7.0)):
+                bad += 1
+                print('case', case, 'WINDOW MISMATCH dims', dims, 'n', n, 'w0', w0, 'wide', wide)
     return (n_cases, refused, bad)
 
 
