@@ -1802,3 +1802,62 @@ def test_allconvnet_identity_with_batchnorm(tiled):
     names = [n for (n, _) in knet._keynet.named_children()]
     assert 'conv3_bn' not in names and 'dropout3' not in names and 'relu3' in names
     assert isinstance(knet._keynet.relu3, KeyedLayer) and knet._keynet.relu3.iskeyedrelu()      # keyed ReLU after the folded batch norm
+
+
+def test_filled_in_handle_first_used_from_four_threads_at_once():
+    """The slot records of the filled-in order-preserving kernel are built on the device at first use (kn_conv.hip: published only once their data is in HBM -- the round-5
+    advisor's finding).  Four host threads, a stream each, call a FRESH handle at the same moment (ctypes drops the GIL inside kn_spmm), some with KN_FLAG_EXACT (fill kernel:
+    needs the records) and some on the matrix cores; kn_release_side_tables in between rounds (the next call rebuilds).  Every result equals the lone-stream result, bit for bit."""
+    import threading
+    rng = np.random.RandomState(5)
+    W = _random_convtaps(rng, 8, 64, 8, 3, 1, False, True)
+    n_vecs = 128
+    d = dev()
+    X = rng.randn(W.shape[1], n_vecs).astype(np.float32)
+    X[-1] = 1.0
+    xd = torch.as_tensor(X).to(d)
+    with torch.cuda.device(d):
+        assert 'convtaps_exact_fill_kernel' in W._device_op(d).plan(n_vecs, _capi.KN_FLAG_EXACT)
+        lone = {}
+        for fl in (_capi.KN_FLAG_EXACT, 0):
+            y = torch.empty((W.shape[0], n_vecs), device=d)
+            W._device_op(d).spmm(xd.data_ptr(), n_vecs, n_vecs, y.data_ptr(), n_vecs, fl, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            lone[fl] = y
+    for rnd in range(4):
+        W2 = copy.deepcopy(W)
+        W2._op = None
+        with torch.cuda.device(d):
+            op = W2._device_op(d)                                  # fresh handle: no side tables yet
+        streams = [torch.cuda.Stream(device=d) for _ in range(4)]
+        outs = [None] * 4
+        errs = []
+        go = threading.Barrier(4)
+
+        def work(k):
+            try:
+                with torch.cuda.device(d):
+                    fl = _capi.KN_FLAG_EXACT if k % 2 == 0 else 0
+                    go.wait()
+                    for rep in range(3):
+                        y = torch.empty((W.shape[0], n_vecs), device=d)
+                        op.spmm(xd.data_ptr(), n_vecs, n_vecs, y.data_ptr(), n_vecs, fl, streams[k].cuda_stream)
+                        outs[k] = (fl, y)
+            except Exception as e:                                 # noqa: BLE001
+                errs.append(repr(e))
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        torch.cuda.synchronize()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        assert not errs, errs
+        for (fl, y) in outs:
+            assert torch.equal(y, lone[fl]), (rnd, fl)
+        with torch.cuda.device(d):
+            op.release_side_tables()                               # (device-synchronising; the handle stays usable)
+            y = torch.empty((W.shape[0], n_vecs), device=d)
+            op.spmm(xd.data_ptr(), n_vecs, n_vecs, y.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(y, lone[_capi.KN_FLAG_EXACT])
