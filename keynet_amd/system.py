@@ -164,6 +164,17 @@ class KeyedModel(object):
         keyed = [c for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer)]
         on_dev = img_cipher.is_cuda and img_cipher.dim() == 2
         capturing = on_dev and torch.cuda.is_current_stream_capturing()
+        if on_dev and not capturing and _slots_out is None and img_cipher.shape[0] % self.BATCH_TILE and img_cipher.dtype == torch.float32 and self._has_tiled_conv(keyed):
+            # The conv-taps kernels tile the batch in 128 / 256 columns: an odd batch runs their ragged forms (VGG-16, stored order: 186 ms at 64 images, 131 ms at 192, against
+            # 72 ms at 128 and 122 ms at 256; matrix cores: 73 ms at 192 against 56 ms at 256 -- profiles/r06_vgg16_other_batches.txt).  Such a batch is padded with zero
+            # images to whole tiles, in the feature-major layout the kernels read; every image is its own column of every product, so its logits are what they are in any
+            # batch (bit for bit under the stored-order contract), and zero images raise no layer's max |x|.
+            n = img_cipher.shape[0]
+            padded = -(-n // self.BATCH_TILE) * self.BATCH_TILE
+            xp = torch.zeros((img_cipher.shape[1], padded), dtype=torch.float32, device=img_cipher.device).t()
+            xp[:n] = img_cipher.detach()
+            self._padded_forwards = getattr(self, '_padded_forwards', 0) + 1
+            return self.forward_linear(xp, overlap=overlap)[:n]
         y = None
         for _ in range(self.RESCREEN_MAX_PASSES):
             screened = set()
@@ -196,6 +207,12 @@ class KeyedModel(object):
             self.__dict__['_recalibrations'] = self.__dict__.get('_recalibrations', 0) + len(redo)
             self.__dict__.pop('_overlap_plans', None)
         return redo
+
+    BATCH_TILE = 128           # forward_linear pads a device batch of a tiled-conv key-net to whole multiples of this many images
+
+    @staticmethod
+    def _has_tiled_conv(keyed):
+        return any(isinstance(c.W, ksp.Conv2dTiledMatrix) for c in keyed)
 
     def _forward_once(self, img_cipher, overlap, slots, screened):
         """One pass over the keyed layers.  `slots` (device f32 [L + 1], zeroed) / `screened` (indices of the keyed layers whose contract

@@ -1861,3 +1861,33 @@ def test_filled_in_handle_first_used_from_four_threads_at_once():
             op.spmm(xd.data_ptr(), n_vecs, n_vecs, y.data_ptr(), n_vecs, _capi.KN_FLAG_EXACT, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
             assert torch.equal(y, lone[_capi.KN_FLAG_EXACT])
+
+
+@pytest.mark.parametrize('name', ['mini_tiled_permutation.npz', 'mini_tiled_stochastic.npz'])
+def test_odd_batches_of_a_tiled_keynet_are_padded_to_whole_tiles(golden, name):
+    """Round 6: the conv-taps kernels tile the batch in 128 / 256 columns and their ragged forms are slow (profiles/r06_vgg16_other_batches.txt), so KeyedModel.forward_linear pads
+    a device batch of a tiled-conv key-net with zero images to whole multiples of 128.  Every image is its own column: its logits are the same in any batch -- bit for bit under
+    the stored-order contract (permutation keys), inside the float-key gate otherwise --, a whole-tile batch is not padded, a host batch takes the same route."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    x = torch.as_tensor(z['x_cipher']).to(dev())
+    rng = np.random.RandomState(0)
+    big = torch.as_tensor(np.vstack([z['x_cipher'][rng.randint(0, z['x_cipher'].shape[0], size=256)]]).astype(np.float32)).to(dev())
+    knet._padded_forwards = 0
+    full = knet.forward_linear(big)
+    assert knet._padded_forwards == 0 and full.shape[0] == 256
+    exact = 'permutation' in name
+    for n in (1, 37, 130, 200):
+        before = knet._padded_forwards
+        y = knet.forward_linear(big[:n])
+        assert knet._padded_forwards == before + 1 and y.shape[0] == n
+        if exact:
+            assert torch.equal(y, full[:n]), n
+        else:
+            assert bool(torch.all((y - full[:n]).abs() <= 2e-5 + 2e-5 * full[:n].abs())), n
+    # the reference vectors still come out (batch of the golden file: not a multiple of 128 either)
+    y = knet.forward_linear(x).cpu().numpy()
+    last = z['Y.%s' % [str(n) for n in z['layer_names']][-1]]
+    assert bool(np.all(np.abs(y - last) <= 2e-5 + 2e-5 * np.abs(last)))      # (a key-net loaded from the reference's arrays runs its conv layers on the matrix cores)
+    yh = knet.forward_linear(torch.as_tensor(z['x_cipher']))       # host tensor in, host tensor out
+    assert not yh.is_cuda and np.array_equal(yh.numpy(), y)
