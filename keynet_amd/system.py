@@ -164,6 +164,11 @@ class KeyedModel(object):
         keyed = [c for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer)]
         on_dev = img_cipher.is_cuda and img_cipher.dim() == 2
         capturing = on_dev and torch.cuda.is_current_stream_capturing()
+        if (on_dev and not capturing and _slots_out is None and img_cipher.dtype == torch.float32 and img_cipher.shape[0] % self.BATCH_TILE == 0 and
+                not img_cipher.t().is_contiguous() and self._has_tiled_conv(keyed)):
+            # a row-major [N, D] batch (how a caller of the reference holds it): the kernels read feature-major memory, so the first layer would copy it anyway -- done here, once,
+            # the forward can also take its two-window overlapped form (VGG-16 at 256 images: 58.7 -> 57.0 ms, tools/layout_time.py)
+            img_cipher = img_cipher.detach().t().contiguous().t()
         if on_dev and not capturing and _slots_out is None and img_cipher.shape[0] % self.BATCH_TILE and img_cipher.dtype == torch.float32 and self._has_tiled_conv(keyed):
             # The conv-taps kernels tile the batch in 128 / 256 columns: an odd batch runs their ragged forms (VGG-16, stored order: 186 ms at 64 images, 131 ms at 192, against
             # 72 ms at 128 and 122 ms at 256; matrix cores: 73 ms at 192 against 56 ms at 256 -- profiles/r06_vgg16_other_batches.txt).  Such a batch is padded with zero
