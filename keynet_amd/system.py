@@ -164,6 +164,22 @@ class KeyedModel(object):
         keyed = [c for c in self._keynet.children() if isinstance(c, klayer.KeyedLayer)]
         on_dev = img_cipher.is_cuda and img_cipher.dim() == 2
         capturing = on_dev and torch.cuda.is_current_stream_capturing()
+        if on_dev and not capturing and _slots_out is None and img_cipher.dtype == torch.float32 and self._has_tiled_conv(keyed):
+            # The fast loaders address an activation block with 32-bit element offsets: a layer of R rows takes them while R x N < 2^31.  VGG-16's conv1_2 (3.2 M rows) leaves
+            # them at 1 024 images -- 113.7 ms in the stored order against 2 x 31 ms for two passes of 512 (profiles/r06_vgg16_other_batches.txt) -- so a batch that large runs
+            # as passes of the largest multiple of 256 images that keeps every layer inside.
+            big = max(max(c.W.shape) for c in keyed)
+            chunk = (self.MAX_BLOCK_ELEMENTS - 1) // big // 256 * 256
+            if 0 < chunk < img_cipher.shape[0]:
+                n = img_cipher.shape[0]
+                self._chunked_forwards = getattr(self, '_chunked_forwards', 0) + 1
+                outs = []
+                for lo in range(0, n, chunk):
+                    part = img_cipher[lo:lo + chunk]
+                    if img_cipher.t().is_contiguous():             # (a window of feature-major memory: its own feature-major block, so that a pass takes the overlapped form)
+                        part = part.detach().t().contiguous().t()
+                    outs.append(self.forward_linear(part, overlap=overlap))
+                return torch.cat(outs, dim=0)
         if (on_dev and not capturing and _slots_out is None and img_cipher.dtype == torch.float32 and img_cipher.shape[0] % self.BATCH_TILE == 0 and
                 not img_cipher.t().is_contiguous() and self._has_tiled_conv(keyed)):
             # a row-major [N, D] batch (how a caller of the reference holds it): the kernels read feature-major memory, so the first layer would copy it anyway -- done here, once,
@@ -214,6 +230,7 @@ class KeyedModel(object):
         return redo
 
     BATCH_TILE = 128           # forward_linear pads a device batch of a tiled-conv key-net to whole multiples of this many images
+    MAX_BLOCK_ELEMENTS = 1 << 31   # ... and splits a batch whose largest layer would hold this many activations or more into passes
 
     @staticmethod
     def _has_tiled_conv(keyed):

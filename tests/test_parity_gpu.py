@@ -1891,3 +1891,27 @@ def test_odd_batches_of_a_tiled_keynet_are_padded_to_whole_tiles(golden, name):
     assert bool(np.all(np.abs(y - last) <= 2e-5 + 2e-5 * np.abs(last)))      # (a key-net loaded from the reference's arrays runs its conv layers on the matrix cores)
     yh = knet.forward_linear(torch.as_tensor(z['x_cipher']))       # host tensor in, host tensor out
     assert not yh.is_cuda and np.array_equal(yh.numpy(), y)
+
+
+def test_a_batch_too_large_for_32_bit_offsets_runs_in_passes(golden):
+    """Round 6: a layer's fast loaders take an activation block of fewer than 2^31 elements; KeyedModel.forward_linear runs a larger batch as passes of whole 256-image tiles
+    (VGG-16 in the stored order at 1 024 images: conv1_2 113.7 ms -> 2 x 31 ms).  Here the limit is lowered so that the mini-net's 600 images take three passes: same logits,
+    bit for bit, as the one-pass forward; feature-major and row-major batches."""
+    z = golden('mini_tiled_permutation.npz')
+    knet = kio.keynet_from_arrays(z)
+    rng = np.random.RandomState(1)
+    X = z['x_cipher'][rng.randint(0, z['x_cipher'].shape[0], size=600)].astype(np.float32)
+    xr = torch.as_tensor(X).to(dev())                               # row-major
+    xf = torch.as_tensor(np.ascontiguousarray(X.T)).to(dev()).t()   # feature-major memory
+    one = knet.forward_linear(xf)
+    assert getattr(knet, '_chunked_forwards', 0) == 0
+    big = max(max(c.W.shape) for c in knet._keynet.children() if hasattr(c, 'W'))
+    knet.MAX_BLOCK_ELEMENTS = big * 256 + 1                         # passes of 256 images
+    try:
+        for x in (xf, xr):
+            before = getattr(knet, '_chunked_forwards', 0)
+            y = knet.forward_linear(x)
+            assert knet._chunked_forwards == before + 1 and y.shape == one.shape
+            assert torch.equal(y, one)
+    finally:
+        del knet.MAX_BLOCK_ELEMENTS
