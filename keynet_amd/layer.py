@@ -271,6 +271,9 @@ class KeyedLayer(nn.Module):
         W = self.W
         xt = x_affine.t()
         dev = xt.device if xt.is_cuda else None
+        if xt.shape[1] == 0:
+            # an empty batch (a rank whose shard of a small batch is empty) decides nothing: the layer stays 'auto' and calibrates on the first batch that holds an image
+            return W.torchdot(xt, relu=relu, exact=True).t()
         rec = dict(layer=self._repr, decided='exact', reason='no matrix-core path for this operator')
         if not self.mfma_capable(dev):
             self._exact = True

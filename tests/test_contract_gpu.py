@@ -324,3 +324,17 @@ def test_reserve_workspace_makes_a_first_dense_call_capturable():
         torch.cuda.synchronize()
     ref = W.torchdot(x, exact=False)
     assert torch.equal(y, ref)
+
+
+def test_an_empty_first_batch_decides_nothing(golden):
+    """A rank whose shard of a small batch is empty calls the key-net with zero images before it has seen any: the layers whose contract is still 'auto' must not calibrate
+    on nothing (it used to raise from max() of an empty tensor) -- they return the empty block and decide on the first batch that holds an image."""
+    z = golden('mini_tiled_stochastic.npz')
+    knet = kio.keynet_from_arrays(z, recalibrate=True)
+    x = torch.as_tensor(z['x_cipher']).to(dev())
+    assert knet.contract_report()['undecided']
+    y0 = knet.forward_linear(x[:0])
+    assert tuple(y0.shape) == (0, 11) and knet.contract_report()['undecided']
+    y = knet.forward_linear(x)
+    assert not knet.contract_report()['undecided'] and y.shape[0] == x.shape[0]
+    assert tuple(knet.forward_linear(x[:0]).shape) == (0, 11)
