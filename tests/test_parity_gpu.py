@@ -1915,3 +1915,20 @@ def test_a_batch_too_large_for_32_bit_offsets_runs_in_passes(golden):
             assert torch.equal(y, one)
     finally:
         del knet.MAX_BLOCK_ELEMENTS
+
+
+@pytest.mark.parametrize('name', ['mini_tiled_permutation.npz', 'mini_tiled_stochastic.npz', 'lenet_perm.npz'])
+def test_graph_capture_at_any_batch_size(golden, name):
+    """KeyedModel.capture on batches of 1 / 37 / 128 / 300 images (the eager forward pads a tiled-conv key-net's odd batch to whole tiles; a capture records the batch as it is):
+    the replayed graph returns the eager logits bit for bit, on the captured input and on other data of the same shape."""
+    z = golden(name)
+    knet = kio.keynet_from_arrays(z)
+    rng = np.random.RandomState(0)
+    big = torch.as_tensor(z['x_cipher'][rng.randint(0, z['x_cipher'].shape[0], size=300)].astype(np.float32)).to(dev())
+    for n in (1, 37, 128, 300):
+        x = big[:n]
+        eager = knet.forward_linear(x)
+        replay = knet.capture(x)
+        assert torch.equal(replay(x).clone(), eager), n
+        other = big[300 - n:]
+        assert torch.equal(replay(other).clone(), knet.forward_linear(other)), n
